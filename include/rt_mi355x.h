@@ -1,0 +1,270 @@
+/*
+ * rt_mi355x.h -- C ABI of librt_mi355x.so, the MI355X (gfx950) replacement for the
+ * per-pixel render loop of Roia2529/RayTracing-folder (RayTracingFinal / RayTracingProj13).
+ *
+ * The reference has no C ABI of its own: its boundary is a set of C++ abstract classes plus
+ * globals plus three free functions.  Every entry point below names
+ * the reference interface it replaces (paths relative to /root/reference;
+ * FIN = RayTracingFinal/RayTracingFinal, P13 = RayTracingProj13/RayTracingProj13).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types.
+ *   - every function returns RT_OK (0) or a negative rt_status; it never throws.
+ *     rt_last_error() returns a thread-local message for the last failure.
+ *   - "host" pointers are ordinary process memory; "dev" pointers are HIP device pointers
+ *     (e.g. torch.Tensor.data_ptr() of a cuda tensor).
+ *   - images are row-major, row 0 = top of the image (FIN/include/scene.h:540-656).
+ *   - there is NO CPU fallback: calls that need the GPU return RT_ERR_NO_DEVICE when no
+ *     gfx950 device is visible.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef int rt_status;
+#define RT_OK               0
+#define RT_ERR_ARG         -1   /* bad argument (null pointer, out-of-range index, ...)   */
+#define RT_ERR_STATE       -2   /* call not allowed in this state (e.g. job still live)  */
+#define RT_ERR_NO_DEVICE   -3   /* no HIP device / not gfx950                            */
+#define RT_ERR_DEVICE      -4   /* a HIP call failed (message has the HIP error string)  */
+#define RT_ERR_IO          -5   /* file could not be read / parsed                       */
+#define RT_ERR_LIMIT       -6   /* input exceeds a documented limit                      */
+
+/* ---- scene records (all little-endian, packed exactly as declared) --------------------- */
+
+/* object kinds: the reference's Object subclasses, FIN/include/objects.h:21,79,124 */
+#define RT_OBJ_NONE   0
+#define RT_OBJ_SPHERE 1
+#define RT_OBJ_PLANE  2
+#define RT_OBJ_MESH   3
+
+/* One scene-graph node = the reference's Node (+ its Transformation base),
+ * FIN/include/scene.h:224-262,438-514.  Matrices are column-major float[9] exactly like
+ * cyMatrix3f::data (FIN/include/cyMatrix.h:290-296).  Nodes are listed parent-before-child
+ * in the depth-first order TraceNode visits them (FIN/main.cpp:108-130); node 0 is the root
+ * (parent = -1).  100 bytes. */
+typedef struct rt_node {
+    float   tm[9];      /* Transformation::tm  */
+    float   itm[9];     /* Transformation::itm */
+    float   pos[3];     /* Transformation::pos */
+    int32_t parent;     /* index of parent node, -1 for the root */
+    int32_t obj_type;   /* RT_OBJ_*                              */
+    int32_t mesh;       /* mesh index for RT_OBJ_MESH, else -1   */
+    int32_t material;   /* index into materials, -1 = none       */
+} rt_node;
+
+/* BVH node in the reference's 28-byte layout, FIN/include/cyBVH.h:187-200:
+ * data bit31 = leaf; leaf: bits28-30 = count-1, bits0-27 = offset into elements;
+ * internal: bits0-30 = index of first child (second child = first+1).  Root = node 1. */
+typedef struct rt_bvh_node {
+    float    box[6];
+    uint32_t data;
+} rt_bvh_node;
+
+/* MtlBlinn parameter block, FIN/include/materials.h:377-383 (88 bytes). */
+typedef struct rt_blinn {
+    float diffuse[3];
+    float specular[3];
+    float reflection[3];
+    float refraction[3];
+    float emission[3];
+    float absorption[3];
+    float glossiness;
+    float ior;
+    float reflection_glossiness;
+    float refraction_glossiness;
+} rt_blinn;
+
+/* lights, FIN/include/lights.h:30-174 */
+#define RT_LIGHT_AMBIENT 0
+#define RT_LIGHT_DIRECT  1
+#define RT_LIGHT_POINT   2
+typedef struct rt_light {
+    int32_t type;
+    float   intensity[3];
+    float   position[3];    /* point light            */
+    float   direction[3];   /* direct light (unit)    */
+    float   size;           /* point light disc size  */
+} rt_light;
+
+/* Camera, FIN/include/scene.h:518-536; dir and up already orthonormalised the way
+ * LoadScene does it (FIN/xmlload.cpp:124-127). */
+typedef struct rt_camera {
+    float   pos[3], dir[3], up[3];
+    float   fov, focaldist, dof;
+    int32_t width, height;
+} rt_camera;
+
+/* 24-byte photon, FIN/include/cyPhotonMap.h:47-65 (wire format of the reference's .dat dump,
+ * FIN/main.cpp:398-400). */
+typedef struct rt_photon {
+    float    position[3];
+    float    power;
+    uint8_t  color[3];
+    uint8_t  plane_and_dirz;   /* bits0-1 split plane, bit3 = direction z is negative */
+    int16_t  dir_x, dir_y;
+} rt_photon;
+
+/* shading semantics: which snapshot's MtlBlinn::Shade / primitives to follow */
+#define RT_SHADE_FIN 0   /* FIN/main.cpp:516-708 (+ FIN primitives, two-sided triangles)      */
+#define RT_SHADE_P13 1   /* P13/main.cpp:485-756 (+ P13 primitives, back-face-culled tris)    */
+
+/* The reference's compile-time #defines (FIN/main.cpp:19-32, FIN/include/lights.h:16-18,
+ * FIN/include/materials.h:20-25, FIN/main.cpp:699) as one runtime block.
+ * rt_params_default() fills the FIN values. */
+typedef struct rt_params {
+    int32_t  min_sample;         /* MIN_SAMPLE 4                                    */
+    int32_t  max_sample;         /* MAX_SAMPLE 8                                    */
+    float    threshold;          /* THRESHOLD 1e-3 (variance gate); <0 = never      */
+    int32_t  bounce;             /* BOUNCE 4                                        */
+    int32_t  hemisphere_sample;  /* HEMISPHERE_SAMPLE 30 (result discarded in FIN)  */
+    int32_t  knn_k;              /* EstimateIrradiance<400>                         */
+    float    knn_radius;         /* radius = 1                                      */
+    int32_t  shade_model;        /* RT_SHADE_*                                      */
+    int32_t  shadow_samples;     /* MIN_SHADOW_SAMPLES 4 (identical rays at size 0) */
+    uint32_t seed;               /* counter-RNG seed for stochastic features        */
+    double   gamma;              /* #define gamma 2.2 (a double literal)            */
+    int32_t  reserved[4];
+} rt_params;
+
+/* Which tiles of the image this call renders.  Tiles are tile_w x tile_h pixels, numbered
+ * row-major over the image; this call renders tiles first, first+stride, ... (< total).
+ * first=0, stride=1 renders the whole image.  Replaces pixelIterator (FIN/main.cpp:65-85). */
+typedef struct rt_tile_range {
+    int32_t tile_w, tile_h;
+    int32_t first, stride;
+} rt_tile_range;
+
+/* per-job statistics (rays by class, traversal work, kernel time) */
+typedef struct rt_stats {
+    uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract;
+    uint64_t instance_visits;       /* leaf-object transforms applied            */
+    uint64_t bvh_nodes_visited;
+    uint64_t tris_tested;
+    uint64_t photon_queries;
+    uint64_t photons_visited;
+    uint64_t pixels;
+    uint64_t samples;
+    double   ms_trace;              /* sum of HIP-event durations: trace+shade kernels   */
+    double   ms_gather;             /* photon gather kernels                              */
+    double   ms_resolve;            /* resolve kernels                                    */
+    double   ms_total;              /* wall time of the job on its stream (events)        */
+    uint64_t launches_trace, launches_gather, launches_resolve;
+} rt_stats;
+
+typedef struct rt_scene rt_scene;   /* opaque */
+typedef struct rt_job   rt_job;     /* opaque */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int          rt_abi_version(void);
+const char  *rt_last_error(void);
+/* number of usable gfx950 devices (0 when none); never fails */
+int          rt_device_count(void);
+void         rt_params_default(rt_params *p);
+
+/* ---- scene: replaces the global singletons rootNode/materials/lights/objList/photonmap
+ *      (FIN/main.cpp:36-49) ------------------------------------------------------------- */
+rt_status rt_scene_create(rt_scene **out);
+void      rt_scene_destroy(rt_scene *s);
+
+/* Node tree as LoadScene builds it (FIN/xmlload.cpp:65-132,168-261). */
+rt_status rt_scene_set_nodes(rt_scene *s, const rt_node *nodes, int32_t n);
+/* One TriObj (FIN/include/objects.h:124-303): cyTriMesh arrays V/F/VN/FN
+ * (FIN/include/cyTriMesh.h:104-111) and its cyBVH node/element arrays
+ * (FIN/include/cyBVH.h:202-203).  f/fn are 3 indices per face.  nodes[0] is unused. */
+rt_status rt_scene_set_mesh(rt_scene *s, int32_t mesh,
+                            const float *v, int32_t nv,
+                            const uint32_t *f, int32_t nf,
+                            const float *vn, int32_t nvn, const uint32_t *fn,
+                            const rt_bvh_node *nodes, int32_t nnodes,
+                            const uint32_t *elements);
+rt_status rt_scene_set_materials(rt_scene *s, const rt_blinn *m, int32_t n);
+rt_status rt_scene_set_lights(rt_scene *s, const rt_light *l, int32_t n);
+/* environment / background colour (FIN/include/scene.h:406-434; textures: not yet) */
+rt_status rt_scene_set_environment(rt_scene *s, const float env_rgb[3], const float bg_rgb[3]);
+/* Balanced photon array exactly as PhotonMap::photons after PrepareForIrradianceEstimation
+ * (FIN/include/cyPhotonMap.h:196-218): photons[0] unused, photons[1..n_stored] heap-ordered.
+ * n_stored = 0 clears the map (photon term contributes 0). */
+rt_status rt_scene_set_photons(rt_scene *s, const rt_photon *photons, uint32_t n_stored);
+
+/* Host-side loader with the reference's XML/OBJ schema (FIN/xmlload.cpp:65-554,
+ * FIN/include/cyTriMesh.h:263-547, FIN/include/objects.h:137-145).  OBJ names resolve
+ * relative to the XML file's directory.  Fills nodes/meshes/materials/lights/camera. */
+rt_status rt_scene_load_xml(rt_scene *s, const char *path);
+rt_status rt_scene_get_camera(const rt_scene *s, rt_camera *out);
+
+/* Export the host-side arrays (so a caller can hand the same bytes to another consumer).
+ * Pass NULL pointers to query counts only. */
+rt_status rt_scene_counts(const rt_scene *s, int32_t *n_nodes, int32_t *n_meshes,
+                          int32_t *n_materials, int32_t *n_lights, uint32_t *n_photons);
+rt_status rt_scene_get_nodes(const rt_scene *s, rt_node *out, int32_t cap);
+rt_status rt_scene_get_materials(const rt_scene *s, rt_blinn *out, int32_t cap);
+rt_status rt_scene_get_lights(const rt_scene *s, rt_light *out, int32_t cap);
+rt_status rt_scene_mesh_counts(const rt_scene *s, int32_t mesh, int32_t *nv, int32_t *nf,
+                               int32_t *nvn, int32_t *nnodes);
+rt_status rt_scene_get_mesh(const rt_scene *s, int32_t mesh, float *v, uint32_t *f, float *vn,
+                            uint32_t *fn, rt_bvh_node *nodes, uint32_t *elements);
+
+/* ---- host helpers that mirror reference host code --------------------------------------- */
+/* cyBVH build with MeanSplit (FIN/include/cyBVH.h:122-142,295-328) as TriObj::Load calls it
+ * (maxElementsPerNode = 4, FIN/include/objects.h:143).  nodes_out needs room for 2*nf+1
+ * nodes; returns the node count (including the unused node 0) in *nnodes. */
+rt_status rt_bvh_build(const float *v, int32_t nv, const uint32_t *f, int32_t nf,
+                       int32_t max_per_leaf, rt_bvh_node *nodes_out, int32_t *nnodes,
+                       uint32_t *elements_out);
+/* PhotonMap::PrepareForIrradianceEstimation (FIN/include/cyPhotonMap.h:196-284):
+ * in = photons[1..n] unordered (in[0] unused), out = balanced heap order (out[0] = in[0]).
+ * `in` is permuted in place exactly like the reference permutes its vector. */
+rt_status rt_photon_balance(rt_photon *in, uint32_t n, rt_photon *out);
+
+/* ---- rendering: replaces BeginRender/StopRender + RenderPixel + RenderImage progress
+ *      (FIN/main.cpp:202-344,984-1012; FIN/include/scene.h:586-589) ---------------------- */
+/* Asynchronous: returns after the job's worker thread has started.  Output buffers are
+ * caller-owned host memory of width*height pixels (rgb8: 3 bytes per pixel) and may be read
+ * at any time (partially filled while the job runs, as in the reference). */
+rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt_params *p,
+                          const rt_tile_range *tiles, int device,
+                          uint8_t *rgb8, float *z, uint8_t *count, rt_job **out);
+/* Same, but the outputs are DEVICE pointers on `device` and the work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the library's own stream); only this call's tiles are
+ * written.  Synchronous with respect to enqueueing; completion follows stream order unless
+ * `sync` is non-zero. */
+rt_status rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_params *p,
+                                 const rt_tile_range *tiles, int device, void *hip_stream,
+                                 uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
+                                 int sync, rt_stats *stats_out);
+int       rt_render_progress(rt_job *j);      /* pixels finished so far (monotonic)       */
+rt_status rt_render_stop(rt_job *j);          /* cooperative cancel (StopRender)          */
+rt_status rt_render_wait(rt_job *j);          /* join; returns the job's final status     */
+rt_status rt_job_stats(rt_job *j, rt_stats *out);
+void      rt_job_destroy(rt_job *j);
+
+/* ---- single-stage entry points (used by parity tests and by hosts that keep their own
+ *      RenderPixel): inputs/outputs are HOST arrays, the work runs on the GPU -------------- */
+/* n closest-hit queries = n calls of TraceNode(rootNode, ray, hit) (FIN/main.cpp:94-130).
+ * rays: n x 6 floats (p, dir).  Outputs per ray: hit flag, z, p[3], N[3], node index, front. */
+rt_status rt_trace_rays(rt_scene *s, int shade_model, int device, const float *rays, int64_t n,
+                        uint8_t *hit, float *z, float *p, float *N, int32_t *node,
+                        uint8_t *front);
+/* n irradiance estimates = n calls of photonmap.EstimateIrradiance<k>(irr, dir, radius, pos,
+ * &normal, 1, CONSTANT) (FIN/include/cyPhotonMap.h:288-336).  pos, normal: n x 3 floats;
+ * outputs irr, dir: n x 3 floats. */
+rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, float radius,
+                                 const float *pos, const float *normal, int64_t n,
+                                 float *irr, float *dir);
+/* n shades of primary-ray samples = Trace + MtlBlinn::Shade(ray, hit, lights, bounce, 0)
+ * (FIN/main.cpp:294-297): rays n x 6; outputs hit flag, rgb (linear, before gamma), z. */
+rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, const float *rays,
+                        int64_t n, uint8_t *hit, float *rgb, float *z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

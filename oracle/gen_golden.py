@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""gen_golden.py -- TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz.
+
+Runs oracle/_ref/ref_harness_{fin,p13} (the reference's own headers compiled where they lie
+under /root/reference, see oracle/Makefile) on seeded inputs and stores inputs + the
+reference's outputs as small fixtures.  Only runs in the build container (the reference tree
+does not exist on the GPU box); the fixtures are committed.
+
+    python oracle/gen_golden.py            # regenerate everything
+"""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("RT_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+HARNESS = {m: os.path.join(ROOT, "oracle", "_ref", f"ref_harness_{m}") for m in ("fin", "p13")}
+TEAPOT = os.path.join(REF, "RayTracingFinal", "RayTracingFinal", "data", "teapot.obj")
+
+HITREC = np.dtype([("hit", "<i4"), ("z", "<f4"), ("p", "<f4", 3), ("N", "<f4", 3), ("front", "<i4")])
+BVHNODE = np.dtype([("box", "<f4", 6), ("data", "<u4")])
+PHOTON = np.dtype([("position", "<f4", 3), ("power", "<f4"), ("color", "u1", 3),
+                   ("plane_and_dirz", "u1"), ("dir_x", "<i2"), ("dir_y", "<i2")])
+assert HITREC.itemsize == 36 and BVHNODE.itemsize == 28 and PHOTON.itemsize == 24
+
+
+def run(model, cmd, payload, *extra):
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(payload)
+        subprocess.run([HARNESS[model], cmd, fin, fout, *extra], check=True,
+                       stdout=subprocess.DEVNULL)
+        with open(fout, "rb") as f:
+            return f.read()
+
+
+def rays_with_z(rng, n, spread=3.0):
+    """rays: origins in a cube, directions of mixed length; some axis-parallel; z0 mostly BIG."""
+    o = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d *= rng.choice([0.25, 1.0, 1.0, 4.0], size=(n, 1)).astype(np.float32)
+    # aim most rays roughly at the origin so that they hit something
+    aim = rng.random(n) < 0.7
+    tgt = rng.uniform(-0.9, 0.9, (n, 3)).astype(np.float32)
+    d[aim] = (tgt[aim] - o[aim]) * rng.uniform(0.2, 2.0, (aim.sum(), 1)).astype(np.float32)
+    # exact zeros in direction components
+    zc = rng.random(n) < 0.05
+    d[zc, rng.integers(0, 3, zc.sum())] = 0.0
+    # origins inside the unit sphere
+    ins = rng.random(n) < 0.15
+    o[ins] = rng.uniform(-0.5, 0.5, (ins.sum(), 3)).astype(np.float32)
+    z0 = np.full(n, 1.0e30, np.float32)
+    sm = rng.random(n) < 0.2
+    z0[sm] = rng.uniform(0.1, 5.0, sm.sum()).astype(np.float32)
+    return np.concatenate([o, d, z0[:, None]], axis=1).astype(np.float32)
+
+
+def gen_prims(model):
+    rng = np.random.default_rng(101)
+    n = 4096
+    r = rays_with_z(rng, n)
+    out = run(model, "prims", struct.pack("<i", n) + r.tobytes())
+    rec = np.frombuffer(out, HITREC)
+    np.savez_compressed(os.path.join(GOLD, f"prims_{model}.npz"), rays=r,
+                        sphere=rec[:n], plane=rec[n:])
+
+
+def gen_box():
+    rng = np.random.default_rng(102)
+    n = 4096
+    lo = rng.uniform(-2, 1, (n, 3)).astype(np.float32)
+    hi = lo + rng.uniform(0, 2, (n, 3)).astype(np.float32)
+    flat = rng.random(n) < 0.1
+    hi[flat, 2] = lo[flat, 2]                       # zero-thickness boxes (axis-aligned triangles)
+    r = rays_with_z(rng, n)
+    tmax = np.where(rng.random(n) < 0.8, np.float32(1.0e30), rng.uniform(0.1, 6, n)).astype(np.float32)
+    rec = np.concatenate([lo, hi, r[:, :6], tmax[:, None]], axis=1).astype(np.float32)
+    out = run("fin", "box", struct.pack("<i", n) + rec.tobytes())
+    np.savez_compressed(os.path.join(GOLD, "box.npz"), rec=rec, hit=np.frombuffer(out, "<i4"))
+
+
+def parse_mesh(out):
+    nv, nf, nvn, nnodes = struct.unpack_from("<4i", out, 0)
+    off = 16
+    def take(dt, count):
+        nonlocal off
+        a = np.frombuffer(out, dt, count, off)
+        off += a.nbytes
+        return a
+    v = take("<f4", nv * 3).reshape(nv, 3)
+    f = take("<u4", nf * 3).reshape(nf, 3)
+    vn = take("<f4", nvn * 3).reshape(nvn, 3)
+    fn = take("<u4", nf * 3).reshape(nf, 3)
+    nodes = take(BVHNODE, nnodes)
+    elements = take("<u4", nf)
+    hits = np.frombuffer(out, HITREC, -1, off)
+    return v, f, vn, fn, nodes, elements, hits
+
+
+def write_tri_obj(path, v, f, vn, fn):
+    """own OBJ export of the loaded teapot arrays (already fan-triangulated by the reference's
+    loader); %.9g round-trips float32 exactly."""
+    with open(path, "w") as o:
+        o.write("# teapot mesh arrays as loaded by the reference's cyTriMesh (triangulated)\n")
+        for p in v:
+            o.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for p in vn:
+            o.write("vn %.9g %.9g %.9g\n" % tuple(p))
+        for a, b in zip(f, fn):
+            o.write("f %d//%d %d//%d %d//%d\n" % (a[0] + 1, b[0] + 1, a[1] + 1, b[1] + 1, a[2] + 1, b[2] + 1))
+
+
+def gen_mesh(model):
+    rng = np.random.default_rng(103)
+    n = 4096
+    # teapot bounds are roughly [-8,9] x [-5,5] x [0,8]
+    o = rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+    tgt = np.stack([rng.uniform(-8, 9, n), rng.uniform(-5, 5, n), rng.uniform(0, 8, n)], 1).astype(np.float32)
+    d = tgt - o
+    nrm = rng.random(n) < 0.5
+    d[nrm] /= np.linalg.norm(d[nrm], axis=1, keepdims=True)
+    ins = rng.random(n) < 0.1                       # origins inside the teapot's box
+    o[ins] = tgt[ins]
+    d[ins] = rng.normal(size=(ins.sum(), 3))
+    z0 = np.full(n, 1.0e30, np.float32)
+    sm = rng.random(n) < 0.1
+    z0[sm] = rng.uniform(0.3, 1.2, sm.sum())
+    r = np.concatenate([o, d.astype(np.float32), z0[:, None]], 1).astype(np.float32)
+    out = run(model, "mesh", struct.pack("<i", n) + r.tobytes(), TEAPOT)
+    v, f, vn, fn, nodes, elements, hits = parse_mesh(out)
+    assert len(hits) == n
+    np.savez_compressed(os.path.join(GOLD, f"mesh_teapot_{model}.npz"), rays=r, hits=hits,
+                        **({"v": v, "f": f, "vn": vn, "fn": fn, "nodes": nodes, "elements": elements}
+                           if model == "fin" else {}))
+    if model == "fin":
+        write_tri_obj(os.path.join(GOLD, "teapot_tri.obj"), v, f, vn, fn)
+        # the triangulated export must load back to identical arrays through the reference loader
+        out2 = run(model, "mesh", struct.pack("<i", 0), os.path.join(GOLD, "teapot_tri.obj"))
+        v2, f2, vn2, fn2, nodes2, el2, _ = parse_mesh(out2)
+        assert (v2 == v).all() and (f2 == f).all() and (vn2 == vn).all() and (fn2 == fn).all()
+        assert nodes2.tobytes() == nodes.tobytes() and (el2 == elements).all()
+    print(f"mesh[{model}]: nv={len(v)} nf={len(f)} nvn={len(vn)} nnodes={len(nodes)} hits={int(hits['hit'].sum())}")
+
+
+NODE_OPS = {
+    # (kind, a0..a3): 0 scale xyz, 1 rotate axis xyz + degrees, 2 translate xyz -- Cornell scene.xml
+    "box_group": [(2, 0, 0, 12, 0)],
+    "wall_bottom": [(0, 32, 32, 32, 0), (2, 0, 0, -12, 0)],
+    "wall_top": [(0, 32, 32, 32, 0), (1, 1, 0, 0, 180), (2, 0, 0, 12, 0)],
+    "wall_back": [(0, 32, 32, 32, 0), (1, 1, 0, 0, 90), (2, 0, 20, 0, 0)],
+    "wall_left": [(0, 32, 32, 32, 0), (1, 0, 1, 0, 90), (2, -15, 0, 0, 0)],
+    "wall_right": [(0, 32, 32, 32, 0), (1, 0, 1, 0, -90), (2, 15, 0, 0, 0)],
+    "teapot": [(0, 0.8, 0.8, 0.8, 0), (1, 0, 0, 1, -30), (2, 2, 5, 0, 0)],
+    "sphere1": [(0, 4, 4, 4, 0), (2, 8, -6, 4, 0)],
+    "identity": [],
+    "skew": [(0, 1, 2, 3, 0), (1, 1, 1, 0, 33), (2, 0.5, -1, 2, 0), (1, 0, 2, 1, -70)],
+}
+
+
+def gen_node():
+    rng = np.random.default_rng(104)
+    n = 256
+    res = {}
+    for name, ops in NODE_OPS.items():
+        rays = np.concatenate([rng.uniform(-30, 30, (n, 3)), rng.normal(size=(n, 3))], 1).astype(np.float32)
+        hits = np.concatenate([rng.uniform(-1, 1, (n, 3)), rng.normal(size=(n, 3))], 1).astype(np.float32)
+        payload = struct.pack("<i", len(ops))
+        for op in ops:
+            payload += struct.pack("<i4f", int(op[0]), *[float(x) for x in op[1:]])
+        payload += struct.pack("<i", n) + rays.tobytes() + hits.tobytes()
+        out = np.frombuffer(run("fin", "node", payload), "<f4")
+        res[name + "_ops"] = np.array(ops, np.float64).reshape(len(ops), 5)
+        res[name + "_tm"] = out[0:9]
+        res[name + "_itm"] = out[9:18]
+        res[name + "_pos"] = out[18:21]
+        res[name + "_rays"] = rays
+        res[name + "_hits"] = hits
+        res[name + "_rays_local"] = out[21:21 + 6 * n].reshape(n, 6)
+        res[name + "_hits_parent"] = out[21 + 6 * n:21 + 12 * n].reshape(n, 6)
+    np.savez_compressed(os.path.join(GOLD, "node.npz"), **res)
+
+
+def gen_misc():
+    rng = np.random.default_rng(105)
+    n = 512
+    rgb = rng.uniform(-0.2, 1.3, (n, 3)).astype(np.float32)
+    rgb[:8] = np.array([[0, 0, 0], [1, 1, 1], [0.999999, 0.5, 0.25], [1 / 255, 2 / 255, 254 / 255],
+                        [0.0039, 0.00393, 1.004], [-1, 2, 0.5], [0.2, 0.4, 0.6], [255, 1e9, -1e9]], np.float32)
+    out = run("fin", "misc", struct.pack("<i", n) + rgb.tobytes())
+    h2 = np.frombuffer(out, "<f4", n, 0)
+    h3 = np.frombuffer(out, "<f4", n, 4 * n)
+    c24 = np.frombuffer(out, "u1", 3 * n, 8 * n).reshape(n, 3)
+    np.savez_compressed(os.path.join(GOLD, "misc.npz"), rgb=rgb, halton2=h2, halton3=h3, color24=c24)
+
+
+def synth_photons(rng, n):
+    """photons on the floor/walls of a 20 x 20 x 10 room with a dense patch (so that some
+    queries find far more than k photons and some far fewer)."""
+    pos = np.empty((n, 3), np.float32)
+    which = rng.integers(0, 3, n)
+    u, v = rng.uniform(-10, 10, n), rng.uniform(-10, 10, n)
+    dense = rng.random(n) < 0.35
+    u[dense] = rng.normal(2.0, 1.2, dense.sum())
+    v[dense] = rng.normal(-3.0, 1.2, dense.sum())
+    pos[:, 0] = np.where(which == 1, -10, u)
+    pos[:, 1] = np.where(which == 2, 10, np.where(which == 1, u, v))
+    pos[:, 2] = np.where(which == 0, 0, np.abs(v) * 0.5)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pw = rng.uniform(0.05, 1.0, (n, 3)) * rng.uniform(0.5, 30, (n, 1))
+    return np.concatenate([pos, d, pw], 1).astype(np.float32)
+
+
+def gen_photon(tag, npho, k, radius, nq, seed):
+    rng = np.random.default_rng(seed)
+    ph = synth_photons(rng, npho)
+    scale = np.float32(4 * np.pi / npho)
+    qi = rng.integers(0, npho, nq)
+    qpos = ph[qi, :3] + rng.normal(0, 0.05, (nq, 3)).astype(np.float32)
+    qn = rng.normal(size=(nq, 3))
+    qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+    # most normals face the stored directions (dir . N < 0 accepted)
+    flip = (ph[qi, 3:6] * qn).sum(1) > 0
+    qn[flip & (rng.random(nq) < 0.8)] *= -1
+    q = np.concatenate([qpos, qn], 1).astype(np.float32)
+    payload = (struct.pack("<i", npho) + ph.tobytes() + struct.pack("<fif", scale, k, radius) +
+               struct.pack("<i", nq) + q.tobytes())
+    out = run("fin", "photon", payload)
+    off = 0
+    packed = np.frombuffer(out, PHOTON, npho, off); off += npho * 24
+    balanced = np.frombuffer(out, PHOTON, npho + 1, off); off += (npho + 1) * 24
+    half = struct.unpack_from("<i", out, off)[0]; off += 4
+    dec = np.frombuffer(out, "<f4", npho * 6, off).reshape(npho, 6); off += npho * 24
+    res = np.frombuffer(out, "<f4", nq * 6, off).reshape(nq, 6)
+    np.savez_compressed(os.path.join(GOLD, f"photon_{tag}.npz"), photons_in=ph, scale=scale, k=k,
+                        radius=np.float32(radius), queries=q, packed=packed, balanced=balanced,
+                        half=half, decoded=dec, result=res)
+    nz = int((res[:, :3].sum(1) > 0).sum())
+    print(f"photon[{tag}]: n={npho} k={k} r={radius} half={half} queries with light: {nz}/{nq}")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    for m in ("fin", "p13"):
+        if not os.path.exists(HARNESS[m]):
+            sys.exit(f"{HARNESS[m]} missing: run `make -C oracle` in the build container first")
+    gen_prims("fin")
+    gen_prims("p13")
+    gen_box()
+    gen_mesh("fin")
+    gen_mesh("p13")
+    gen_node()
+    gen_misc()
+    gen_photon("k400", 12000, 400, 1.0, 384, 106)
+    gen_photon("k50", 3001, 50, 1.5, 256, 107)
+    gen_photon("k8", 64, 8, 4.0, 64, 108)
+    print("fixtures written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,295 @@
+"""orc.py -- TEST INFRASTRUCTURE ONLY: ctypes binding of oracle/liboracle.so (rt_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+
+# numpy mirrors of the POD records in include/rt_mi355x.h
+NODE = np.dtype([("tm", "<f4", 9), ("itm", "<f4", 9), ("pos", "<f4", 3), ("parent", "<i4"),
+                 ("obj_type", "<i4"), ("mesh", "<i4"), ("material", "<i4")])
+BVHNODE = np.dtype([("box", "<f4", 6), ("data", "<u4")])
+BLINN = np.dtype([("diffuse", "<f4", 3), ("specular", "<f4", 3), ("reflection", "<f4", 3),
+                  ("refraction", "<f4", 3), ("emission", "<f4", 3), ("absorption", "<f4", 3),
+                  ("glossiness", "<f4"), ("ior", "<f4"), ("reflection_glossiness", "<f4"),
+                  ("refraction_glossiness", "<f4")])
+LIGHT = np.dtype([("type", "<i4"), ("intensity", "<f4", 3), ("position", "<f4", 3),
+                  ("direction", "<f4", 3), ("size", "<f4")])
+PHOTON = np.dtype([("position", "<f4", 3), ("power", "<f4"), ("color", "u1", 3),
+                   ("plane_and_dirz", "u1"), ("dir_x", "<i2"), ("dir_y", "<i2")])
+HIT = np.dtype([("z", "<f4"), ("p", "<f4", 3), ("N", "<f4", 3), ("node", "<i4"), ("front", "<i4")])
+assert (NODE.itemsize, BVHNODE.itemsize, BLINN.itemsize, LIGHT.itemsize, PHOTON.itemsize,
+        HIT.itemsize) == (100, 28, 88, 44, 24, 36)
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov", C.c_float), ("focaldist", C.c_float), ("dof", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("min_sample", C.c_int32), ("max_sample", C.c_int32), ("threshold", C.c_float),
+                ("bounce", C.c_int32), ("hemisphere_sample", C.c_int32), ("knn_k", C.c_int32),
+                ("knn_radius", C.c_float), ("shade_model", C.c_int32),
+                ("shadow_samples", C.c_int32), ("seed", C.c_uint32), ("gamma", C.c_double),
+                ("reserved", C.c_int32 * 4)]
+
+
+def default_params(**kw):
+    """FIN defaults (FIN/main.cpp:19-32)."""
+    p = Params(min_sample=4, max_sample=8, threshold=1e-3, bounce=4, hemisphere_sample=30,
+               knn_k=400, knn_radius=1.0, shade_model=0, shadow_samples=4, seed=20171203, gamma=2.2)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("nv", C.c_int32), ("f", C.c_void_p), ("nf", C.c_int32),
+                ("vn", C.c_void_p), ("nvn", C.c_int32), ("fn", C.c_void_p),
+                ("nodes", C.c_void_p), ("nnodes", C.c_int32), ("elements", C.c_void_p)]
+
+
+class _Scene(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_int32), ("meshes", C.c_void_p),
+                ("n_meshes", C.c_int32), ("materials", C.c_void_p), ("n_materials", C.c_int32),
+                ("lights", C.c_void_p), ("n_lights", C.c_int32), ("photons", C.c_void_p),
+                ("n_photons", C.c_uint32), ("env", C.c_float * 3), ("bg", C.c_float * 3)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays_primary", "rays_shadow", "rays_reflect",
+                                          "rays_refract", "box_tests", "tri_tests", "node_visits",
+                                          "photon_queries", "photons_visited")]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", HERE, "liboracle.so"], check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orc_halton.restype = C.c_float
+        _lib.orc_halton.argtypes = [C.c_int, C.c_int]
+        _lib.orc_shadow.restype = C.c_float
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Mesh:
+    def __init__(self, v, f, vn, fn, nodes, elements):
+        self.v = _c(v, np.float32).reshape(-1, 3)
+        self.f = _c(f, np.uint32).reshape(-1, 3)
+        self.vn = _c(vn, np.float32).reshape(-1, 3)
+        self.fn = _c(fn, np.uint32).reshape(-1, 3)
+        self.nodes = _c(nodes, BVHNODE)
+        self.elements = _c(elements, np.uint32)
+
+    def c(self):
+        return _Mesh(_p(self.v), len(self.v), _p(self.f), len(self.f), _p(self.vn), len(self.vn),
+                     _p(self.fn), _p(self.nodes), len(self.nodes), _p(self.elements))
+
+
+class Scene:
+    """Holds the numpy arrays alive and exposes an orc_scene."""
+
+    def __init__(self, nodes, meshes=(), materials=None, lights=None, photons=None,
+                 env=(0, 0, 0), bg=(0, 0, 0)):
+        self.nodes = _c(nodes, NODE)
+        self.meshes = list(meshes)
+        self.materials = _c(materials if materials is not None else np.zeros(0, BLINN), BLINN)
+        self.lights = _c(lights if lights is not None else np.zeros(0, LIGHT), LIGHT)
+        self.photons = _c(photons, PHOTON) if photons is not None else np.zeros(0, PHOTON)
+        self._cm = (_Mesh * max(1, len(self.meshes)))(*[m.c() for m in self.meshes])
+        self.c = _Scene(_p(self.nodes), len(self.nodes), C.cast(self._cm, C.c_void_p),
+                        len(self.meshes), _p(self.materials), len(self.materials),
+                        _p(self.lights), len(self.lights), _p(self.photons),
+                        max(0, len(self.photons) - 1), (C.c_float * 3)(*env), (C.c_float * 3)(*bg))
+
+
+def halton(i, base):
+    return lib().orc_halton(int(i), int(base))
+
+
+def color24(rgb):
+    rgb = _c(rgb, np.float32).reshape(-1, 3)
+    out = np.zeros((len(rgb), 3), np.uint8)
+    for i in range(len(rgb)):
+        lib().orc_color24(_p(rgb[i]), _p(out[i]))
+    return out
+
+
+def _prim(fn, model, rays, z0):
+    rays = _c(rays, np.float32).reshape(-1, 6)
+    n = len(rays)
+    hits = np.zeros(n, HIT)
+    hit = np.zeros(n, np.int32)
+    hits["z"] = z0
+    hits["front"] = 1
+    hits["node"] = -1
+    for i in range(n):
+        hit[i] = fn(int(model), _p(rays[i]), C.c_void_p(hits[i:i + 1].ctypes.data))
+    return hit, hits
+
+
+def sphere_intersect(model, rays, z0):
+    return _prim(lib().orc_sphere_intersect, model, rays, z0)
+
+
+def plane_intersect(model, rays, z0):
+    return _prim(lib().orc_plane_intersect, model, rays, z0)
+
+
+def box_intersect(box, ray, tmax):
+    box, ray = _c(box, np.float32), _c(ray, np.float32)
+    return lib().orc_box_intersect(_p(box), _p(ray), C.c_float(tmax))
+
+
+def mesh_intersect(model, mesh, rays, z0):
+    cm = mesh.c()
+    return _prim(lambda m, r, h: lib().orc_mesh_intersect(m, C.byref(cm), r, h), model, rays, z0)
+
+
+def to_node_coords(node, rays):
+    node = _c(node, NODE).reshape(1)
+    rays = _c(rays, np.float32).reshape(-1, 6)
+    out = np.zeros_like(rays)
+    for i in range(len(rays)):
+        lib().orc_to_node_coords(_p(node), _p(rays[i]), _p(out[i]))
+    return out
+
+
+def from_node_coords(node, pN):
+    node = _c(node, NODE).reshape(1)
+    pN = _c(pN, np.float32).reshape(-1, 6)
+    out = np.zeros_like(pN)
+    h = np.zeros(1, HIT)
+    for i in range(len(pN)):
+        h["p"][0] = pN[i, :3]
+        h["N"][0] = pN[i, 3:]
+        lib().orc_from_node_coords(_p(node), _p(h))
+        out[i, :3], out[i, 3:] = h["p"][0], h["N"][0]
+    return out
+
+
+def trace(scene, model, rays):
+    rays = _c(rays, np.float32).reshape(-1, 6)
+    hits = np.zeros(len(rays), HIT)
+    hit = np.zeros(len(rays), np.int32)
+    for i in range(len(rays)):
+        hit[i] = lib().orc_trace(C.byref(scene.c), int(model), _p(rays[i]),
+                                 C.c_void_p(hits[i:i + 1].ctypes.data))
+    return hit, hits
+
+
+def shade_rays(scene, params, rays):
+    """Trace + Shade(ray, hit, lights, BOUNCE) per ray -> (hit flags, linear rgb, z)."""
+    rays = _c(rays, np.float32).reshape(-1, 6)
+    n = len(rays)
+    rgb = np.zeros((n, 3), np.float32)
+    hit = np.zeros(n, np.uint8)
+    z = np.full(n, 1.0e30, np.float32)
+    h = np.zeros(1, HIT)
+    for i in range(n):
+        if lib().orc_trace(C.byref(scene.c), params.shade_model, _p(rays[i]), _p(h)):
+            hit[i] = 1
+            z[i] = h["z"][0]
+            lib().orc_shade(C.byref(scene.c), C.byref(params), _p(rays[i]), _p(h),
+                            params.bounce, _p(rgb[i]))
+    return hit, rgb, z
+
+
+def photon_pack(pos, dirn, power):
+    pos, dirn, power = (_c(a, np.float32).reshape(-1, 3) for a in (pos, dirn, power))
+    out = np.zeros(len(pos), PHOTON)
+    for i in range(len(pos)):
+        lib().orc_photon_pack(_p(pos[i]), _p(dirn[i]), _p(power[i]), C.c_void_p(out[i:i + 1].ctypes.data))
+    return out
+
+
+def photon_decode(photons):
+    photons = _c(photons, PHOTON)
+    d = np.zeros((len(photons), 3), np.float32)
+    pw = np.zeros((len(photons), 3), np.float32)
+    for i in range(len(photons)):
+        ptr = C.c_void_p(photons[i:i + 1].ctypes.data)
+        lib().orc_photon_direction(ptr, _p(d[i]))
+        lib().orc_photon_power(ptr, _p(pw[i]))
+    return d, pw
+
+
+def photon_balance(photons_1based):
+    """photons_1based: array of n+1 records (index 0 unused).  Returns the balanced array."""
+    a = _c(photons_1based, PHOTON).copy()
+    out = np.zeros_like(a)
+    lib().orc_photon_balance(_p(a), C.c_uint32(len(a) - 1), _p(out))
+    return out
+
+
+def estimate_irradiance(balanced, k, radius, pos, normal):
+    balanced = _c(balanced, PHOTON)
+    pos, normal = (_c(a, np.float32).reshape(-1, 3) for a in (pos, normal))
+    irr = np.zeros_like(pos)
+    d = np.zeros_like(pos)
+    for i in range(len(pos)):
+        lib().orc_estimate_irradiance(_p(balanced), C.c_uint32(len(balanced) - 1), int(k),
+                                      C.c_float(radius), _p(pos[i]), _p(normal[i]), _p(irr[i]), _p(d[i]))
+    return irr, d
+
+
+def bvh_build(v, f, max_per_leaf=4):
+    v = _c(v, np.float32).reshape(-1, 3)
+    f = _c(f, np.uint32).reshape(-1, 3)
+    nodes = np.zeros(2 * len(f) + 2, BVHNODE)
+    el = np.zeros(len(f), np.uint32)
+    n = lib().orc_bvh_build(_p(v), _p(f), len(f), int(max_per_leaf), _p(nodes), _p(el))
+    return nodes[:n].copy(), el
+
+
+def primary_ray(cam, x, y, j):
+    r = np.zeros(6, np.float32)
+    lib().orc_primary_ray(C.byref(cam), int(x), int(y), int(j), _p(r))
+    return r
+
+
+def render(scene, cam, params, x0=0, y0=0, x1=None, y1=None):
+    w, h = cam.width, cam.height
+    x1 = w if x1 is None else x1
+    y1 = h if y1 is None else y1
+    rgb = np.zeros((h, w, 3), np.uint8)
+    z = np.zeros((h, w), np.float32)
+    cnt = np.zeros((h, w), np.uint8)
+    lib().orc_render(C.byref(scene.c), C.byref(cam), C.byref(params), int(x0), int(y0), int(x1),
+                     int(y1), _p(rgb), _p(z), _p(cnt))
+    return rgb, z, cnt
+
+
+def counters_reset():
+    lib().orc_counters_reset()
+
+
+def counters():
+    c = Counters()
+    lib().orc_counters_get(C.byref(c))
+    return {n: getattr(c, n) for n, _ in Counters._fields_}

@@ -1,0 +1,300 @@
+// ref_harness.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Drives the REFERENCE's own code -- compiled from the headers/sources where they lie under
+// /root/reference (nothing is copied) -- to produce golden vectors that pin oracle/rt_oracle.c.
+// Built by oracle/Makefile into oracle/_ref/ (git-ignored).  Runs only in the build container.
+//
+// What can be built: scene.h, scene.cpp (Box::IntersectRay), objects.h (Sphere, Plane, TriObj +
+// cyTriMesh OBJ loader + cyBVH), cyPhotonMap.h, cyColor.h/cyPoint.h/cyMatrix.h.
+// What cannot: main.cpp (TraceNode, Shade, RenderPixel, GenLight::Shadow) -- it textually
+// includes viewport.cpp, which needs <GL/glut.h>, absent from this image.  No stand-in header is
+// written for it; those functions stay "parity unpinned" (DESIGN.md).
+//
+// The three Object subclasses declare a GLUT-drawing virtual (ViewportDisplay) that only
+// viewport.cpp defines, so their vtables are never emitted.  The harness is therefore linked as
+// an executable with --unresolved-symbols=ignore-all and only ever makes class-qualified
+// (non-virtual) calls, e.g. obj.Sphere::IntersectRay(...).
+//
+// usage: ref_harness <command> <in.bin> <out.bin> [path]
+// All files are raw little-endian arrays; layouts are documented next to each command and
+// mirrored by oracle/gen_golden.py.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <vector>
+#include <string>
+#include <iostream>
+#include <algorithm>
+#include <cmath>
+
+#include "scene.h"
+#include "objects.h"
+#include "cyPhotonMap.h"
+
+// the reference declares these as globals in main.cpp; objects.h has `extern` declarations only
+Sphere theSphere;
+Plane thePlane;
+
+static std::vector<char> slurp(const char *path)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    fseek(fp, 0, SEEK_END); long n = ftell(fp); fseek(fp, 0, SEEK_SET);
+    std::vector<char> b(n);
+    if (n && fread(b.data(), 1, n, fp) != (size_t)n) { fprintf(stderr, "short read\n"); exit(2); }
+    fclose(fp);
+    return b;
+}
+struct Out {
+    FILE *fp;
+    explicit Out(const char *p) { fp = fopen(p, "wb"); if (!fp) { fprintf(stderr, "cannot write %s\n", p); exit(2); } }
+    ~Out() { fclose(fp); }
+    template <class T> void put(const T &v) { fwrite(&v, sizeof(T), 1, fp); }
+    void bytes(const void *p, size_t n) { fwrite(p, 1, n, fp); }
+};
+
+struct HitRec { int32_t hit; float z; float p[3]; float N[3]; int32_t front; };
+static HitRec rec(bool h, const HitInfo &hi)
+{
+    HitRec r; memset(&r, 0, sizeof r);
+    r.hit = h; r.z = hi.z;
+    if (h) { r.p[0] = hi.p.x; r.p[1] = hi.p.y; r.p[2] = hi.p.z; r.N[0] = hi.N.x; r.N[1] = hi.N.y; r.N[2] = hi.N.z; r.front = hi.front; }
+    return r;
+}
+
+// in: int32 n; n x {float ray[6]; float z0}   out: n x HitRec (sphere), n x HitRec (plane)
+static int cmd_prims(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    int32_t n = *(int32_t *)b.data();
+    const float *d = (const float *)(b.data() + 4);
+    Out o(out);
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < n; i++) {
+            Ray r(Point3(d[7 * i], d[7 * i + 1], d[7 * i + 2]), Point3(d[7 * i + 3], d[7 * i + 4], d[7 * i + 5]));
+            HitInfo hi; hi.Init(); hi.z = d[7 * i + 6];
+            bool h = pass == 0 ? theSphere.Sphere::IntersectRay(r, hi) : thePlane.Plane::IntersectRay(r, hi);
+            o.put(rec(h, hi));
+        }
+    return 0;
+}
+
+// in: int32 n; n x {float box[6]; float ray[6]; float tmax}   out: n x int32
+static int cmd_box(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    int32_t n = *(int32_t *)b.data();
+    const float *d = (const float *)(b.data() + 4);
+    Out o(out);
+    for (int i = 0; i < n; i++) {
+        const float *q = d + 13 * i;
+        Box bx(q);
+        Ray r(Point3(q[6], q[7], q[8]), Point3(q[9], q[10], q[11]));
+        int32_t h = bx.IntersectRay(r, q[12]);
+        o.put(h);
+    }
+    return 0;
+}
+
+// mesh <rays.bin> <out.bin> <file.obj>
+// in: int32 n; n x {float ray[6]; float z0}
+// out: int32 nv,nf,nvn,nnodes(with node 0); v[nv*3] f[nf*3] vn[nvn*3] fn[nf*3]
+//      nodes[nnodes] x {float box[6]; uint32 data}; elements[nf]; then n x HitRec
+static int cmd_mesh(const char *in, const char *out, const char *objpath)
+{
+    TriObj *tobj = new TriObj;
+    if (!tobj->Load(objpath, false)) { fprintf(stderr, "load failed\n"); return 3; }
+    // TriObj::bvh is private: rebuild an identical one through the public class (deterministic build)
+    cyBVHTriMesh bvh;
+    bvh.SetMesh(tobj, 4);
+    std::vector<unsigned> ids; ids.push_back(bvh.GetRootNodeID());
+    unsigned maxid = 1;
+    const unsigned *ebase = nullptr;
+    for (size_t k = 0; k < ids.size(); k++) {
+        unsigned id = ids[k];
+        if (id > maxid) maxid = id;
+        if (bvh.IsLeafNode(id)) {
+            const unsigned *e = bvh.GetNodeElements(id);
+            if (!ebase || e < ebase) ebase = e;
+        } else { ids.push_back(bvh.GetFirstChildNode(id)); ids.push_back(bvh.GetSecondChildNode(id)); }
+    }
+    int32_t nv = tobj->NV(), nf = tobj->NF(), nvn = tobj->NVN(), nnodes = maxid + 1;
+    Out o(out);
+    o.put(nv); o.put(nf); o.put(nvn); o.put(nnodes);
+    for (int i = 0; i < nv; i++) { o.put(tobj->V(i).x); o.put(tobj->V(i).y); o.put(tobj->V(i).z); }
+    for (int i = 0; i < nf; i++) for (int k = 0; k < 3; k++) { uint32_t x = tobj->F(i).v[k]; o.put(x); }
+    for (int i = 0; i < nvn; i++) { o.put(tobj->VN(i).x); o.put(tobj->VN(i).y); o.put(tobj->VN(i).z); }
+    for (int i = 0; i < nf; i++) for (int k = 0; k < 3; k++) { uint32_t x = tobj->FN(i).v[k]; o.put(x); }
+    for (int id = 0; id < nnodes; id++) {
+        float box[6] = {0, 0, 0, 0, 0, 0}; uint32_t data = 0;
+        if (id >= 1) {
+            memcpy(box, bvh.GetNodeBounds(id), sizeof box);
+            if (bvh.IsLeafNode(id)) {
+                uint32_t cnt = bvh.GetNodeElementCount(id);
+                uint32_t off = (uint32_t)(bvh.GetNodeElements(id) - ebase);
+                data = 0x80000000u | ((cnt - 1) << 28) | off;
+            } else data = bvh.GetFirstChildNode(id);
+        }
+        o.bytes(box, sizeof box); o.put(data);
+    }
+    for (int i = 0; i < nf; i++) { uint32_t e = ebase[i]; o.put(e); }
+    std::vector<char> b = slurp(in);
+    int32_t n = *(int32_t *)b.data();
+    const float *d = (const float *)(b.data() + 4);
+    for (int i = 0; i < n; i++) {
+        Ray r(Point3(d[7 * i], d[7 * i + 1], d[7 * i + 2]), Point3(d[7 * i + 3], d[7 * i + 4], d[7 * i + 5]));
+        HitInfo hi; hi.Init(); hi.z = d[7 * i + 6];
+        bool h = tobj->TriObj::IntersectRay(r, hi);
+        o.put(rec(h, hi));
+    }
+    return 0;
+}
+
+// in: int32 nops; nops x {int32 kind(0 scale,1 rotate,2 translate); float a[4]}  (rotate: axis xyz + degrees)
+//     int32 n; n x {float ray[6]}; n x {float p[3], N[3]}
+// out: float tm[9], itm[9], pos[3]; n x float ray_local[6]; n x {float p[3], N[3]}
+static int cmd_node(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    const char *c = b.data();
+    int32_t nops = *(int32_t *)c; c += 4;
+    Node node;
+    for (int i = 0; i < nops; i++) {
+        int32_t kind = *(int32_t *)c; c += 4;
+        const float *a = (const float *)c; c += 16;
+        if (kind == 0) node.Scale(a[0], a[1], a[2]);
+        else if (kind == 1) { Point3 s(a[0], a[1], a[2]); s.Normalize(); node.Rotate(s, a[3]); }   // xmlload.cpp LoadTransform
+        else node.Translate(Point3(a[0], a[1], a[2]));
+    }
+    int32_t n = *(int32_t *)c; c += 4;
+    const float *rays = (const float *)c; c += (size_t)n * 24;
+    const float *hits = (const float *)c;
+    Out o(out);
+    o.bytes(node.GetTransform().data, 36);
+    o.bytes(node.GetInverseTransform().data, 36);
+    o.bytes(&node.GetPosition().x, 12);
+    for (int i = 0; i < n; i++) {
+        Ray r(Point3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), Point3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]));
+        Ray l = node.ToNodeCoords(r);
+        o.put(l.p.x); o.put(l.p.y); o.put(l.p.z); o.put(l.dir.x); o.put(l.dir.y); o.put(l.dir.z);
+    }
+    for (int i = 0; i < n; i++) {
+        HitInfo hi; hi.Init();
+        hi.p = Point3(hits[6 * i], hits[6 * i + 1], hits[6 * i + 2]);
+        hi.N = Point3(hits[6 * i + 3], hits[6 * i + 4], hits[6 * i + 5]);
+        node.FromNodeCoords(hi);
+        o.put(hi.p.x); o.put(hi.p.y); o.put(hi.p.z); o.put(hi.N.x); o.put(hi.N.y); o.put(hi.N.z);
+    }
+    return 0;
+}
+
+// in: int32 n; n x float rgb[3]    out: n x float halton2, n x float halton3 (index i), n x uint8 rgb[3]
+static int cmd_misc(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    int32_t n = *(int32_t *)b.data();
+    const float *d = (const float *)(b.data() + 4);
+    Out o(out);
+    for (int i = 0; i < n; i++) o.put(Halton(i, 2));
+    for (int i = 0; i < n; i++) o.put(Halton(i, 3));
+    for (int i = 0; i < n; i++) {
+        Color24 c24 = (Color24)Color(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        o.put(c24.r); o.put(c24.g); o.put(c24.b);
+    }
+    return 0;
+}
+
+struct PM : public cy::PhotonMap {
+    std::vector<Photon> &vec() { return photons; }
+    int half() const { return halfStoredPhotons; }
+};
+
+template <int K> static void estimate(const PM &pm, float radius, const float *q, float *res)
+{
+    Color irr; Point3 dir;
+    Point3 N(q[3], q[4], q[5]);
+    pm.EstimateIrradiance<K>(irr, dir, radius, Point3(q[0], q[1], q[2]), &N, 1.f, cy::PhotonMap::FILTER_TYPE_CONSTANT);
+    res[0] = irr.r; res[1] = irr.g; res[2] = irr.b; res[3] = dir.x; res[4] = dir.y; res[5] = dir.z;
+}
+
+// in: int32 np; np x {float pos[3], dir[3], power[3]}; float scale; int32 k; float radius;
+//     int32 nq; nq x {float pos[3], normal[3]}
+// out: np x 24B packed photons (after AddPhoton + ScalePhotonPowers(scale), before balancing);
+//      (np+1) x 24B balanced array (index 0 unused); int32 halfStoredPhotons;
+//      np x float decoded dir[3] + power rgb[3] of the packed photons; nq x float {irr[3], dir[3]}
+static int cmd_photon(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    const char *c = b.data();
+    int32_t np = *(int32_t *)c; c += 4;
+    const float *ph = (const float *)c; c += (size_t)np * 36;
+    float scale = *(float *)c; c += 4;
+    int32_t k = *(int32_t *)c; c += 4;
+    float radius = *(float *)c; c += 4;
+    int32_t nq = *(int32_t *)c; c += 4;
+    const float *q = (const float *)c;
+    PM pm;
+    pm.AllocatePhotons(np);
+    for (int i = 0; i < np; i++) {
+        const float *p = ph + 9 * i;
+        pm.AddPhoton(Point3(p[0], p[1], p[2]), Point3(p[3], p[4], p[5]), Color(p[6], p[7], p[8]));
+    }
+    // AddPhoton leaves bits 0-2 of planeAndDirZ uninitialised (a stack Photon); zero them so the
+    // dump is reproducible -- SetPlane overwrites bits 0-1 for every internal node anyway.
+    {
+        std::vector<cy::PhotonMap::Photon> &v = pm.vec();
+        for (size_t i = 0; i < v.size(); i++) { unsigned char *raw = (unsigned char *)&v[i]; raw[19] &= 0x8; }
+        unsigned char *raw0 = (unsigned char *)&v[0]; memset(raw0, 0, 24);
+    }
+    pm.ScalePhotonPowers(scale);
+    Out o(out);
+    o.bytes(pm.GetPhotons(), (size_t)np * 24);
+    std::vector<float> dec((size_t)np * 6);
+    for (int i = 0; i < np; i++) {
+        Point3 d; Color pw;
+        pm[i].GetDirection(d); pm[i].GetPower(pw);
+        dec[6 * i] = d.x; dec[6 * i + 1] = d.y; dec[6 * i + 2] = d.z; dec[6 * i + 3] = pw.r; dec[6 * i + 4] = pw.g; dec[6 * i + 5] = pw.b;
+    }
+    pm.PrepareForIrradianceEstimation();
+    o.bytes(pm.vec().data(), (size_t)(np + 1) * 24);
+    int32_t half = pm.half();
+    o.put(half);
+    o.bytes(dec.data(), dec.size() * 4);
+    for (int i = 0; i < nq; i++) {
+        float res[6];
+        switch (k) {
+        case 1: estimate<1>(pm, radius, q + 6 * i, res); break;
+        case 8: estimate<8>(pm, radius, q + 6 * i, res); break;
+        case 50: estimate<50>(pm, radius, q + 6 * i, res); break;
+        case 100: estimate<100>(pm, radius, q + 6 * i, res); break;
+        case 200: estimate<200>(pm, radius, q + 6 * i, res); break;
+        case 400: estimate<400>(pm, radius, q + 6 * i, res); break;
+        default: fprintf(stderr, "k=%d not instantiated\n", k); return 4;
+        }
+        o.bytes(res, sizeof res);
+    }
+    return 0;
+}
+
+// time <in.bin> <out.bin>: same input as `photon`; prints seconds spent in the nq queries (k=400)
+static int cmd_time(const char *in, const char *out)
+{
+    (void)out;
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: ref_harness <prims|box|mesh|node|misc|photon> in out [obj]\n"); return 1; }
+    std::string cmd = argv[1];
+    if (cmd == "prims") return cmd_prims(argv[2], argv[3]);
+    if (cmd == "box") return cmd_box(argv[2], argv[3]);
+    if (cmd == "mesh") { if (argc < 5) return 1; return cmd_mesh(argv[2], argv[3], argv[4]); }
+    if (cmd == "node") return cmd_node(argv[2], argv[3]);
+    if (cmd == "misc") return cmd_misc(argv[2], argv[3]);
+    if (cmd == "photon") return cmd_photon(argv[2], argv[3]);
+    if (cmd == "time") return cmd_time(argv[2], argv[3]);
+    fprintf(stderr, "unknown command %s\n", cmd.c_str());
+    return 1;
+}

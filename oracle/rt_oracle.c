@@ -1,0 +1,1172 @@
+/*
+ * rt_oracle.c -- TEST INFRASTRUCTURE ONLY (see rt_oracle.h for the pinning status).
+ *
+ * Plain-C restatement of the reference's render path.  Every function follows the reference
+ * operation by operation (same float expression order, same thresholds, same quirks) and
+ * names the file:line it restates.  FIN = /root/reference/RayTracingFinal/RayTracingFinal,
+ * P13 = /root/reference/RayTracingProj13/RayTracingProj13.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (no FMA contraction, IEEE float).
+ *
+ * Overload notes (C++ -> C): the reference calls pow()/exp() on float arguments with
+ * <math.h>/<cmath> of a C++ standard library in scope, so overload resolution picks the
+ * float versions (std::pow(float,float), exp(float)); pow(float,int) promotes to double.
+ * Those choices are restated explicitly as powf/expf/pow below.
+ */
+#include "rt_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BIGFLOAT 1.0e30f   /* FIN/include/scene.h:56 */
+/* the reference's min/max are macros (FIN/include/scene.h:48-54): NaN-propagating as written */
+#define RMIN(a,b) ((a)<(b)?(a):(b))
+#define RMAX(a,b) ((a)>(b)?(a):(b))
+
+static orc_counters g_cnt;
+void orc_counters_reset(void) { memset(&g_cnt, 0, sizeof g_cnt); }
+void orc_counters_get(orc_counters *out) { *out = g_cnt; }
+
+/* ---- cyPoint3f subset (FIN/include/cyPoint.h:259-350) ---------------------------------- */
+typedef struct { float x, y, z; } v3;
+static v3 V3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+static v3 v3p(const float *p) { return V3(p[0], p[1], p[2]); }
+static v3 vadd(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static v3 vsub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static v3 vmul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static v3 vscale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static v3 vdivs(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+static v3 vneg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+/* Dot = (a*b).Sum() = x+y+z left to right, cyPoint.h:342,303 */
+static float vdot(v3 a, v3 b) { v3 r = vmul(a, b); return r.x + r.y + r.z; }
+static v3 vcross(v3 a, v3 p) { return V3(a.y * p.z - a.z * p.y, a.z * p.x - a.x * p.z, a.x * p.y - a.y * p.x); }
+static float vlen2(v3 a) { return vdot(a, a); }
+static float vlen(v3 a) { return sqrtf(vlen2(a)); }
+static v3 vnorm(v3 a) { return vdivs(a, vlen(a)); }            /* *this /= Length() */
+static void st3(float *o, v3 a) { o[0] = a.x; o[1] = a.y; o[2] = a.z; }
+
+/* Matrix3 * Point3, column-major (FIN/include/cyMatrix.h:542-546) */
+static v3 mmul(const float *d, v3 p)
+{
+    return V3(p.x * d[0] + p.y * d[3] + p.z * d[6],
+              p.x * d[1] + p.y * d[4] + p.z * d[7],
+              p.x * d[2] + p.y * d[5] + p.z * d[8]);
+}
+/* Transformation::TransposeMult (FIN/include/scene.h:254-261): column i dot dir */
+static v3 mtmul(const float *d, v3 dir)
+{
+    return V3(vdot(V3(d[0], d[1], d[2]), dir),
+              vdot(V3(d[3], d[4], d[5]), dir),
+              vdot(V3(d[6], d[7], d[8]), dir));
+}
+
+/* ---- Halton, Color24 -------------------------------------------------------------------- */
+/* FIN/include/scene.h:131-140 */
+float orc_halton(int index, int base)
+{
+    float r = 0;
+    float f = 1.0f / (float)base;
+    for (int i = index; i > 0; i /= base) {
+        r += f * (i % base);
+        f /= (float)base;
+    }
+    return r;
+}
+
+/* Color24(Color): FloatToByte = Clamp(int(r*255)) (FIN/include/cyColor.h:245-246).
+ * int(NaN) is undefined behaviour in the reference; this restatement maps NaN to 0 and
+ * saturates out-of-int-range values (documented deviation). */
+static uint8_t float_to_byte(float r)
+{
+    float s = r * 255;
+    if (!(s == s)) return 0;
+    if (s <= -2147483648.0f) return 0;
+    if (s >= 2147483647.0f) return 255;
+    int v = (int)s;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+void orc_color24(const float rgb[3], uint8_t out[3])
+{
+    out[0] = float_to_byte(rgb[0]); out[1] = float_to_byte(rgb[1]); out[2] = float_to_byte(rgb[2]);
+}
+
+/* ---- primitives -------------------------------------------------------------------------- */
+/* Sphere::IntersectRay, FIN/include/objects.h:24-70 (identical in P13/include/objects.h:23-69).
+ * uvw is not produced (no textures on this path yet). */
+int orc_sphere_intersect(int model, const float ray[6], orc_hit *hit)
+{
+    (void)model;
+    v3 rp = v3p(ray), rd = v3p(ray + 3);
+    int behitted = 0;
+    float a = vdot(rd, rd);
+    float c = vdot(rp, rp) - 1;
+    float b = 2 * vdot(rp, rd);
+    float insqrt = b * b - (4 * a * c);
+    float zero = 0.001f;
+    if (insqrt >= zero) {
+        float t1 = (-b + sqrtf(insqrt)) / (a * 2);
+        float t2 = (-b - sqrtf(insqrt)) / (a * 2);
+        float prez = hit->z;
+        float min_t = t2;
+        if (min_t >= prez) return 0;
+        if (t1 > zero && t2 < zero && t1 < prez) {
+            hit->z = t1;
+            hit->front = 0;
+            behitted = 1;
+            v3 p = vadd(vscale(rd, hit->z), rp);          /* hitinfo.z*ray.dir+ray.p */
+            st3(hit->p, p);
+            st3(hit->N, vnorm(p));
+        } else if (t1 > zero && t2 > zero && t2 < prez) {
+            behitted = 1;
+            hit->z = min_t;
+            hit->front = 1;
+            v3 p = vadd(vscale(rd, hit->z), rp);
+            st3(hit->p, p);
+            st3(hit->N, vnorm(p));
+        }
+    }
+    return behitted;
+}
+
+/* Plane::IntersectRay, FIN/include/objects.h:84-111; the P13 variant flips `front`
+ * (P13/include/objects.h:83-110: N.d < 0 -> front=false). */
+int orc_plane_intersect(int model, const float ray[6], orc_hit *hit)
+{
+    float zero = 0.001f;
+    v3 P = v3p(ray), d = v3p(ray + 3);
+    v3 N = V3(0, 0, 1);
+    float t = -(P.z / d.z);
+    if (t >= zero && t < BIGFLOAT && t < hit->z) {
+        v3 Hitp = vadd(P, vscale(d, t));                   /* P+t*d */
+        if (Hitp.x >= -1 && Hitp.x <= 1 && Hitp.y >= -1 && Hitp.y <= 1) {
+            hit->z = t;
+            st3(hit->p, Hitp);
+            st3(hit->N, N);
+            float nd = vdot(N, d);
+            if (model == RT_SHADE_P13) hit->front = (nd < 0.0f) ? 0 : 1;
+            else                       hit->front = (nd <= 0.0f) ? 1 : 0;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* Box::IntersectRay, FIN/scene.cpp:11-65 */
+int orc_box_intersect(const float box[6], const float ray[6], float t_max)
+{
+    g_cnt.box_tests++;
+    const float *p = ray, *dir = ray + 3;
+    /* IsInside, FIN/include/scene.h:123 */
+    int inside = 1;
+    for (int i = 0; i < 3; i++) if (box[i] > p[i] || box[3 + i] < p[i]) { inside = 0; break; }
+    if (inside) return 1;
+    float tenter = -t_max;
+    float texit = t_max;
+    for (int i = 0; i < 3; i++) {
+        if (dir[i] != 0.0f) {
+            float t0 = (box[i] - p[i]) / dir[i];
+            float t1 = (box[3 + i] - p[i]) / dir[i];
+            if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+            tenter = RMAX(t0, tenter);
+            texit = RMIN(t1, texit);
+        }
+    }
+    return tenter <= texit && texit <= t_max;
+}
+
+static v3 mesh_v(const orc_mesh *m, uint32_t i) { return v3p(m->v + 3 * (size_t)i); }
+static v3 mesh_vn(const orc_mesh *m, uint32_t i) { return v3p(m->vn + 3 * (size_t)i); }
+
+/* TriObj::TriangleArea, FIN/include/objects.h:146-157 */
+static float triangle_area(int i, v3 A, v3 B, v3 C)
+{
+    switch (i) {
+    case 0: return (B.y - A.y) * (C.z - A.z) - (C.y - A.y) * (B.z - A.z);
+    case 1: return (B.x - A.x) * (C.z - A.z) - (C.x - A.x) * (B.z - A.z);
+    default: return (B.x - A.x) * (C.y - A.y) - (C.x - A.x) * (B.y - A.y);
+    }
+}
+
+/* cyTriMesh::GetNormal = Interpolate(faceID, vn, fn, bc), FIN/include/cyTriMesh.h:167,191 */
+static v3 mesh_normal(const orc_mesh *m, uint32_t face, v3 bc)
+{
+    const uint32_t *fn = m->fn + 3 * (size_t)face;
+    return vadd(vadd(vscale(mesh_vn(m, fn[0]), bc.x), vscale(mesh_vn(m, fn[1]), bc.y)),
+                vscale(mesh_vn(m, fn[2]), bc.z));
+}
+
+/* TriObj::IntersectTriangle, FIN/include/objects.h:226-267 (two-sided, bias 1e-3) */
+static int tri_intersect_fin(const orc_mesh *m, const float ray[6], orc_hit *hit, uint32_t face)
+{
+    g_cnt.tri_tests++;
+    v3 rp = v3p(ray), rd = v3p(ray + 3);
+    float bias = 0.001f;
+    const uint32_t *f = m->f + 3 * (size_t)face;
+    v3 A = mesh_v(m, f[0]), B = mesh_v(m, f[1]), C = mesh_v(m, f[2]);
+    v3 N = vnorm(vcross(vsub(B, A), vsub(C, A)));
+    const float dz = vdot(rd, N);
+    if (fabsf(dz) < 1e-7f) return 0;
+    const float pz = vdot(vsub(rp, A), N);
+    const float t = -pz / dz;
+    if (t <= bias) return 0;
+    if (t < hit->z) {
+        int front = (dz <= 0);
+        /* CheckHit(hitSide=HIT_FRONT, front) is always true (objects.h:120-122) */
+        v3 p = vadd(rp, vscale(rd, t));
+        int ignoredAxis;
+        const float abs_nx = fabsf(N.x), abs_ny = fabsf(N.y), abs_nz = fabsf(N.z);
+        if (abs_nx > abs_ny && abs_nx > abs_nz) ignoredAxis = 0;
+        else if (abs_ny > abs_nz) ignoredAxis = 1;
+        else ignoredAxis = 2;
+        const float s = 1.f / triangle_area(ignoredAxis, A, B, C);
+        const float a = triangle_area(ignoredAxis, p, B, C) * s;
+        const float b = triangle_area(ignoredAxis, p, C, A) * s;
+        const float c = 1.f - a - b;
+        if (a < 0 || b < 0 || c < 0) return 0;
+        hit->z = t;
+        st3(hit->p, p);
+        st3(hit->N, mesh_normal(m, face, V3(a, b, c)));    /* NOT normalised */
+        hit->front = front;
+        return 1;
+    }
+    return 0;
+}
+
+/* TriObj::IntersectTriangle, P13/include/objects.h:148-206 (back-face culled, bias 1e-7) */
+static int tri_intersect_p13(const orc_mesh *m, const float ray[6], orc_hit *hit, uint32_t face)
+{
+    g_cnt.tri_tests++;
+    v3 rp = v3p(ray), rd = v3p(ray + 3);
+    float bias = 1e-7f;
+    const uint32_t *f = m->f + 3 * (size_t)face;
+    v3 A = mesh_v(m, f[0]), B = mesh_v(m, f[1]), C = mesh_v(m, f[2]);
+    v3 tN = vnorm(vcross(vsub(B, A), vsub(C, A)));
+    if (vdot(tN, vsub(rp, A)) < bias) return 0;
+    if (vdot(tN, rd) == 0) return 0;
+    float t = vdot(tN, vsub(C, rp)) / vdot(tN, rd);
+    if (t < bias || t >= hit->z || t >= BIGFLOAT) return 0;
+    /* fmax/fabs are the double versions */
+    double maxN = fmax(fabs(tN.x), fabs(tN.y));
+    float maxNf = (float)maxN;                             /* float maxN = fmax(...) */
+    maxNf = (float)fmax(fabs(tN.z), maxNf);
+    v3 P = vadd(rp, vscale(rd, t));
+    float pa[2], pb[2], pc[2], pp[2];
+    if (maxNf == fabs(tN.x)) {
+        pa[0] = A.y; pa[1] = A.z; pb[0] = B.y; pb[1] = B.z; pc[0] = C.y; pc[1] = C.z; pp[0] = P.y; pp[1] = P.z;
+    } else if (maxNf == fabs(tN.y)) {
+        pa[0] = A.x; pa[1] = A.z; pb[0] = B.x; pb[1] = B.z; pc[0] = C.x; pc[1] = C.z; pp[0] = P.x; pp[1] = P.z;
+    } else {
+        pa[0] = A.x; pa[1] = A.y; pb[0] = B.x; pb[1] = B.y; pc[0] = C.x; pc[1] = C.y; pp[0] = P.x; pp[1] = P.y;
+    }
+    /* Point2::Cross: x*p.y - y*p.x (cyPoint.h) */
+#define CR2(ax, ay, bx, by) ((ax) * (by) - (ay) * (bx))
+    float area_tri = CR2(pa[0] - pc[0], pa[1] - pc[1], pb[0] - pc[0], pb[1] - pc[1]);
+    float area_bcp = CR2(pp[0] - pc[0], pp[1] - pc[1], pb[0] - pc[0], pb[1] - pc[1]);
+    float area_acp = CR2(pa[0] - pc[0], pa[1] - pc[1], pp[0] - pc[0], pp[1] - pc[1]);
+#undef CR2
+    float alpha = area_bcp / area_tri;
+    float beta = area_acp / area_tri;
+    float gamma_ = (float)(1.0 - alpha - beta);
+    if (alpha < -bias || beta < -bias || gamma_ < -bias || alpha > 1.0 || beta > 1.0 || gamma_ > 1.0) return 0;
+    v3 PN = mesh_normal(m, face, V3(alpha, beta, gamma_));
+    hit->front = 1;
+    st3(hit->p, vadd(vadd(vscale(A, alpha), vscale(B, beta)), vscale(C, gamma_)));
+    st3(hit->N, vnorm(PN));
+    hit->z = t;
+    return 1;
+}
+
+/* TriObj::TraceBVHNode, FIN/include/objects.h:271-302: depth first, child1 then child2,
+ * box test with t_max = BIGFLOAT (no closest-hit culling). */
+static int trace_bvh_node(int model, const orc_mesh *m, const float ray[6], orc_hit *hit, uint32_t id)
+{
+    const rt_bvh_node *n = &m->nodes[id];
+    g_cnt.node_visits++;
+    int hitted = 0;
+    if (!orc_box_intersect(n->box, ray, BIGFLOAT)) return 0;
+    if (n->data & 0x80000000u) {                           /* IsLeafNode, cyBVH.h:195 */
+        uint32_t count = ((n->data >> 28) & 7u) + 1;       /* ElementCount, cyBVH.h:194 */
+        uint32_t off = n->data & 0x0FFFFFFFu;              /* ElementOffset, cyBVH.h:193 */
+        for (uint32_t i = 0; i < count; i++) {
+            int h = (model == RT_SHADE_P13) ? tri_intersect_p13(m, ray, hit, m->elements[off + i])
+                                            : tri_intersect_fin(m, ray, hit, m->elements[off + i]);
+            if (h) hitted = 1;
+        }
+        return hitted;
+    }
+    uint32_t c = n->data & 0x7FFFFFFFu;                    /* ChildIndex, cyBVH.h:192 */
+    if (trace_bvh_node(model, m, ray, hit, c)) hitted = 1;
+    if (trace_bvh_node(model, m, ray, hit, c + 1)) hitted = 1;
+    return hitted;
+}
+
+int orc_mesh_intersect(int model, const orc_mesh *m, const float ray[6], orc_hit *hit)
+{
+    if (m->nf <= 0 || m->nnodes < 2) return 0;
+    return trace_bvh_node(model, m, ray, hit, 1);          /* GetRootNodeID() == 1 */
+}
+
+/* ---- scene graph ------------------------------------------------------------------------- */
+/* Node::ToNodeCoords, FIN/include/scene.h:502-508 */
+void orc_to_node_coords(const rt_node *n, const float ray[6], float out[6])
+{
+    v3 p = v3p(ray), d = v3p(ray + 3), pos = v3p(n->pos);
+    v3 rp = mmul(n->itm, vsub(p, pos));                    /* TransformTo, scene.h:236 */
+    v3 rd = vsub(mmul(n->itm, vsub(vadd(p, d), pos)), rp);
+    st3(out, rp); st3(out + 3, rd);
+}
+
+/* Node::FromNodeCoords, FIN/include/scene.h:509-513 */
+void orc_from_node_coords(const rt_node *n, orc_hit *hit)
+{
+    v3 p = vadd(mmul(n->tm, v3p(hit->p)), v3p(n->pos));    /* TransformFrom, scene.h:237 */
+    v3 N = vnorm(mtmul(n->itm, v3p(hit->N)));              /* VectorTransformFrom + GetNormalized */
+    st3(hit->p, p); st3(hit->N, N);
+}
+
+/* TraceNode, FIN/main.cpp:108-130 */
+static int trace_node(const orc_scene *s, int model, int idx, const float ray[6], orc_hit *hit)
+{
+    const rt_node *node = &s->nodes[idx];
+    float r[6];
+    orc_to_node_coords(node, ray, r);
+    int h = 0;
+    if (node->obj_type != RT_OBJ_NONE) {
+        int oh = 0;
+        if (node->obj_type == RT_OBJ_SPHERE) oh = orc_sphere_intersect(model, r, hit);
+        else if (node->obj_type == RT_OBJ_PLANE) oh = orc_plane_intersect(model, r, hit);
+        else if (node->obj_type == RT_OBJ_MESH && node->mesh >= 0 && node->mesh < s->n_meshes)
+            oh = orc_mesh_intersect(model, &s->meshes[node->mesh], r, hit);
+        if (oh) {
+            h = 1;
+            hit->node = idx;
+            orc_from_node_coords(node, hit);
+        }
+    }
+    for (int c = idx + 1; c < s->n_nodes; c++) {           /* children in document order */
+        if (s->nodes[c].parent != idx) continue;
+        if (trace_node(s, model, c, r, hit)) {
+            orc_from_node_coords(node, hit);
+            h = 1;
+        }
+    }
+    return h;
+}
+
+static void hit_init(orc_hit *h)
+{
+    /* HitInfo::Init, FIN/include/scene.h:163 */
+    memset(h, 0, sizeof *h);
+    h->z = BIGFLOAT; h->node = -1; h->front = 1;
+}
+
+int orc_trace(const orc_scene *s, int model, const float ray[6], orc_hit *hit)
+{
+    hit_init(hit);
+    if (s->n_nodes <= 0) return 0;
+    return trace_node(s, model, 0, ray, hit);
+}
+
+/* GenLight::Shadow, FIN/main.cpp:499-513 */
+float orc_shadow(const orc_scene *s, int model, const float ray[6], float t_max)
+{
+    float bias = 1e-14f;
+    orc_hit h;
+    g_cnt.rays_shadow++;
+    if (orc_trace(s, model, ray, &h)) {
+        if (h.z > bias && h.z < t_max) return 0.0f;
+    }
+    return 1.0f;
+}
+
+/* Light::Direction: Ambient (0,0,0) lights.h:35; Direct: direction lights.h:51;
+ * Point: (p-position).GetNormalized() lights.h:159 */
+static v3 light_direction(const rt_light *l, v3 p)
+{
+    if (l->type == RT_LIGHT_POINT) return vnorm(vsub(p, v3p(l->position)));
+    if (l->type == RT_LIGHT_DIRECT) return v3p(l->direction);
+    return V3(0, 0, 0);
+}
+
+/* Light::Illuminate.
+ *   Ambient: intensity (FIN/include/lights.h:34)
+ *   Direct : Shadow(Ray(p,-direction)) * intensity, t_max = BIGFLOAT (lights.h:50)
+ *   Point  : FIN/include/lights.h:67-131 -- 4 samples on a disc of radius `size`; with size==0
+ *            every sample ray is position-p exactly (xv1.Length() == 0), the mean is 0 or 1 and
+ *            the 16-sample refinement never runs.  size>0 draws rand() (statistical only).
+ *            P13 variant (P13/include/lights.h:65-91) also collapses to position-p at size 0. */
+void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
+                    const float p_[3], const float N_[3], float out[3])
+{
+    (void)N_;
+    int model = P->shade_model;
+    v3 p = v3p(p_);
+    v3 I = v3p(l->intensity);
+    if (l->type == RT_LIGHT_AMBIENT) { st3(out, I); return; }
+    if (l->type == RT_LIGHT_DIRECT) {
+        float ray[6];
+        st3(ray, p); st3(ray + 3, vneg(v3p(l->direction)));
+        st3(out, vscale(I, orc_shadow(s, model, ray, BIGFLOAT)));   /* Shadow(...) * intensity */
+        return;
+    }
+    v3 position = v3p(l->position);
+    float size = l->size;
+    int ns = P->shadow_samples > 0 ? P->shadow_samples : 4;
+    float shadow = 0.0f;
+    if (model == RT_SHADE_P13) {
+        float shadow_coef = 0.0f;
+        for (int i = 0; i < ns; i++) {
+            float r = orc_halton(i, 2);
+            r = sqrtf(r) * size;
+            float theta = (float)(M_PI * 2.0 * rand() / (float)RAND_MAX);
+            float gam = (float)(M_PI * rand() / (float)RAND_MAX);
+            float dx = r * sinf(gam) * cosf(theta);
+            float dy = r * sinf(gam) * sinf(theta);
+            float dz = r * cosf(gam);
+            v3 newlightPos = vadd(V3(dx, dy, dz), position);
+            float ray[6];
+            st3(ray, p); st3(ray + 3, vsub(newlightPos, p));
+            shadow_coef += orc_shadow(s, model, ray, 1);
+        }
+        v3 avg_shadow = vdivs(vscale(I, shadow_coef), (float)ns);   /* intensity*coef/SAMPLES */
+        float distance = vlen2(vsub(p, position));
+        st3(out, vdivs(avg_shadow, distance));
+        return;
+    }
+    v3 dir = vsub(position, p);
+    v3 xAxis = V3(1, 0, 0), yAxis = V3(0, 1, 0), v1;
+    if (vdot(dir, xAxis) > 0.8) v1 = vcross(yAxis, dir);
+    else v1 = vcross(xAxis, dir);
+    v3 v2 = vcross(v1, dir);
+    v2 = vnorm(v2);
+    v1 = vnorm(v1);
+    for (int i = 0; i < ns; i++) {
+        float random = rand() / (float)RAND_MAX;
+        float rRadius = sqrtf(random) * size;
+        random = rand() / (float)RAND_MAX;
+        float rAngle = (float)(random * (2.0 * M_PI));
+        float xv = (float)(rRadius * cos(rAngle));
+        float yv = (float)(rRadius * sin(rAngle));
+        v3 xv1 = vscale(v1, xv), yv2 = vscale(v2, yv);
+        /* (position + xv1.Length() + yv2.Length()) - p : scalars added to all 3 coords */
+        float lx = vlen(xv1), ly = vlen(yv2);
+        v3 sd = vsub(V3(position.x + lx + ly, position.y + lx + ly, position.z + lx + ly), p);
+        float ray[6];
+        st3(ray, p); st3(ray + 3, sd);
+        shadow += orc_shadow(s, model, ray, 1);
+    }
+    shadow /= (float)ns;
+    if (shadow != 0.0 && shadow != 1.0) {
+        const int nmax = 16;                               /* MAX_SHADOW_SAMPLES */
+        shadow = 0.0f;
+        for (int i = 0; i < nmax; i++) {
+            float random = rand() / (float)RAND_MAX;
+            float rRadius = sqrtf(random) * size;
+            random = rand() / (float)RAND_MAX;
+            float rAngle = (float)(random * (2.0 * M_PI));
+            float xv = (float)(rRadius * cos(rAngle));
+            float yv = (float)(rRadius * sin(rAngle));
+            v3 xv1 = vscale(v1, -xv), yv2 = vscale(v2, -yv);
+            float lx = vlen(xv1), ly = vlen(yv2);
+            v3 sd = vsub(V3(position.x + lx + ly, position.y + lx + ly, position.z + lx + ly), p);
+            float ray[6];
+            st3(ray, p); st3(ray + 3, sd);
+            shadow += orc_shadow(s, model, ray, 1);
+        }
+        shadow /= (float)nmax;
+    }
+    /* intensity * shadow / (p - position).LengthSquared() */
+    st3(out, vdivs(vscale(I, shadow), vlen2(vsub(p, position))));
+}
+
+/* Attenuation, FIN/include/materials.h:60-66 (exp(float) -> expf, see header note) */
+static v3 attenuation(v3 absorption, float l)
+{
+    return V3(expf(-absorption.x * l), expf(-absorption.y * l), expf(-absorption.z * l));
+}
+
+static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3]);
+static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3]);
+
+void orc_shade(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3])
+{
+    if (P->shade_model == RT_SHADE_P13) shade_p13(s, P, ray, h, bounce, out);
+    else shade_fin(s, P, ray, h, bounce, out);
+}
+
+static const rt_blinn *hit_material(const orc_scene *s, const orc_hit *h)
+{
+    static const rt_blinn none = {{0}};
+    int m = s->nodes[h->node].material;
+    if (m < 0 || m >= s->n_materials) return &none;
+    return &s->materials[m];
+}
+
+/* MtlBlinn::Shade, FIN/main.cpp:516-708 */
+static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *hInfo, int bounceCount, float out[3])
+{
+    const rt_blinn *mtl = hit_material(s, hInfo);
+    v3 color = v3p(mtl->emission);                                         /* :517 */
+    const v3 p = v3p(hInfo->p);
+    v3 N = vnorm(v3p(hInfo->N));                                           /* :521-522 */
+    v3 direction = vnorm(vneg(v3p(ray + 3)));                              /* :523-524 */
+    v3 kd = v3p(mtl->diffuse), ks = v3p(mtl->specular);
+    float gloss = mtl->glossiness;
+    v3 reflection = v3p(mtl->reflection), refraction = v3p(mtl->refraction);
+    float ior = mtl->ior;
+    v3 absorption = v3p(mtl->absorption);
+
+    const float coef = s->n_lights == 0 ? 1.0f : 1.0f / s->n_lights;       /* :545 */
+    for (int li = 0; li < s->n_lights; li++) {
+        const rt_light *light = &s->lights[li];
+        float Il[3];
+        orc_illuminate(s, P, light, hInfo->p, (const float *)&N, Il);
+        v3 intensity = vscale(v3p(Il), coef);                              /* :551 */
+        if (hInfo->front) {
+            if (light->type != RT_LIGHT_AMBIENT) {
+                v3 L = vscale(light_direction(light, p), (float)(-1));     /* :556 */
+                L = vnorm(L);
+                v3 H = vnorm(vadd(L, direction));
+                float cosNL = RMAX(0.f, vdot(N, L));
+                float cosNH = RMAX(0.f, vdot(N, H));
+                v3 diffuse = vscale(vmul(kd, intensity), cosNL);           /* :563 */
+                v3 specular = vscale(vscale(vmul(ks, intensity), powf(cosNH, gloss)), cosNL);   /* :564 */
+                color = vadd(color, vadd(diffuse, specular));              /* :566 */
+            } else {
+                orc_illuminate(s, P, light, hInfo->p, (const float *)&N, Il);
+                intensity = v3p(Il);                                       /* :568 */
+                color = vadd(color, vmul(kd, intensity));                  /* :569 */
+            }
+        }
+    }
+
+    /* reflection / refraction set-up, :577-610 */
+    float ein = 1, eout = ior;
+    if (!hInfo->front) { ein = ior; eout = 1; }
+    float eta = ein / eout;
+    v3 Y = vdot(N, direction) > 0.f ? N : vneg(N);
+    const v3 Z = vcross(direction, Y);
+    v3 X = vnorm(vcross(Y, Z));
+    float cosI = vdot(N, direction);
+    float sinI = sqrtf(1 - cosI * cosI);
+    float sinO = RMAX(0.f, RMIN(1.f, sinI * eta));
+    float cosO = sqrtf(1.f - sinO * sinO);
+    v3 tDir = vsub(vscale(vneg(X), sinO), vscale(Y, cosO));                /* -X*sinO - Y*cosO */
+    v3 rDir = vsub(vscale(vscale(N, 2.f), vdot(N, direction)), direction); /* 2.f*N*(N.d) - d */
+    const float C0 = (eta - 1.f) * (eta - 1.f) / ((eta + 1.f) * (eta + 1.f));
+    float rC = C0 + (1.f - C0) * powf(1.f - fabsf(cosI), 5.f);
+    const float tC = 1.f - rC;
+    const int totReflection = (eta * sinI) > 1.001f;                       /* materials.h:20 */
+    const v3 tK = totReflection ? V3(0.f, 0.f, 0.f) : vscale(refraction, tC);
+    const v3 rK = totReflection ? vadd(reflection, refraction) : vadd(reflection, vscale(refraction, rC));
+    const float thr = 0.001f;                                              /* materials.h:21-22 */
+
+    if (bounceCount > 0 && (rK.x > thr || rK.y > thr || rK.z > thr)) {     /* :613-623 */
+        float r[6];
+        st3(r, p); st3(r + 3, vnorm(rDir));
+        orc_hit hh;
+        g_cnt.rays_reflect++;
+        if (orc_trace(s, P->shade_model, r, &hh)) {
+            v3 K = vmul(rK, hh.front ? V3(1.f, 1.f, 1.f) : attenuation(absorption, hh.z));
+            float c[3];
+            shade_fin(s, P, r, &hh, bounceCount - 1, c);
+            color = vadd(color, vmul(K, v3p(c)));
+        }
+    }
+    if (bounceCount > 0 && (tK.x > thr || tK.y > thr || tK.z > thr)) {     /* :625-638 */
+        float r[6];
+        st3(r, p); st3(r + 3, vnorm(tDir));
+        orc_hit hh;
+        g_cnt.rays_refract++;
+        if (orc_trace(s, P->shade_model, r, &hh)) {
+            v3 K = vmul(tK, hh.front ? V3(1.f, 1.f, 1.f) : attenuation(absorption, hh.z));
+            float c[3];
+            shade_fin(s, P, r, &hh, bounceCount - 1, c);
+            color = vadd(color, vmul(K, v3p(c)));
+        } else {
+            color = vadd(color, vmul(tK, v3p(s->env)));                    /* SampleEnvironment, no texture */
+        }
+    }
+    v3 idr = V3(0, 0, 0);
+    if (bounceCount == P->bounce) {
+        /* :642-693 -- HEMISPHERE_SAMPLE rays are traced and shaded, but the result is assigned
+         * to a shadowing inner variable (:676) and the outer idrColor (:668) stays 0, so the
+         * block adds exactly 0.  Not traced here (SURVEY.md section 0 finding 2). */
+    } else {
+        /* :695-705 */
+        float irr[3], dir[3];
+        if (s->n_photons > 0) {
+            orc_estimate_irradiance(s->photons, s->n_photons, P->knn_k, P->knn_radius,
+                                    hInfo->p, (const float *)&N, irr, dir);
+            float theta = vdot(N, vneg(v3p(dir)));
+            theta = (theta > 0.0 ? theta : 0.0f);
+            idr = vadd(idr, vscale(vmul(kd, v3p(irr)), theta));            /* kd * photonrad * theta */
+        }
+    }
+    color = vadd(color, idr);
+    st3(out, color);
+}
+
+/* MtlBlinn::Shade, P13/main.cpp:485-756 (glossiness jitter needs rand(): only the
+ * deterministic reflectionGlossiness == refractionGlossiness == 0 case is restated). */
+static float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   /* P13/main.cpp:98-106 */
+static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *hInfo, int bounceCount, float out[3])
+{
+    const rt_blinn *m = hit_material(s, hInfo);
+    v3 ra_color = V3(0, 0, 0), re_color = V3(0, 0, 0), re_ra_color;
+    v3 ambient_color = V3(0, 0, 0), diffuse_color = V3(0, 0, 0);
+    v3 N = v3p(hInfo->N), Pp = v3p(hInfo->p);
+    v3 Kd = v3p(m->diffuse), Ks = v3p(m->specular);
+    float alpha = m->glossiness;
+    for (int i = 0; i < s->n_lights; i++) {
+        const rt_light *l = &s->lights[i];
+        float Il[3];
+        if (l->type == RT_LIGHT_AMBIENT) {
+            orc_illuminate(s, P, l, hInfo->p, hInfo->N, Il);
+            ambient_color = vadd(ambient_color, vmul(v3p(Il), Kd));                   /* :510 */
+        } else {
+            orc_illuminate(s, P, l, hInfo->p, hInfo->N, Il);
+            v3 I_i = v3p(Il);
+            v3 L = vnorm(vscale(light_direction(l, Pp), (float)-1));
+            v3 V = vnorm(vneg(v3p(ray + 3)));
+            v3 H = vnorm(vadd(L, V));
+            v3 kse = vadd(vscale(Ks, powf(vdot(N, H), alpha)), Kd);                   /* :547 */
+            float theta = vdot(N, L);
+            diffuse_color = vadd(diffuse_color, vmul(vscale(I_i, (theta > 0.0 ? theta : 0.0f)), kse));   /* :551 */
+        }
+    }
+    v3 all = vadd(ambient_color, diffuse_color);                                      /* :622 (idr, cau = 0) */
+    v3 V = vneg(vnorm(v3p(ray + 3)));                                                 /* :632 */
+    if (bounceCount > 0) {                                                            /* :633-663 */
+        float costheta = clampf(vdot(N, V), -1.0f, 1.0f);
+        v3 R = vsub(vscale(N, 2 * costheta), V);
+        float r[6];
+        st3(r, Pp); st3(r + 3, vnorm(R));
+        orc_hit hh;
+        g_cnt.rays_reflect++;
+        if (orc_trace(s, P->shade_model, r, &hh)) {
+            float c[3];
+            shade_p13(s, P, r, &hh, bounceCount - 1, c);
+            re_color = v3p(c);
+        } else re_color = v3p(s->env);
+    }
+    all = vadd(all, vmul(re_color, v3p(m->reflection)));                              /* :665 */
+    if (bounceCount > 0) {                                                            /* :671-751 */
+        N = v3p(hInfo->N);
+        float R0 = 0.0f, re_ratio = 0.0f, ra_ratio = 0.0f;
+        V = vnorm(V);
+        float costheta1 = fabsf(vdot(V, N));
+        float sintheta1 = sqrtf(RMAX(0.0f, 1 - (costheta1 * costheta1)));
+        float n1 = 1.0, n2 = 1.0;
+        if (hInfo->front) n2 = m->ior;
+        else { n1 = m->ior; N = vneg(N); }
+        float ratio_n = n1 / n2;
+        float sintheta2 = ratio_n * sintheta1;
+        orc_hit hh;
+        hit_init(&hh);
+        float absorb = 1.0;
+        if (sintheta2 <= 1.0) {
+            float costheta2 = sqrtf(RMAX(0.0f, 1 - (sintheta2 * sintheta2)));
+            v3 S = vcross(N, vcross(N, V));
+            N = vnorm(N);
+            S = vnorm(S);
+            v3 T = vadd(vscale(vneg(N), costheta2), vscale(S, sintheta2));
+            float r[6];
+            st3(r, Pp); st3(r + 3, T);
+            g_cnt.rays_refract++;
+            if (orc_trace(s, P->shade_model, r, &hh)) {
+                float c[3];
+                shade_p13(s, P, r, &hh, bounceCount - 1, c);
+                ra_color = v3p(c);
+            } else ra_color = v3p(s->env);
+            absorb = expf(-m->absorption[0] * hh.z);                                  /* :728 */
+            R0 = (n1 - n2) / (n1 + n2);
+            R0 = R0 * R0;
+            double tmp = 1.0 - costheta1;
+            re_ratio = (float)(R0 + (1.0 - R0) * pow(tmp, 5.0));
+            ra_ratio = (float)(1.0 - re_ratio);
+        } else re_ratio = 1.0f;
+        re_ra_color = re_color;
+        /* refraction * (ra_ratio*absorb*ra_color + re_ratio*re_ra_color) */
+        all = vadd(all, vmul(v3p(m->refraction),
+                             vadd(vscale(ra_color, ra_ratio * absorb), vscale(re_ra_color, re_ratio))));
+    }
+    st3(out, all);
+}
+
+/* ---- photon map -------------------------------------------------------------------------- */
+/* Photon::SetPower / SetDirection, FIN/include/cyPhotonMap.h:139-156; AddPhoton :184-192
+ * (a fresh Photon's planeAndDirZ is uninitialised in the reference; 0 here). */
+void orc_photon_pack(const float pos[3], const float dir[3], const float pw[3], rt_photon *out)
+{
+    memset(out, 0, sizeof *out);
+    out->position[0] = pos[0]; out->position[1] = pos[1]; out->position[2] = pos[2];
+    out->dir_x = (int16_t)(dir[0] * 0x7FFF);
+    out->dir_y = (int16_t)(dir[1] * 0x7FFF);
+    if (dir[2] > 0) out->plane_and_dirz &= 0x7;
+    else out->plane_and_dirz = 0x8 | (out->plane_and_dirz & 0x7);
+    float power = pw[0];
+    if (power < pw[1]) power = pw[1];
+    if (power < pw[2]) power = pw[2];
+    out->power = power;
+    float c[3] = { pw[0] / power, pw[1] / power, pw[2] / power };
+    orc_color24(c, out->color);
+}
+
+/* Photon::GetDirection, FIN/include/cyPhotonMap.h:158-180 -- including the reference's
+ * `dirX*dirX + dirY-dirY` typo (:162): z is derived from x alone. */
+void orc_photon_direction(const rt_photon *p, float dir[3])
+{
+    int dirX = p->dir_x, dirY = p->dir_y;
+    dir[0] = (float)dirX / (float)0x7FFF;
+    dir[1] = (float)dirY / (float)0x7FFF;
+    int dirXY2 = dirX * dirX + dirY - dirY;
+    if (dirXY2 > 0x3FFF0001) dirXY2 = 0x3FFF0001;
+    int dirZ2 = 0x3FFF0001 - dirXY2;
+    int dirZ = 0;
+    int place = 0x40000000;
+    int remainder = dirZ2;
+    while (place > remainder) place = place >> 2;
+    while (place) {
+        if (remainder >= dirZ + place) {
+            remainder = remainder - dirZ - place;
+            dirZ = dirZ + (place << 1);
+        }
+        dirZ = dirZ >> 1;
+        place = place >> 2;
+    }
+    dir[2] = (float)dirZ / (float)0x7FFF;
+    if (p->plane_and_dirz & 0x8) dir[2] = -dir[2];
+}
+
+/* Photon::GetPower, cyPhotonMap.h:58: color.ToColor()*power, ToColor = c/255.0f */
+void orc_photon_power(const rt_photon *p, float rgb[3])
+{
+    rgb[0] = (p->color[0] / 255.0f) * p->power;
+    rgb[1] = (p->color[1] / 255.0f) * p->power;
+    rgb[2] = (p->color[2] / 255.0f) * p->power;
+}
+
+/* PhotonMap::BalanceSegment, FIN/include/cyPhotonMap.h:222-284 */
+static void balance_segment(rt_photon *ph, rt_photon *bal, v3 boxMin, v3 boxMax,
+                            uint32_t index, uint32_t start, uint32_t end)
+{
+    uint32_t median = 1;
+    while ((4 * median) <= (end - start + 1)) median += median;
+    if ((3 * median) <= (end - start + 1)) { median += median; median += start - 1; }
+    else median = end - median + 1;
+    int axis = 2;
+    v3 boxDif = vsub(boxMax, boxMin);
+    if (boxDif.x > boxDif.y) { if (boxDif.x > boxDif.z) axis = 0; }
+    else if (boxDif.y > boxDif.z) axis = 1;
+    uint32_t left = start, right = end;
+#define SWAP(i, j) do { rt_photon t_ = ph[i]; ph[i] = ph[j]; ph[j] = t_; } while (0)
+    while (right > left) {
+        const float v = ph[right].position[axis];
+        uint32_t i = left - 1;
+        uint32_t j = right;
+        while (ph[++i].position[axis] < v);
+        while (ph[--j].position[axis] > v && j > left);
+        while (i < j) {
+            SWAP(i, j);
+            while (ph[++i].position[axis] < v);
+            while (ph[--j].position[axis] > v && j > left);
+        }
+        SWAP(i, right);
+        if (i >= median) right = i - 1;
+        if (i <= median) left = i + 1;
+    }
+#undef SWAP
+    bal[index] = ph[median];
+    bal[index].plane_and_dirz = (uint8_t)((bal[index].plane_and_dirz & 0x8) | (axis & 0x3));   /* SetPlane :63 */
+    if (median > start) {
+        if (start < median - 1) {
+            v3 tBoxMax = boxMax;
+            ((float *)&tBoxMax)[axis] = bal[index].position[axis];
+            balance_segment(ph, bal, boxMin, tBoxMax, 2 * index, start, median - 1);
+        } else bal[2 * index] = ph[start];
+    }
+    if (median < end) {
+        if (median + 1 < end) {
+            v3 tBoxMin = boxMin;
+            ((float *)&tBoxMin)[axis] = bal[index].position[axis];
+            balance_segment(ph, bal, tBoxMin, boxMax, 2 * index + 1, median + 1, end);
+        } else bal[2 * index + 1] = ph[end];
+    }
+}
+
+/* PhotonMap::PrepareForIrradianceEstimation, cyPhotonMap.h:196-218.  The bounding box loop
+ * starts from photons[0] (the unused slot) exactly like the reference. */
+void orc_photon_balance(rt_photon *in, uint32_t n, rt_photon *out)
+{
+    v3 boxMin = v3p(in[0].position), boxMax = boxMin;
+    for (uint32_t i = 1; i <= n; i++) {
+        const float *q = in[i].position;
+        if (boxMin.x > q[0]) boxMin.x = q[0];
+        if (boxMax.x < q[0]) boxMax.x = q[0];
+        if (boxMin.y > q[1]) boxMin.y = q[1];
+        if (boxMax.y < q[1]) boxMax.y = q[1];
+        if (boxMin.z > q[2]) boxMin.z = q[2];
+        if (boxMax.z < q[2]) boxMax.z = q[2];
+    }
+    memset(out, 0, sizeof(rt_photon) * ((size_t)n + 1));   /* std::vector value-initialises */
+    if (n >= 1) balance_segment(in, out, boxMin, boxMax, 1, 1, n);
+}
+
+typedef struct {
+    v3 pos; const v3 *normal; int maxPhotons; int found;
+    float *dist2; rt_photon *photon;
+    const rt_photon *photons; int half;
+} nearest_t;
+
+/* PhotonMap::LocatePhotons, cyPhotonMap.h:365-440 (normScale == 0 since ellipticity == 1) */
+static void locate_photons(nearest_t *np, const int index)
+{
+    const rt_photon *p = &np->photons[index];
+    g_cnt.photons_visited++;
+    int axis = p->plane_and_dirz & 0x3;
+    if (index < np->half) {
+        float dist = ((const float *)&np->pos)[axis] - p->position[axis];
+        if (dist > 0) {
+            locate_photons(np, 2 * index + 1);
+            if (dist * dist < np->dist2[0]) locate_photons(np, 2 * index);
+        } else {
+            locate_photons(np, 2 * index);
+            if (dist * dist < np->dist2[0]) locate_photons(np, 2 * index + 1);
+        }
+    }
+    v3 dif = vsub(v3p(p->position), np->pos);
+    float dist2 = vlen2(dif);
+    if (dist2 < np->dist2[0]) {
+        if (np->normal) {
+            float d[3];
+            orc_photon_direction(p, d);
+            if (vdot(v3p(d), *np->normal) >= 0) return;
+        }
+        if (np->found < np->maxPhotons) {
+            np->found++;
+            np->dist2[np->found] = dist2;
+            np->photon[np->found] = *p;
+            if (np->found == np->maxPhotons) {
+                int half_found = np->found >> 1;
+                for (int k = half_found; k >= 1; k--) {
+                    int parent = k;
+                    rt_photon tp = np->photon[k];
+                    float td2 = np->dist2[k];
+                    while (parent <= half_found) {
+                        int j = parent + parent;
+                        if (j < np->found && np->dist2[j] < np->dist2[j + 1]) j++;
+                        if (td2 >= np->dist2[j]) break;
+                        np->dist2[parent] = np->dist2[j];
+                        np->photon[parent] = np->photon[j];
+                        parent = j;
+                    }
+                    np->photon[parent] = tp;
+                    np->dist2[parent] = td2;
+                }
+            }
+        } else {
+            int parent = 1;
+            int j = 2;
+            while (j <= np->found) {
+                if (j < np->found && np->dist2[j] < np->dist2[j + 1]) j++;
+                if (dist2 > np->dist2[j]) break;
+                np->dist2[parent] = np->dist2[j];
+                np->photon[parent] = np->photon[j];
+                parent = j;
+                j <<= 1;
+            }
+            np->photon[parent] = *p;
+            np->dist2[parent] = dist2;
+            np->dist2[0] = np->dist2[1];
+        }
+    }
+}
+
+/* PhotonMap::EstimateIrradiance<k>(irr, dir, radius, pos, &normal, 1, CONSTANT),
+ * cyPhotonMap.h:288-336.  halfStoredPhotons = (size-1)/2 - 1 (:217). */
+void orc_estimate_irradiance(const rt_photon *photons, uint32_t n, int k, float radius,
+                             const float pos[3], const float normal[3], float irr[3], float dir[3])
+{
+    irr[0] = irr[1] = irr[2] = 0; dir[0] = dir[1] = dir[2] = 0;
+    g_cnt.photon_queries++;
+    if (n == 0 || k <= 0) return;
+    float *d2 = (float *)malloc(sizeof(float) * ((size_t)k + 1));
+    rt_photon *fp = (rt_photon *)malloc(sizeof(rt_photon) * ((size_t)k + 1));
+    v3 nrm = normal ? v3p(normal) : V3(0, 0, 0);
+    nearest_t np;
+    np.pos = v3p(pos); np.normal = normal ? &nrm : 0; np.maxPhotons = k; np.found = 0;
+    np.dist2 = d2; np.photon = fp; np.photons = photons; np.half = (int)(n / 2) - 1;
+    np.dist2[0] = radius * radius;
+    locate_photons(&np, 1);
+    v3 I = V3(0, 0, 0), D = V3(0, 0, 0);
+    for (int i = 1; i <= np.found; i++) {
+        float pw[3], dd[3];
+        orc_photon_power(&np.photon[i], pw);
+        float filter = 1;
+        I = vadd(I, vscale(v3p(pw), filter));                                 /* irrad += filter*power */
+        orc_photon_direction(&np.photon[i], dd);
+        D = vadd(D, vscale(v3p(dd), filter * np.photon[i].power));            /* dir*(filter*GetMaxPower) */
+    }
+    if (np.found > 0) {
+        float area = (float)M_PI * np.dist2[0];
+        if (area > 0) { const float one_over_area = 1.0f / area; I = vscale(I, one_over_area); }
+        D = vnorm(D);
+    }
+    st3(irr, I); st3(dir, D);
+    free(d2); free(fp);
+}
+
+/* ---- cyBVH build -------------------------------------------------------------------------- */
+typedef struct tnode { struct tnode *c1, *c2; float box[6]; uint32_t count, offset; } tnode;
+
+static void ebounds(const float *v, const uint32_t *f, uint32_t i, float box[6])
+{   /* BVHTriMesh::GetElementBounds, FIN/include/cyBVH.h:356-368 */
+    const uint32_t *fi = f + 3 * (size_t)i;
+    const float *p = v + 3 * (size_t)fi[0];
+    box[0] = box[3] = p[0]; box[1] = box[4] = p[1]; box[2] = box[5] = p[2];
+    for (int j = 1; j < 3; j++) {
+        p = v + 3 * (size_t)fi[j];
+        for (int k = 0; k < 3; k++) {
+            if (box[k] > p[k]) box[k] = p[k];
+            if (box[k + 3] < p[k]) box[k + 3] = p[k];
+        }
+    }
+}
+static float ecenter(const float *v, const uint32_t *f, uint32_t i, int dim)
+{   /* GetElementCenter, cyBVH.h:371-375 */
+    const uint32_t *fi = f + 3 * (size_t)i;
+    return (v[3 * (size_t)fi[0] + dim] + v[3 * (size_t)fi[1] + dim] + v[3 * (size_t)fi[2] + dim]) / 3.0f;
+}
+static void box_init(float b[6]) { b[0] = b[1] = b[2] = 1e30f; b[3] = b[4] = b[5] = -1e30f; }
+static void box_add(float b[6], const float o[6])
+{ for (int i = 0; i < 3; i++) { if (b[i] > o[i]) b[i] = o[i]; if (b[i + 3] < o[i + 3]) b[i + 3] = o[i + 3]; } }
+
+/* MeanSplit, cyBVH.h:295-328 */
+static uint32_t mean_split(const float *v, const uint32_t *f, uint32_t elementCount, uint32_t *ne,
+                           const float *box, uint32_t maxPer)
+{
+    if (elementCount <= maxPer) return 0;
+    float d[3] = { box[3] - box[0], box[4] - box[1], box[5] - box[2] };
+    uint32_t sd[3];
+    sd[0] = d[0] >= d[1] ? (d[0] >= d[2] ? 0 : 2) : (d[1] >= d[2] ? 1 : 2);
+    sd[1] = (sd[0] + 1) % 3;
+    sd[2] = (sd[0] + 2) % 3;
+    if (d[sd[1]] < d[sd[2]]) { uint32_t t = sd[1]; sd[1] = sd[2]; sd[2] = t; }
+    uint32_t child1 = 0;
+    for (int s = 0; s < 3; s++) {
+        uint32_t splitDim = sd[s];
+        float splitPos = 0.5f * (box[splitDim] + box[splitDim + 3]);
+        uint32_t i = 0, j = elementCount;
+        while (i < j) {
+            float center = ecenter(v, f, ne[i], (int)splitDim);
+            if (center <= splitPos) i++;
+            else { j--; uint32_t t = ne[i]; ne[i] = ne[j]; ne[j] = t; }
+        }
+        if (i < elementCount && i > 0) { child1 = i; break; }
+    }
+    return child1;
+}
+
+/* SplitTempNode, cyBVH.h:242-278 (CY_BVH_MAX_ELEMENT_COUNT = 8) */
+static void split_temp(const float *v, const uint32_t *f, uint32_t *elements, tnode *t, uint32_t maxPer)
+{
+    uint32_t *ne = &elements[t->offset];
+    uint32_t c1 = mean_split(v, f, t->count, ne, t->box, maxPer);
+    if (c1 == 0 || c1 >= t->count) {
+        if (t->count > 8) c1 = t->count / 2;
+        else return;
+    }
+    float b1[6], b2[6], eb[6];
+    box_init(b1); box_init(b2);
+    for (uint32_t i = 0; i < c1; i++) { ebounds(v, f, ne[i], eb); box_add(b1, eb); }
+    for (uint32_t i = c1; i < t->count; i++) { ebounds(v, f, ne[i], eb); box_add(b2, eb); }
+    t->c1 = (tnode *)calloc(1, sizeof(tnode));
+    t->c2 = (tnode *)calloc(1, sizeof(tnode));
+    t->c1->count = c1; t->c1->offset = t->offset; memcpy(t->c1->box, b1, sizeof b1);
+    t->c2->count = t->count - c1; t->c2->offset = t->offset + c1; memcpy(t->c2->box, b2, sizeof b2);
+    split_temp(v, f, elements, t->c1, maxPer);
+    split_temp(v, f, elements, t->c2, maxPer);
+}
+static uint32_t tcount(const tnode *t) { return 1 + (t->c1 ? tcount(t->c1) : 0) + (t->c2 ? tcount(t->c2) : 0); }
+/* ConvertTempData, cyBVH.h:281-291 */
+static uint32_t convert_temp(rt_bvh_node *nodes, uint32_t id, const tnode *t, uint32_t childIndex)
+{
+    memcpy(nodes[id].box, t->box, sizeof t->box);
+    if (!t->c1) {
+        nodes[id].data = (t->offset & 0x0FFFFFFFu) | ((t->count - 1) << 28) | 0x80000000u;
+        return childIndex;
+    }
+    nodes[id].data = childIndex & 0x7FFFFFFFu;
+    uint32_t nci = convert_temp(nodes, childIndex, t->c1, childIndex + 2);
+    return convert_temp(nodes, childIndex + 1, t->c2, nci);
+}
+static void tfree(tnode *t) { if (!t) return; tfree(t->c1); tfree(t->c2); free(t); }
+
+/* BVH::Build, cyBVH.h:122-142 */
+int orc_bvh_build(const float *v, const uint32_t *f, int32_t nf, int32_t max_per_leaf,
+                  rt_bvh_node *nodes_out, uint32_t *elements_out)
+{
+    if (nf <= 0) return 0;
+    uint32_t maxPer = (uint32_t)max_per_leaf;
+    if (maxPer > 8) maxPer = 8;
+    for (int32_t i = 0; i < nf; i++) elements_out[i] = (uint32_t)i;
+    float box[6], eb[6];
+    box_init(box);
+    for (int32_t i = 0; i < nf; i++) { ebounds(v, f, (uint32_t)i, eb); box_add(box, eb); }
+    tnode *root = (tnode *)calloc(1, sizeof(tnode));
+    root->count = (uint32_t)nf; root->offset = 0; memcpy(root->box, box, sizeof box);
+    split_temp(v, f, elements_out, root, maxPer);
+    uint32_t n = tcount(root);
+    memset(&nodes_out[0], 0, sizeof(rt_bvh_node));
+    convert_temp(nodes_out, 1, root, 2);
+    tfree(root);
+    return (int)n + 1;
+}
+
+/* ---- RenderPixel -------------------------------------------------------------------------- */
+typedef struct { v3 b; float u, v; float m[9]; } cam_setup;
+
+/* camera set-up in RenderPixel, FIN/main.cpp:205-224 */
+static void camera_setup(const rt_camera *cam, cam_setup *cs)
+{
+    float theta = cam->fov;
+    float l = cam->focaldist;
+    float h = (float)(2 * l * tan(theta / 2 * (M_PI / 180)));
+    float w = h * (float)cam->width / cam->height;
+    v3 b = V3(-w / 2, h / 2, -l);
+    float u = w / cam->width;
+    float v = -h / cam->height;
+    float du = u / 2, dv = v / 2;
+    b.x += du; b.y += dv;
+    v3 up = v3p(cam->up);
+    v3 z_new = vscale(v3p(cam->dir), (float)-1);
+    v3 x_new = vcross(up, z_new);
+    up = vnorm(up); z_new = vnorm(z_new); x_new = vnorm(x_new);
+    cs->b = b; cs->u = u; cs->v = v;
+    cs->m[0] = x_new.x; cs->m[1] = x_new.y; cs->m[2] = x_new.z;      /* Matrix3(x,y,z) = columns */
+    cs->m[3] = up.x; cs->m[4] = up.y; cs->m[5] = up.z;
+    cs->m[6] = z_new.x; cs->m[7] = z_new.y; cs->m[8] = z_new.z;
+}
+
+/* generateSample (FIN/main.cpp:147-162) + ray build (:288-292), dof == 0 */
+static void primary_ray(const rt_camera *cam, const cam_setup *cs, int x, int y, int j, float ray[6])
+{
+    v3 tmp = vadd(V3(x * cs->u, y * cs->v, 0), cs->b);                 /* :235-236 */
+    float sx = orc_halton(j, 2) * cs->u;
+    float sy = cs->v * orc_halton(j, 3);
+    sx += tmp.x; sy += tmp.y;
+    v3 sample = V3(sx, sy, tmp.z);
+    v3 d_campos = V3(0, 0, 0);
+    v3 o = vadd(v3p(cam->pos), d_campos);
+    v3 dir = mmul(cs->m, sample);
+    dir = vsub(dir, d_campos);
+    dir = vnorm(dir);
+    st3(ray, o); st3(ray + 3, dir);
+}
+
+void orc_primary_ray(const rt_camera *cam, int x, int y, int j, float ray[6])
+{
+    cam_setup cs;
+    camera_setup(cam, &cs);
+    primary_ray(cam, &cs, x, y, j, ray);
+}
+
+/* VariantOverThreshold, FIN/main.cpp:164-189 (pow(float,int) -> double) */
+static int variant_over_threshold(const float *list, int n, float threshold)
+{
+    float ninverse = (float)(1.0 / n);
+    float sum[3] = { 0, 0, 0 }, sq[3] = { 0, 0, 0 };
+    for (int i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) {
+            float t = list[3 * i + c];
+            sum[c] += t;
+            sq[c] = (float)((double)sq[c] + pow((double)t, 2));
+        }
+    int over = 0;
+    for (int c = 0; c < 3; c++) {
+        float avg = ninverse * sum[c];
+        float var = (float)((double)(sq[c] * ninverse) + pow((double)avg, 2) - (double)(2 * avg * ninverse * sum[c]));
+        if (var > threshold) over = 1;
+    }
+    return over;
+}
+
+int orc_pixel_samples(const orc_scene *s, const rt_camera *cam, const rt_params *P,
+                      int x, int y, int j0, int j1, float *rgb, uint8_t *hitmask, float *z)
+{
+    cam_setup cs;
+    camera_setup(cam, &cs);
+    int nh = 0;
+    for (int j = j0; j < j1; j++) {
+        float ray[6];
+        primary_ray(cam, &cs, x, y, j, ray);
+        orc_hit h;
+        g_cnt.rays_primary++;
+        hitmask[j - j0] = 0;
+        rgb[3 * (j - j0)] = rgb[3 * (j - j0) + 1] = rgb[3 * (j - j0) + 2] = 0;
+        if (orc_trace(s, P->shade_model, ray, &h)) {
+            orc_shade(s, P, ray, &h, P->bounce, &rgb[3 * (j - j0)]);
+            hitmask[j - j0] = 1;
+            if (z) *z = h.z;
+            nh++;
+        }
+    }
+    return nh;
+}
+
+/* RenderPixel, FIN/main.cpp:202-344 over a pixel rectangle */
+void orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *P,
+                int x0, int y0, int x1, int y1, uint8_t *rgb8, float *zbuf, uint8_t *count)
+{
+    cam_setup cs;
+    camera_setup(cam, &cs);
+    int has_children = 0;
+    for (int i = 1; i < s->n_nodes; i++) if (s->nodes[i].parent == 0) has_children = 1;
+    int maxs = P->max_sample > P->min_sample ? P->max_sample : P->min_sample;
+    float *colorlist = (float *)malloc(sizeof(float) * 3 * (size_t)(maxs > 0 ? maxs : 1));
+    for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) {
+        int index = y * cam->width + x;
+        if (!has_children) continue;                                   /* :266 */
+        int hit = 0, ncol = 0;
+        float hitz = 0;
+        int s_start = 0, s_end = P->min_sample;
+        while (s_start == 0 || (variant_over_threshold(colorlist, ncol, P->threshold) && s_start != P->max_sample)) {
+            for (int k = s_start; k < s_end; k++) {
+                float ray[6];
+                primary_ray(cam, &cs, x, y, k, ray);
+                orc_hit h;
+                g_cnt.rays_primary++;
+                if (orc_trace(s, P->shade_model, ray, &h)) {
+                    hit = 1;
+                    orc_shade(s, P, ray, &h, P->bounce, &colorlist[3 * ncol]);
+                    ncol++;
+                    hitz = h.z;
+                }
+            }
+            s_start = s_end;
+            s_end = P->max_sample;
+            if (!hit) break;
+            if (s_start >= s_end && s_start != P->max_sample) break;   /* guard: min > max */
+        }
+        float g[3];
+        if (hit) {
+            /* averageColor, :191-199 */
+            float n = 1 / (float)ncol;
+            v3 c = V3(0, 0, 0);
+            for (int i = 0; i < ncol; i++) c = vadd(c, vscale(v3p(&colorlist[3 * i]), n));
+            count[index] = (ncol <= P->min_sample) ? 0 : 255;          /* :312-315 */
+            float ig = (float)(1.0 / (double)P->gamma);                /* powf(x, 1.0/gamma) */
+            g[0] = powf(c.x, ig); g[1] = powf(c.y, ig); g[2] = powf(c.z, ig);
+            orc_color24(g, &rgb8[3 * (size_t)index]);
+            zbuf[index] = hitz;
+        } else {
+            float ig = (float)(1.0 / (double)P->gamma);
+            g[0] = powf(s->bg[0], ig); g[1] = powf(s->bg[1], ig); g[2] = powf(s->bg[2], ig);
+            orc_color24(g, &rgb8[3 * (size_t)index]);
+            zbuf[index] = BIGFLOAT;
+            count[index] = 0;
+        }
+    }
+    free(colorlist);
+}

@@ -1,0 +1,109 @@
+/*
+ * rt_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded, recursive CPU restatement of the reference's per-pixel render
+ * loop (RayTracingFinal/RayTracingFinal = FIN).  It exists to CHECK the HIP path; nothing in
+ * the product may include, link or call it (only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg do).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   pinned against the reference's own code compiled here (oracle/_ref/ref_harness, built from
+ *   the headers where they lie in /root/reference):
+ *       Sphere/Plane/TriObj::IntersectRay + TraceBVHNode + Box::IntersectRay, cyBVH build,
+ *       Node::ToNodeCoords/FromNodeCoords, Halton, Color24, PhotonMap balance + kNN
+ *       (EstimateIrradiance<400>), Photon pack/decode.
+ *   PARITY UNPINNED (FIN/main.cpp textually includes viewport.cpp, which needs <GL/glut.h>;
+ *   that header is absent from this image, so main.cpp is unbuildable here):
+ *       TraceNode, GenLight::Shadow, PointLight::Illuminate, MtlBlinn::Shade, RenderPixel.
+ *   Those are restated line by line with the file:line they follow.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stdint.h>
+#include "../include/rt_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_mesh {
+    const float *v;      int32_t nv;
+    const uint32_t *f;   int32_t nf;
+    const float *vn;     int32_t nvn;
+    const uint32_t *fn;
+    const rt_bvh_node *nodes; int32_t nnodes;
+    const uint32_t *elements;
+} orc_mesh;
+
+typedef struct orc_scene {
+    const rt_node *nodes;       int32_t n_nodes;
+    const orc_mesh *meshes;     int32_t n_meshes;
+    const rt_blinn *materials;  int32_t n_materials;
+    const rt_light *lights;     int32_t n_lights;
+    const rt_photon *photons;   uint32_t n_photons;   /* balanced, [0] unused */
+    float env[3], bg[3];
+} orc_scene;
+
+typedef struct orc_hit {
+    float z; float p[3]; float N[3];
+    int32_t node; int32_t front;
+} orc_hit;
+
+typedef struct orc_counters {
+    uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract;
+    uint64_t box_tests, tri_tests, node_visits;
+    uint64_t photon_queries, photons_visited;
+} orc_counters;
+
+void  orc_counters_reset(void);
+void  orc_counters_get(orc_counters *out);
+
+float orc_halton(int index, int base);
+void  orc_color24(const float rgb[3], uint8_t out[3]);
+
+/* primitives in object space; hit->z carries the current closest distance in/out */
+int   orc_sphere_intersect(int model, const float ray[6], orc_hit *hit);
+int   orc_plane_intersect(int model, const float ray[6], orc_hit *hit);
+int   orc_box_intersect(const float box[6], const float ray[6], float t_max);
+int   orc_mesh_intersect(int model, const orc_mesh *m, const float ray[6], orc_hit *hit);
+
+void  orc_to_node_coords(const rt_node *n, const float ray[6], float out[6]);
+void  orc_from_node_coords(const rt_node *n, orc_hit *hit);
+
+/* TraceNode(rootNode, ray, hit); returns 1 on hit (hit initialised by the callee) */
+int   orc_trace(const orc_scene *s, int model, const float ray[6], orc_hit *hit);
+float orc_shadow(const orc_scene *s, int model, const float ray[6], float t_max);
+void  orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
+                     const float p[3], const float N[3], float out[3]);
+void  orc_shade(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h,
+                int bounce, float out[3]);
+
+/* photon map */
+void  orc_photon_pack(const float pos[3], const float dir[3], const float power[3], rt_photon *out);
+void  orc_photon_direction(const rt_photon *p, float dir[3]);
+void  orc_photon_power(const rt_photon *p, float rgb[3]);
+void  orc_photon_balance(rt_photon *in, uint32_t n, rt_photon *out);
+void  orc_estimate_irradiance(const rt_photon *photons, uint32_t n, int k, float radius,
+                              const float pos[3], const float normal[3],
+                              float irr[3], float dir[3]);
+
+/* cyBVH build (MeanSplit), returns node count incl. unused node 0 */
+int   orc_bvh_build(const float *v, const uint32_t *f, int32_t nf, int32_t max_per_leaf,
+                    rt_bvh_node *nodes_out, uint32_t *elements_out);
+
+/* primary ray of sample j of pixel (x,y) as RenderPixel builds it */
+void  orc_primary_ray(const rt_camera *cam, int x, int y, int j, float ray[6]);
+/* RenderPixel over the pixel rectangle [x0,x1) x [y0,y1); outputs are full-image buffers */
+void  orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *P,
+                 int x0, int y0, int x1, int y1,
+                 uint8_t *rgb8, float *z, uint8_t *count);
+/* per-sample linear colour of one pixel (before averaging); returns number of hit samples.
+ * rgb has room for max_sample*3 floats, hitmask one byte per sample index. */
+int   orc_pixel_samples(const orc_scene *s, const rt_camera *cam, const rt_params *P,
+                        int x, int y, int j0, int j1, float *rgb, uint8_t *hitmask, float *z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
