@@ -1,0 +1,284 @@
+"""ctypes binding of librt_mi355x.so (the C ABI declared in include/rt_mi355x.h).
+
+The render entry points run ONLY on the HIP kernels; when the library or a gfx950 device is
+missing they raise -- there is no CPU fallback in this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "librt_mi355x.so")
+CSRC = os.path.join(HERE, "csrc")
+
+# numpy mirrors of the POD records of include/rt_mi355x.h
+NODE = np.dtype([("tm", "<f4", 9), ("itm", "<f4", 9), ("pos", "<f4", 3), ("parent", "<i4"),
+                 ("obj_type", "<i4"), ("mesh", "<i4"), ("material", "<i4")])
+BVHNODE = np.dtype([("box", "<f4", 6), ("data", "<u4")])
+BLINN = np.dtype([("diffuse", "<f4", 3), ("specular", "<f4", 3), ("reflection", "<f4", 3),
+                  ("refraction", "<f4", 3), ("emission", "<f4", 3), ("absorption", "<f4", 3),
+                  ("glossiness", "<f4"), ("ior", "<f4"), ("reflection_glossiness", "<f4"),
+                  ("refraction_glossiness", "<f4")])
+LIGHT = np.dtype([("type", "<i4"), ("intensity", "<f4", 3), ("position", "<f4", 3),
+                  ("direction", "<f4", 3), ("size", "<f4")])
+PHOTON = np.dtype([("position", "<f4", 3), ("power", "<f4"), ("color", "u1", 3),
+                   ("plane_and_dirz", "u1"), ("dir_x", "<i2"), ("dir_y", "<i2")])
+assert (NODE.itemsize, BVHNODE.itemsize, BLINN.itemsize, LIGHT.itemsize, PHOTON.itemsize) == (100, 28, 88, 44, 24)
+
+OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3
+LIGHT_AMBIENT, LIGHT_DIRECT, LIGHT_POINT = 0, 1, 2
+SHADE_FIN, SHADE_P13 = 0, 1
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("dir", C.c_float * 3), ("up", C.c_float * 3),
+                ("fov", C.c_float), ("focaldist", C.c_float), ("dof", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("min_sample", C.c_int32), ("max_sample", C.c_int32), ("threshold", C.c_float),
+                ("bounce", C.c_int32), ("hemisphere_sample", C.c_int32), ("knn_k", C.c_int32),
+                ("knn_radius", C.c_float), ("shade_model", C.c_int32),
+                ("shadow_samples", C.c_int32), ("seed", C.c_uint32), ("gamma", C.c_double),
+                ("reserved", C.c_int32 * 4)]
+
+
+class TileRange(C.Structure):
+    _fields_ = [("tile_w", C.c_int32), ("tile_h", C.c_int32), ("first", C.c_int32), ("stride", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = ([(n, C.c_uint64) for n in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract",
+                                           "instance_visits", "bvh_nodes_visited", "tris_tested",
+                                           "photon_queries", "photons_visited", "pixels", "samples")] +
+                [(n, C.c_double) for n in ("ms_trace", "ms_gather", "ms_resolve", "ms_total")] +
+                [(n, C.c_uint64) for n in ("launches_trace", "launches_gather", "launches_resolve")])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/rt_mi355x.h declares
+SYMBOLS = [
+    "rt_abi_version", "rt_last_error", "rt_device_count", "rt_params_default",
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_set_nodes", "rt_scene_set_mesh",
+    "rt_scene_set_materials", "rt_scene_set_lights", "rt_scene_set_environment",
+    "rt_scene_set_photons", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
+    "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
+    "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_render_begin",
+    "rt_render_tiles_device", "rt_render_progress", "rt_render_stop", "rt_render_wait",
+    "rt_job_stats", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
+]
+
+
+class RtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"rt_mi355x status {status}: {message}")
+        self.status = status
+
+
+def build(verbose=False):
+    """Compile librt_mi355x.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", CSRC] + ([] if verbose else ["-s"]), check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtError(-3, f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.rt_last_error.restype = C.c_char_p
+        for name in SYMBOLS:
+            getattr(_lib, name)          # AttributeError here = header/library mismatch
+        _lib.rt_render_progress.restype = C.c_int
+    return _lib
+
+
+def _check(st):
+    if st != 0:
+        raise RtError(st, lib().rt_last_error().decode(errors="replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def default_params(**kw):
+    p = Params()
+    lib().rt_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def device_count():
+    return lib().rt_device_count()
+
+
+def bvh_build(v, f, max_per_leaf=4):
+    v = _c(v, np.float32).reshape(-1, 3)
+    f = _c(f, np.uint32).reshape(-1, 3)
+    nodes = np.zeros(2 * len(f) + 2, BVHNODE)
+    el = np.zeros(len(f), np.uint32)
+    n = C.c_int32()
+    _check(lib().rt_bvh_build(_p(v), len(v), _p(f), len(f), int(max_per_leaf), _p(nodes), C.byref(n), _p(el)))
+    return nodes[:n.value].copy(), el
+
+
+def photon_balance(photons_1based):
+    a = _c(photons_1based, PHOTON).copy()
+    out = np.zeros_like(a)
+    _check(lib().rt_photon_balance(_p(a), C.c_uint32(len(a) - 1), _p(out)))
+    return out
+
+
+class Scene:
+    """Owns an rt_scene handle."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(lib().rt_scene_create(C.byref(self._h)))
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            lib().rt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setters -------------------------------------------------------------------------------
+    def set_nodes(self, nodes):
+        nodes = _c(nodes, NODE)
+        _check(lib().rt_scene_set_nodes(self._h, _p(nodes), len(nodes)))
+
+    def set_mesh(self, index, v, f, vn, fn, nodes, elements):
+        v, vn = _c(v, np.float32).reshape(-1, 3), _c(vn, np.float32).reshape(-1, 3)
+        f, fn = _c(f, np.uint32).reshape(-1, 3), _c(fn, np.uint32).reshape(-1, 3)
+        nodes, elements = _c(nodes, BVHNODE), _c(elements, np.uint32)
+        _check(lib().rt_scene_set_mesh(self._h, int(index), _p(v), len(v), _p(f), len(f), _p(vn), len(vn),
+                                       _p(fn), _p(nodes), len(nodes), _p(elements)))
+
+    def set_materials(self, m):
+        m = _c(m, BLINN)
+        _check(lib().rt_scene_set_materials(self._h, _p(m), len(m)))
+
+    def set_lights(self, l):
+        l = _c(l, LIGHT)
+        _check(lib().rt_scene_set_lights(self._h, _p(l), len(l)))
+
+    def set_environment(self, env=(0, 0, 0), bg=(0, 0, 0)):
+        e, b = (C.c_float * 3)(*env), (C.c_float * 3)(*bg)
+        _check(lib().rt_scene_set_environment(self._h, e, b))
+
+    def set_photons(self, balanced_1based):
+        if balanced_1based is None or len(balanced_1based) < 2:
+            _check(lib().rt_scene_set_photons(self._h, None, C.c_uint32(0)))
+            return
+        a = _c(balanced_1based, PHOTON)
+        _check(lib().rt_scene_set_photons(self._h, _p(a), C.c_uint32(len(a) - 1)))
+
+    def load_xml(self, path):
+        _check(lib().rt_scene_load_xml(self._h, os.fsencode(path)))
+
+    # -- getters -------------------------------------------------------------------------------
+    def camera(self):
+        cam = Camera()
+        _check(lib().rt_scene_get_camera(self._h, C.byref(cam)))
+        return cam
+
+    def counts(self):
+        n = [C.c_int32() for _ in range(4)]
+        nph = C.c_uint32()
+        _check(lib().rt_scene_counts(self._h, *[C.byref(x) for x in n], C.byref(nph)))
+        return dict(nodes=n[0].value, meshes=n[1].value, materials=n[2].value, lights=n[3].value, photons=nph.value)
+
+    def export(self):
+        """All host-side arrays (for handing the same bytes to another consumer)."""
+        c = self.counts()
+        nodes = np.zeros(c["nodes"], NODE)
+        mats = np.zeros(c["materials"], BLINN)
+        lights = np.zeros(c["lights"], LIGHT)
+        _check(lib().rt_scene_get_nodes(self._h, _p(nodes), len(nodes)))
+        if len(mats):
+            _check(lib().rt_scene_get_materials(self._h, _p(mats), len(mats)))
+        if len(lights):
+            _check(lib().rt_scene_get_lights(self._h, _p(lights), len(lights)))
+        meshes = []
+        for m in range(c["meshes"]):
+            k = [C.c_int32() for _ in range(4)]
+            _check(lib().rt_scene_mesh_counts(self._h, m, *[C.byref(x) for x in k]))
+            nv, nf, nvn, nn = (x.value for x in k)
+            d = dict(v=np.zeros((nv, 3), np.float32), f=np.zeros((nf, 3), np.uint32),
+                     vn=np.zeros((nvn, 3), np.float32), fn=np.zeros((nf, 3), np.uint32),
+                     nodes=np.zeros(nn, BVHNODE), elements=np.zeros(nf, np.uint32))
+            _check(lib().rt_scene_get_mesh(self._h, m, _p(d["v"]), _p(d["f"]), _p(d["vn"]), _p(d["fn"]),
+                                           _p(d["nodes"]), _p(d["elements"])))
+            meshes.append(d)
+        return dict(nodes=nodes, materials=mats, lights=lights, meshes=meshes)
+
+    # -- GPU work -------------------------------------------------------------------------------
+    def trace_rays(self, rays, shade_model=SHADE_FIN, device=0):
+        rays = _c(rays, np.float32).reshape(-1, 6)
+        n = len(rays)
+        out = dict(hit=np.zeros(n, np.uint8), z=np.zeros(n, np.float32), p=np.zeros((n, 3), np.float32),
+                   N=np.zeros((n, 3), np.float32), node=np.zeros(n, np.int32), front=np.zeros(n, np.uint8))
+        _check(lib().rt_trace_rays(self._h, int(shade_model), int(device), _p(rays), C.c_int64(n), _p(out["hit"]),
+                                   _p(out["z"]), _p(out["p"]), _p(out["N"]), _p(out["node"]), _p(out["front"])))
+        return out
+
+    def estimate_irradiance(self, k, radius, pos, normal, device=0):
+        pos, normal = _c(pos, np.float32).reshape(-1, 3), _c(normal, np.float32).reshape(-1, 3)
+        irr, d = np.zeros_like(pos), np.zeros_like(pos)
+        _check(lib().rt_estimate_irradiance(self._h, int(device), int(k), C.c_float(radius), _p(pos), _p(normal),
+                                            C.c_int64(len(pos)), _p(irr), _p(d)))
+        return irr, d
+
+    def shade_rays(self, params, rays, device=0):
+        rays = _c(rays, np.float32).reshape(-1, 6)
+        n = len(rays)
+        hit, rgb, z = np.zeros(n, np.uint8), np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+        _check(lib().rt_shade_rays(self._h, C.byref(params), int(device), _p(rays), C.c_int64(n), _p(hit), _p(rgb), _p(z)))
+        return hit, rgb, z
+
+    def render(self, cam, params, tiles=None, device=0):
+        """Blocking render through the asynchronous job API (rt_render_begin + rt_render_wait)."""
+        w, h = cam.width, cam.height
+        rgb, z, cnt = np.zeros((h, w, 3), np.uint8), np.zeros((h, w), np.float32), np.zeros((h, w), np.uint8)
+        tiles = tiles or TileRange(32, 8, 0, 1)
+        job = C.c_void_p()
+        _check(lib().rt_render_begin(self._h, C.byref(cam), C.byref(params), C.byref(tiles), int(device),
+                                     _p(rgb), _p(z), _p(cnt), C.byref(job)))
+        try:
+            _check(lib().rt_render_wait(job))
+            st = Stats()
+            _check(lib().rt_job_stats(job, C.byref(st)))
+            progress = lib().rt_render_progress(job)
+        finally:
+            lib().rt_job_destroy(job)
+        return rgb, z, cnt, st, progress
+
+    def render_tiles_device(self, cam, params, tiles, device, rgb_ptr, z_ptr, cnt_ptr, stream=None, sync=True,
+                            want_stats=True):
+        """Render this call's tiles into DEVICE buffers (e.g. torch tensors' data_ptr())."""
+        st = Stats()
+        _check(lib().rt_render_tiles_device(self._h, C.byref(cam), C.byref(params), C.byref(tiles), int(device),
+                                            C.c_void_p(stream) if stream else None, C.c_void_p(rgb_ptr),
+                                            C.c_void_p(z_ptr), C.c_void_p(cnt_ptr), 1 if sync else 0,
+                                            C.byref(st) if want_stats else None))
+        return st

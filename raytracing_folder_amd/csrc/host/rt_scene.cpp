@@ -1,0 +1,525 @@
+// rt_scene.cpp -- host scene model: math, OBJ loading, BVH build, photon balancing, lowering.
+// Each routine names the reference code whose behaviour it reproduces (FIN = /root/reference/
+// RayTracingFinal/RayTracingFinal).  Compiled with -ffp-contract=off: transforms, BVH boxes and
+// kd-tree layouts must come out bit-identical to the reference's (tests/test_host_*.py).
+#include "rt_scene.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+
+namespace rt {
+
+// ---- Matrix3 --------------------------------------------------------------------------------
+// cyMatrix3::SetRotation(axis, angle), FIN/include/cyMatrix.h:412-430
+void Matrix3::SetRotation(const Point3 &axis, float angle)
+{
+    const float s = sinf(angle), c = cosf(angle);
+    const float t = 1.0f - c;
+    const float tx = t * axis.x, ty = t * axis.y, tz = t * axis.z;
+    const float txy = tx * axis.y, txz = tx * axis.z, tyz = ty * axis.z;
+    const float sx = s * axis.x, sy = s * axis.y, sz = s * axis.z;
+    data[0] = tx * axis.x + c; data[1] = txy + sz;        data[2] = txz - sy;
+    data[3] = txy - sz;        data[4] = ty * axis.y + c; data[5] = tyz + sx;
+    data[6] = txz + sy;        data[7] = tyz - sx;        data[8] = tz * axis.z + c;
+}
+
+// cyMatrix3::GetInverse, FIN/include/cyMatrix.h:612-633 (adjugate, then each entry / det)
+void Matrix3::GetInverse(Matrix3 &inv) const
+{
+    const float *d = data;
+    inv.data[0] = d[4] * d[8] - d[5] * d[7];
+    inv.data[1] = d[2] * d[7] - d[1] * d[8];
+    inv.data[2] = d[1] * d[5] - d[2] * d[4];
+    inv.data[3] = d[5] * d[6] - d[3] * d[8];
+    inv.data[4] = d[0] * d[8] - d[2] * d[6];
+    inv.data[5] = d[2] * d[3] - d[0] * d[5];
+    inv.data[6] = d[3] * d[7] - d[4] * d[6];
+    inv.data[7] = d[1] * d[6] - d[0] * d[7];
+    inv.data[8] = d[0] * d[4] - d[1] * d[3];
+    const float det = d[0] * inv.data[0] + d[1] * inv.data[3] + d[2] * inv.data[6];
+    for (float &e : inv.data) e = e / det;
+}
+
+// ---- lowering of lights / materials ----------------------------------------------------------
+static void put3(float *o, const Color &c) { o[0] = c.r; o[1] = c.g; o[2] = c.b; }
+static void put3(float *o, const Point3 &p) { o[0] = p.x; o[1] = p.y; o[2] = p.z; }
+
+void AmbientLight::Lower(rt_light &o) const { memset(&o, 0, sizeof o); o.type = RT_LIGHT_AMBIENT; put3(o.intensity, intensity); }
+void DirectLight::Lower(rt_light &o) const { memset(&o, 0, sizeof o); o.type = RT_LIGHT_DIRECT; put3(o.intensity, intensity); put3(o.direction, direction); }
+void PointLight::Lower(rt_light &o) const { memset(&o, 0, sizeof o); o.type = RT_LIGHT_POINT; put3(o.intensity, intensity); put3(o.position, position); o.size = size; }
+
+bool MtlBlinn::Lower(rt_blinn &o) const
+{
+    put3(o.diffuse, diffuse); put3(o.specular, specular); put3(o.reflection, reflection);
+    put3(o.refraction, refraction); put3(o.emission, emission); put3(o.absorption, absorption);
+    o.glossiness = glossiness; o.ior = ior;
+    o.reflection_glossiness = reflectionGlossiness; o.refraction_glossiness = refractionGlossiness;
+    return true;
+}
+
+// ---- OBJ loading -----------------------------------------------------------------------------
+// Behaviour of cyTriMesh::LoadFromFileObj (FIN/include/cyTriMesh.h:263-462) for geometry:
+// whitespace-collapsed lines of at most 1023 characters, '#' comment lines, v / vt / vn /
+// f records, polygons fan-triangulated around their first vertex, 1-based or negative
+// (relative) indices, "v", "v/vt", "v//vn", "v/vt/vn" corner forms.  Normal faces exist from
+// the first `vn` line or the first corner with a normal index onwards.  Material libraries are
+// not read (the Cornell scenes name a scene material for the mesh: loadMtl == false).
+namespace {
+struct LineReader {
+    FILE *fp;
+    char data[1024];
+    int ReadLine()
+    {
+        int c = fgetc(fp);
+        while (c != EOF) {
+            while (c != EOF && isspace(c)) c = fgetc(fp);
+            if (c == '#') { while (c != EOF && c != '\n' && c != '\r' && c != '\0') c = fgetc(fp); }
+            else break;
+        }
+        int i = 0;
+        bool inspace = false;
+        while (i < 1024 - 1) {
+            if (c == EOF || c == '\n' || c == '\r' || c == '\0') break;
+            if (isspace(c)) inspace = true;
+            else {
+                if (inspace) data[i++] = ' ';
+                inspace = false;
+                data[i++] = (char)c;
+            }
+            c = fgetc(fp);
+        }
+        data[i] = '\0';
+        return i;
+    }
+    bool IsCommand(const char *cmd) const
+    {
+        int i = 0;
+        while (cmd[i] != '\0') { if (cmd[i] != data[i]) return false; i++; }
+        return data[i] == '\0' || data[i] == ' ';
+    }
+};
+}  // namespace
+
+bool TriObj::LoadFromFileObj(const char *filename, std::string *err)
+{
+    FILE *fp = fopen(filename, "r");
+    if (!fp) { if (err) *err = std::string("cannot open OBJ file ") + filename; return false; }
+    v.clear(); vn.clear(); f.clear(); fn.clear();
+    LineReader in; in.fp = fp;
+    std::vector<float> vt;                  // counted only (relative vt indices)
+    std::vector<uint32_t> tf;
+    bool hasNormals = false;
+    while (int rb = in.ReadLine()) {
+        if (in.IsCommand("v") || in.IsCommand("vt") || in.IsCommand("vn")) {
+            float p[3] = {0, 0, 0};
+            if (rb > 2) sscanf(in.data + 2, "%f %f %f", &p[0], &p[1], &p[2]);
+            std::vector<float> &dst = in.data[1] == 't' ? vt : (in.data[1] == 'n' ? vn : v);
+            dst.insert(dst.end(), p, p + 3);
+            if (in.data[1] == 'n') hasNormals = true;
+        } else if (in.IsCommand("f")) {
+            int facevert = -1;
+            bool inspace = true, negative = false;
+            int type = 0;
+            uint32_t index = 0;
+            uint32_t face[3] = {0, 0, 0}, nface[3] = {0, 0, 0};
+            for (int i = 2; i < rb; i++) {
+                const char ch = in.data[i];
+                if (ch == ' ') { inspace = true; continue; }
+                if (inspace) {
+                    inspace = false; negative = false; type = 0; index = 0;
+                    if (facevert < 2) {
+                        if (facevert == -1) { face[0] = face[1] = face[2] = 0; nface[0] = nface[1] = nface[2] = 0; }
+                        facevert++;
+                    } else {
+                        // emit the triangle gathered so far and keep (v0, last) for the fan
+                        f.insert(f.end(), face, face + 3);
+                        face[1] = face[2];
+                        if (hasNormals) { fn.insert(fn.end(), nface, nface + 3); nface[1] = nface[2]; }
+                    }
+                }
+                if (ch == '/') { type++; index = 0; }
+                if (ch == '-') negative = true;
+                if (ch >= '0' && ch <= '9') {
+                    index = index * 10 + (uint32_t)(ch - '0');
+                    switch (type) {
+                    case 0: face[facevert] = negative ? (uint32_t)(v.size() / 3) - index : index - 1; break;
+                    case 1: break;   // texture index: not used on this path
+                    case 2: nface[facevert] = negative ? (uint32_t)(vn.size() / 3) - index : index - 1; hasNormals = true; break;
+                    }
+                }
+            }
+            f.insert(f.end(), face, face + 3);
+            if (hasNormals) fn.insert(fn.end(), nface, nface + 3);
+        }
+        if (feof(fp)) break;
+    }
+    fclose(fp);
+    if (vn.empty()) fn.clear();
+    // the reference sizes fn to the face count once normals exist (SetNumNormals) and copies the
+    // normal faces gathered so far to its front; the tail (faces read before the first normal)
+    // is uninitialised there and zero here
+    if (!vn.empty() && fn.size() < f.size()) fn.insert(fn.end(), f.size() - fn.size(), 0u);
+    for (uint32_t idx : f) if (idx >= v.size() / 3) { if (err) *err = "OBJ face index out of range"; return false; }
+    for (uint32_t idx : fn) if (idx >= vn.size() / 3) { if (err) *err = "OBJ normal index out of range"; return false; }
+    return true;
+}
+
+// cyTriMesh::ComputeNormals, FIN/include/cyTriMesh.h:248-261
+void TriObj::ComputeNormals()
+{
+    vn.assign(v.size(), 0.0f);
+    fn = f;
+    auto P = [&](uint32_t i) { return Point3(v[3 * i], v[3 * i + 1], v[3 * i + 2]); };
+    for (size_t i = 0; i < f.size(); i += 3) {
+        Point3 N = (P(f[i + 1]) - P(f[i])) ^ (P(f[i + 2]) - P(f[i]));
+        for (int k = 0; k < 3; k++) {
+            float *d = &vn[3 * f[i + k]];
+            d[0] += N.x; d[1] += N.y; d[2] += N.z;
+        }
+    }
+    for (size_t i = 0; i < vn.size(); i += 3) {
+        Point3 n(vn[i], vn[i + 1], vn[i + 2]);
+        n.Normalize();
+        vn[i] = n.x; vn[i + 1] = n.y; vn[i + 2] = n.z;
+    }
+}
+
+void TriObj::BuildBVH(unsigned maxElementsPerNode)
+{
+    BuildMeanSplitBVH(v.data(), f.data(), NF(), maxElementsPerNode, nodes, elements);
+}
+
+// TriObj::Load, FIN/include/objects.h:137-145
+bool TriObj::Load(const char *filename, bool loadMtl, std::string *err)
+{
+    (void)loadMtl;
+    nodes.clear(); elements.clear();
+    if (!LoadFromFileObj(filename, err)) return false;
+    if (!HasNormals()) ComputeNormals();
+    BuildBVH(4);
+    return true;
+}
+
+// ---- cyBVH build (mean split) ------------------------------------------------------------------
+// FIN/include/cyBVH.h: Build :122-142, SplitTempNode :242-278, MeanSplit :295-328,
+// ConvertTempData :281-291.  Node ids: root 1, the two children of a node adjacent, the left
+// subtree's nodes numbered before the right subtree's.
+namespace {
+struct BuildCtx {
+    const float *v; const uint32_t *f; unsigned maxPer;
+    std::vector<uint32_t> *elements;
+    struct Tmp { float box[6]; unsigned count, offset; int c1, c2; };
+    std::vector<Tmp> tmp;
+
+    void Bounds(uint32_t e, float b[6]) const
+    {
+        const uint32_t *fi = f + 3 * (size_t)e;
+        const float *p = v + 3 * (size_t)fi[0];
+        b[0] = b[3] = p[0]; b[1] = b[4] = p[1]; b[2] = b[5] = p[2];
+        for (int j = 1; j < 3; j++) {
+            p = v + 3 * (size_t)fi[j];
+            for (int k = 0; k < 3; k++) { if (b[k] > p[k]) b[k] = p[k]; if (b[k + 3] < p[k]) b[k + 3] = p[k]; }
+        }
+    }
+    float Center(uint32_t e, unsigned dim) const
+    {
+        const uint32_t *fi = f + 3 * (size_t)e;
+        return (v[3 * (size_t)fi[0] + dim] + v[3 * (size_t)fi[1] + dim] + v[3 * (size_t)fi[2] + dim]) / 3.0f;
+    }
+    static void Grow(float b[6], const float o[6])
+    {
+        for (int i = 0; i < 3; i++) { if (b[i] > o[i]) b[i] = o[i]; if (b[i + 3] < o[i + 3]) b[i + 3] = o[i + 3]; }
+    }
+    static void Empty(float b[6]) { b[0] = b[1] = b[2] = 1e30f; b[3] = b[4] = b[5] = -1e30f; }
+
+    unsigned MeanSplit(unsigned count, uint32_t *ne, const float *box) const
+    {
+        if (count <= maxPer) return 0;
+        const float d[3] = {box[3] - box[0], box[4] - box[1], box[5] - box[2]};
+        unsigned sd[3];
+        sd[0] = d[0] >= d[1] ? (d[0] >= d[2] ? 0 : 2) : (d[1] >= d[2] ? 1 : 2);
+        sd[1] = (sd[0] + 1) % 3;
+        sd[2] = (sd[0] + 2) % 3;
+        if (d[sd[1]] < d[sd[2]]) std::swap(sd[1], sd[2]);
+        for (int s = 0; s < 3; s++) {
+            const unsigned dim = sd[s];
+            const float splitPos = 0.5f * (box[dim] + box[dim + 3]);
+            unsigned i = 0, j = count;
+            while (i < j) {
+                if (Center(ne[i], dim) <= splitPos) i++;
+                else { j--; std::swap(ne[i], ne[j]); }
+            }
+            if (i < count && i > 0) return i;
+        }
+        return 0;
+    }
+    void Split(int t)
+    {
+        uint32_t *ne = elements->data() + tmp[t].offset;
+        unsigned c1 = MeanSplit(tmp[t].count, ne, tmp[t].box);
+        if (c1 == 0 || c1 >= tmp[t].count) {
+            if (tmp[t].count > 8) c1 = tmp[t].count / 2;     // CY_BVH_MAX_ELEMENT_COUNT
+            else return;
+        }
+        Tmp a, b;
+        Empty(a.box); Empty(b.box);
+        float eb[6];
+        for (unsigned i = 0; i < c1; i++) { Bounds(ne[i], eb); Grow(a.box, eb); }
+        for (unsigned i = c1; i < tmp[t].count; i++) { Bounds(ne[i], eb); Grow(b.box, eb); }
+        a.count = c1; a.offset = tmp[t].offset; a.c1 = a.c2 = -1;
+        b.count = tmp[t].count - c1; b.offset = tmp[t].offset + c1; b.c1 = b.c2 = -1;
+        const int ia = (int)tmp.size(); tmp.push_back(a);
+        const int ib = (int)tmp.size(); tmp.push_back(b);
+        tmp[t].c1 = ia; tmp[t].c2 = ib;
+        Split(ia);
+        Split(ib);
+    }
+    unsigned Convert(std::vector<rt_bvh_node> &nodes, unsigned id, int t, unsigned childIndex) const
+    {
+        memcpy(nodes[id].box, tmp[t].box, sizeof(float) * 6);
+        if (tmp[t].c1 < 0) {
+            nodes[id].data = (tmp[t].offset & 0x0FFFFFFFu) | ((tmp[t].count - 1) << 28) | 0x80000000u;
+            return childIndex;
+        }
+        nodes[id].data = childIndex & 0x7FFFFFFFu;
+        const unsigned next = Convert(nodes, childIndex, tmp[t].c1, childIndex + 2);
+        return Convert(nodes, childIndex + 1, tmp[t].c2, next);
+    }
+};
+}  // namespace
+
+void BuildMeanSplitBVH(const float *v, const uint32_t *f, unsigned nf, unsigned maxPerLeaf,
+                       std::vector<rt_bvh_node> &nodes, std::vector<uint32_t> &elements)
+{
+    nodes.clear(); elements.clear();
+    if (nf == 0) return;
+    BuildCtx c;
+    c.v = v; c.f = f; c.maxPer = std::min(maxPerLeaf, 8u); c.elements = &elements;
+    elements.resize(nf);
+    for (unsigned i = 0; i < nf; i++) elements[i] = i;
+    BuildCtx::Tmp root;
+    BuildCtx::Empty(root.box);
+    float eb[6];
+    for (unsigned i = 0; i < nf; i++) { c.Bounds(i, eb); BuildCtx::Grow(root.box, eb); }
+    root.count = nf; root.offset = 0; root.c1 = root.c2 = -1;
+    c.tmp.reserve(2 * (size_t)nf);
+    c.tmp.push_back(root);
+    c.Split(0);
+    nodes.assign(c.tmp.size() + 1, rt_bvh_node{});
+    c.Convert(nodes, 1, 0, 2);
+}
+
+// ---- photon map balancing ------------------------------------------------------------------------
+// PhotonMap::PrepareForIrradianceEstimation + BalanceSegment, FIN/include/cyPhotonMap.h:196-284:
+// left-balanced kd-tree in heap order (children of i at 2i, 2i+1), split axis = widest extent
+// of the segment's box, quick-select partition that permutes the input array in place.
+namespace {
+struct Balancer {
+    rt_photon *ph, *bal;
+    void Segment(float bmin[3], float bmax[3], uint32_t index, uint32_t start, uint32_t end)
+    {
+        uint32_t median = 1;
+        while (4 * median <= end - start + 1) median += median;
+        if (3 * median <= end - start + 1) { median += median; median += start - 1; }
+        else median = end - median + 1;
+        int axis = 2;
+        const float dx = bmax[0] - bmin[0], dy = bmax[1] - bmin[1], dz = bmax[2] - bmin[2];
+        if (dx > dy) { if (dx > dz) axis = 0; }
+        else if (dy > dz) axis = 1;
+        uint32_t left = start, right = end;
+        while (right > left) {
+            const float pivot = ph[right].position[axis];
+            uint32_t i = left - 1, j = right;
+            while (ph[++i].position[axis] < pivot) {}
+            while (ph[--j].position[axis] > pivot && j > left) {}
+            while (i < j) {
+                std::swap(ph[i], ph[j]);
+                while (ph[++i].position[axis] < pivot) {}
+                while (ph[--j].position[axis] > pivot && j > left) {}
+            }
+            std::swap(ph[i], ph[right]);
+            if (i >= median) right = i - 1;
+            if (i <= median) left = i + 1;
+        }
+        bal[index] = ph[median];
+        bal[index].plane_and_dirz = (uint8_t)((bal[index].plane_and_dirz & 0x8) | (axis & 0x3));
+        const float split = bal[index].position[axis];
+        if (median > start) {
+            if (start < median - 1) {
+                float tmax[3] = {bmax[0], bmax[1], bmax[2]};
+                tmax[axis] = split;
+                Segment(bmin, tmax, 2 * index, start, median - 1);
+            } else bal[2 * index] = ph[start];
+        }
+        if (median < end) {
+            if (median + 1 < end) {
+                float tmin[3] = {bmin[0], bmin[1], bmin[2]};
+                tmin[axis] = split;
+                Segment(tmin, bmax, 2 * index + 1, median + 1, end);
+            } else bal[2 * index + 1] = ph[end];
+        }
+    }
+};
+}  // namespace
+
+void BalancePhotons(rt_photon *in, uint32_t n, rt_photon *out)
+{
+    // the reference's box loop starts at photons[0], the unused slot (cyPhotonMap.h:201-210)
+    float bmin[3] = {in[0].position[0], in[0].position[1], in[0].position[2]};
+    float bmax[3] = {bmin[0], bmin[1], bmin[2]};
+    for (uint32_t i = 1; i <= n; i++)
+        for (int a = 0; a < 3; a++) {
+            if (bmin[a] > in[i].position[a]) bmin[a] = in[i].position[a];
+            if (bmax[a] < in[i].position[a]) bmax[a] = in[i].position[a];
+        }
+    memset(out, 0, sizeof(rt_photon) * ((size_t)n + 1));
+    if (n == 0) return;
+    Balancer b{in, out};
+    b.Segment(bmin, bmax, 1, 1, n);
+}
+
+// ---- Scene ------------------------------------------------------------------------------------------
+Material *Scene::FindMaterial(const std::string &n)
+{
+    for (auto &m : materials) if (m && m->name == n) return m.get();
+    return nullptr;
+}
+TriObj *Scene::FindObj(const std::string &n)
+{
+    for (auto &o : objList) if (o.first == n) return o.second.get();
+    return nullptr;
+}
+void Scene::Clear()
+{
+    rootNode.Init(); materials.clear(); lights.clear(); objList.clear();
+    environment = Color(); background = Color(); camera.Init();
+}
+
+// ---- lowering: Node tree -> rt_node[] in TraceNode's visiting order --------------------------------
+namespace {
+struct Lowerer {
+    const Scene &sc; SceneData &out; std::string *err;
+    std::vector<const TriObj *> meshes;
+    std::vector<const Material *> mats;
+    bool ok = true;
+    int MeshIndex(const TriObj *t)
+    {
+        for (size_t i = 0; i < meshes.size(); i++) if (meshes[i] == t) return (int)i;
+        meshes.push_back(t);
+        return (int)meshes.size() - 1;
+    }
+    int MaterialIndex(const Material *m)
+    {
+        if (!m) return -1;
+        for (size_t i = 0; i < mats.size(); i++) if (mats[i] == m) return (int)i;
+        mats.push_back(m);
+        return (int)mats.size() - 1;
+    }
+    void Visit(const Node &n, int parent)
+    {
+        rt_node r;
+        memcpy(r.tm, n.GetTransform().data, sizeof r.tm);
+        memcpy(r.itm, n.GetInverseTransform().data, sizeof r.itm);
+        r.pos[0] = n.GetPosition().x; r.pos[1] = n.GetPosition().y; r.pos[2] = n.GetPosition().z;
+        r.parent = parent; r.obj_type = RT_OBJ_NONE; r.mesh = -1;
+        r.material = MaterialIndex(n.GetMaterial());
+        if (const Object *o = n.GetNodeObj()) {
+            r.obj_type = o->Kind();
+            if (r.obj_type == RT_OBJ_MESH) {
+                const TriObj *t = dynamic_cast<const TriObj *>(o);
+                if (!t) { ok = false; if (err) *err = "node '" + n.name + "': mesh object is not a TriObj"; return; }
+                r.mesh = MeshIndex(t);
+            } else if (r.obj_type != RT_OBJ_SPHERE && r.obj_type != RT_OBJ_PLANE) {
+                ok = false;
+                if (err) *err = "node '" + n.name + "': object kind has no device lowering (no CPU path exists)";
+                return;
+            }
+            if (r.material < 0) { ok = false; if (err) *err = "node '" + n.name + "' has an object but no material"; return; }
+        }
+        const int me = (int)out.nodes.size();
+        out.nodes.push_back(r);
+        for (int i = 0; i < n.GetNumChild() && ok; i++) Visit(*n.GetChild(i), me);
+    }
+};
+}  // namespace
+
+bool Lower(const Scene &scene, SceneData &out, std::string *err)
+{
+    out = SceneData();
+    Lowerer L{scene, out, err};
+    L.Visit(scene.rootNode, -1);
+    if (!L.ok) return false;
+    for (const TriObj *t : L.meshes) {
+        MeshData m;
+        m.v = t->v; m.vn = t->vn; m.f = t->f; m.fn = t->fn; m.nodes = t->nodes; m.elements = t->elements;
+        out.meshes.push_back(std::move(m));
+    }
+    for (const Material *m : L.mats) {
+        rt_blinn b;
+        memset(&b, 0, sizeof b);
+        if (!m->Lower(b)) { if (err) *err = "material '" + m->name + "' has no device lowering"; return false; }
+        out.materials.push_back(b);
+    }
+    for (auto &l : scene.lights) { rt_light r; l->Lower(r); out.lights.push_back(r); }
+    const Camera &c = scene.camera;
+    rt_camera &rc = out.camera;
+    rc.pos[0] = c.pos.x; rc.pos[1] = c.pos.y; rc.pos[2] = c.pos.z;
+    rc.dir[0] = c.dir.x; rc.dir[1] = c.dir.y; rc.dir[2] = c.dir.z;
+    rc.up[0] = c.up.x; rc.up[1] = c.up.y; rc.up[2] = c.up.z;
+    rc.fov = c.fov; rc.focaldist = c.focaldist; rc.dof = c.dof; rc.width = c.imgWidth; rc.height = c.imgHeight;
+    out.has_camera = true;
+    out.env[0] = scene.environment.r; out.env[1] = scene.environment.g; out.env[2] = scene.environment.b;
+    out.bg[0] = scene.background.r; out.bg[1] = scene.background.g; out.bg[2] = scene.background.b;
+    return true;
+}
+
+// ---- PNG (RenderImage::SavePNG, FIN/include/scene.h:645-655): 8-bit grey / RGB ------------------------
+namespace {
+uint32_t crc_table[256];
+void crc_init() { for (uint32_t n = 0; n < 256; n++) { uint32_t c = n; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; crc_table[n] = c; } }
+uint32_t crc(const uint8_t *b, size_t n, uint32_t c = 0xFFFFFFFFu) { for (size_t i = 0; i < n; i++) c = crc_table[(c ^ b[i]) & 0xFF] ^ (c >> 8); return c; }
+void be32(std::vector<uint8_t> &o, uint32_t v) { o.push_back(v >> 24); o.push_back(v >> 16); o.push_back(v >> 8); o.push_back(v); }
+void chunk(std::vector<uint8_t> &o, const char *tag, const std::vector<uint8_t> &d)
+{
+    be32(o, (uint32_t)d.size());
+    std::vector<uint8_t> t(tag, tag + 4);
+    t.insert(t.end(), d.begin(), d.end());
+    o.insert(o.end(), t.begin(), t.end());
+    be32(o, crc(t.data(), t.size()) ^ 0xFFFFFFFFu);
+}
+}  // namespace
+
+bool WritePNG(const char *filename, const uint8_t *data, int w, int h, int comps)
+{
+    if (comps != 1 && comps != 3) return false;
+    crc_init();
+    std::vector<uint8_t> raw;
+    const size_t row = (size_t)w * comps;
+    raw.reserve((row + 1) * h);
+    for (int y = 0; y < h; y++) { raw.push_back(0); raw.insert(raw.end(), data + y * row, data + (y + 1) * row); }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (uint8_t c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        if (raw.empty()) break;
+    }
+    be32(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, (uint32_t)w); be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(comps == 3 ? 2 : 0); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(out, "IHDR", ihdr); chunk(out, "IDAT", z); chunk(out, "IEND", {});
+    FILE *fp = fopen(filename, "wb");
+    if (!fp) return false;
+    const bool ok = fwrite(out.data(), 1, out.size(), fp) == out.size();
+    fclose(fp);
+    return ok;
+}
+
+}  // namespace rt

@@ -1,0 +1,1008 @@
+// rt_api.cpp -- implementation of the C ABI in include/rt_mi355x.h: scene store, lowering to the
+// device layout of rt_dev.h, per-chunk wavefront orchestration on a HIP stream, async jobs.
+// There is no CPU render path in this library: without a gfx950 device the render calls fail.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "host/rt_scene.h"
+#include "rt_dev.h"
+
+// launch wrappers defined in rt_kernels.hip
+void rtk_launch_primary(hipStream_t, const DevScene &, const DevWork &, const rt_params &, const DevRayQueue &, uint32_t *,
+                        const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int, int, int, const float *, int);
+void rtk_launch_bounce(hipStream_t, const DevScene &, const DevWork &, const rt_params &, const DevRayQueue &,
+                       const DevRayQueue &, uint32_t *, int, int);
+void rtk_launch_trace(hipStream_t, const DevScene &, int, const float *, long long, uint8_t *, float *, float *, float *, int32_t *, uint8_t *);
+void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const float4 *, const float4 *, const uint32_t *,
+                       uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int);
+void rtk_launch_resolve(hipStream_t, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
+                        float, float, int, const float *, uint8_t *, float *, uint8_t *, int);
+
+// ---- errors ---------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static rt_status fail(rt_status st, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *rt_last_error(void) { return g_err.c_str(); }
+extern "C" int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+static bool device_is_gfx950(int dev)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+extern "C" int rt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int ok = 0;
+    for (int i = 0; i < n; i++) if (device_is_gfx950(i)) ok++;
+    return ok;
+}
+
+extern "C" void rt_params_default(rt_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->min_sample = 4; p->max_sample = 8; p->threshold = 1e-3f; p->bounce = 4;      // FIN/main.cpp:19-26
+    p->hemisphere_sample = 30; p->knn_k = 400; p->knn_radius = 1.0f;                // :26, :699
+    p->shade_model = RT_SHADE_FIN; p->shadow_samples = 4; p->seed = 20171203u; p->gamma = 2.2;
+}
+
+// ---- device buffers --------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    rt_status ensure(size_t n)
+    {
+        if (n <= bytes && p) return RT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (n == 0) n = 16;
+        HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
+        return RT_OK;
+    }
+    rt_status upload(const void *src, size_t n)
+    {
+        rt_status st = ensure(n);
+        if (st) return st;
+        if (n) HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+        return RT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct DevMeshBufs { DevBuf nodes, tris, tri_face, nrm; };
+
+struct DeviceState {
+    int device = -1;
+    bool scene_valid = false, photons_valid = false;
+    DevBuf nodes, objects, meshes, materials, lights, node_material;
+    std::vector<DevMeshBufs> mesh_bufs;
+    DevBuf pa, pb, pc, tbox;
+    DevScene scene{};
+    // workspace
+    DevBuf sample_rgb, sample_z, sample_hit, rq[2][4], pq[3], counts, pixel_list, stats;
+    size_t ws_samples = 0; uint32_t ws_rq_cap = 0, ws_pq_cap = 0;
+    // scratch for the single-stage entry points
+    DevBuf t_in, t_out[6];
+    hipStream_t stream = nullptr;
+    void release()
+    {
+        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &pa, &pb, &pc, &tbox,
+                          &sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &stats, &t_in}) b->release();
+        for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); }
+        for (int i = 0; i < 2; i++) for (int k = 0; k < 4; k++) rq[i][k].release();
+        for (int k = 0; k < 3; k++) pq[k].release();
+        for (int k = 0; k < 6; k++) t_out[k].release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
+struct rt_scene {
+    rt::SceneData data;
+    std::mutex mu;
+    std::vector<DeviceState *> devs;
+    std::atomic<int> live_jobs{0};
+    void invalidate(bool scene, bool photons)
+    {
+        for (DeviceState *d : devs) { if (scene) d->scene_valid = false; if (photons) d->photons_valid = false; }
+    }
+};
+
+struct rt_job {
+    rt_scene *scene = nullptr;
+    std::thread worker;
+    std::atomic<int> progress{0};
+    std::atomic<bool> stop{false};
+    std::atomic<bool> done{false};
+    rt_status status = RT_OK;
+    std::string error;
+    rt_stats stats{};
+};
+
+// ---- scene store ---------------------------------------------------------------------------------------
+extern "C" rt_status rt_scene_create(rt_scene **out)
+{
+    if (!out) return fail(RT_ERR_ARG, "rt_scene_create: out is NULL");
+    *out = new rt_scene;
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene *s)
+{
+    if (!s) return;
+    for (DeviceState *d : s->devs) {
+        if (hipSetDevice(d->device) == hipSuccess) d->release();
+        delete d;
+    }
+    delete s;
+}
+
+static rt_status check_idle(rt_scene *s, const char *who)
+{
+    if (!s) return fail(RT_ERR_ARG, "%s: scene is NULL", who);
+    if (s->live_jobs.load() > 0) return fail(RT_ERR_STATE, "%s: a render job is still live on this scene", who);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_nodes(rt_scene *s, const rt_node *nodes, int32_t n)
+{
+    rt_status st = check_idle(s, "rt_scene_set_nodes");
+    if (st) return st;
+    if (n < 0 || (n > 0 && !nodes)) return fail(RT_ERR_ARG, "rt_scene_set_nodes: bad array");
+    for (int32_t i = 0; i < n; i++) {
+        if (i == 0 ? nodes[i].parent != -1 : (nodes[i].parent < 0 || nodes[i].parent >= i))
+            return fail(RT_ERR_ARG, "rt_scene_set_nodes: node %d has parent %d (parents must precede children, root first)", i, nodes[i].parent);
+        if (nodes[i].obj_type < RT_OBJ_NONE || nodes[i].obj_type > RT_OBJ_MESH)
+            return fail(RT_ERR_ARG, "rt_scene_set_nodes: node %d has unknown object type %d", i, nodes[i].obj_type);
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->data.nodes.assign(nodes, nodes + n);
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_mesh(rt_scene *s, int32_t mesh, const float *v, int32_t nv, const uint32_t *f, int32_t nf,
+                                       const float *vn, int32_t nvn, const uint32_t *fn, const rt_bvh_node *nodes,
+                                       int32_t nnodes, const uint32_t *elements)
+{
+    rt_status st = check_idle(s, "rt_scene_set_mesh");
+    if (st) return st;
+    if (mesh < 0 || mesh > 65535) return fail(RT_ERR_ARG, "rt_scene_set_mesh: mesh index %d out of range", mesh);
+    if (nv <= 0 || nf <= 0 || nvn <= 0 || nnodes < 2 || !v || !f || !vn || !fn || !nodes || !elements)
+        return fail(RT_ERR_ARG, "rt_scene_set_mesh: every array is required (nv=%d nf=%d nvn=%d nnodes=%d)", nv, nf, nvn, nnodes);
+    for (int64_t i = 0; i < 3LL * nf; i++) {
+        if (f[i] >= (uint32_t)nv) return fail(RT_ERR_ARG, "rt_scene_set_mesh: face index %u >= nv", f[i]);
+        if (fn[i] >= (uint32_t)nvn) return fail(RT_ERR_ARG, "rt_scene_set_mesh: normal index %u >= nvn", fn[i]);
+    }
+    for (int32_t i = 0; i < nf; i++) if (elements[i] >= (uint32_t)nf) return fail(RT_ERR_ARG, "rt_scene_set_mesh: element %u >= nf", elements[i]);
+    std::lock_guard<std::mutex> lk(s->mu);
+    if ((size_t)mesh >= s->data.meshes.size()) s->data.meshes.resize((size_t)mesh + 1);
+    rt::MeshData &m = s->data.meshes[mesh];
+    m.v.assign(v, v + 3 * (size_t)nv); m.f.assign(f, f + 3 * (size_t)nf);
+    m.vn.assign(vn, vn + 3 * (size_t)nvn); m.fn.assign(fn, fn + 3 * (size_t)nf);
+    m.nodes.assign(nodes, nodes + nnodes); m.elements.assign(elements, elements + nf);
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_materials(rt_scene *s, const rt_blinn *m, int32_t n)
+{
+    rt_status st = check_idle(s, "rt_scene_set_materials");
+    if (st) return st;
+    if (n < 0 || (n > 0 && !m)) return fail(RT_ERR_ARG, "rt_scene_set_materials: bad array");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->data.materials.assign(m, m + n);
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_lights(rt_scene *s, const rt_light *l, int32_t n)
+{
+    rt_status st = check_idle(s, "rt_scene_set_lights");
+    if (st) return st;
+    if (n < 0 || (n > 0 && !l)) return fail(RT_ERR_ARG, "rt_scene_set_lights: bad array");
+    for (int32_t i = 0; i < n; i++)
+        if (l[i].type < RT_LIGHT_AMBIENT || l[i].type > RT_LIGHT_POINT) return fail(RT_ERR_ARG, "rt_scene_set_lights: light %d has unknown type", i);
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->data.lights.assign(l, l + n);
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_environment(rt_scene *s, const float env[3], const float bg[3])
+{
+    rt_status st = check_idle(s, "rt_scene_set_environment");
+    if (st) return st;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (env) memcpy(s->data.env, env, 12);
+    if (bg) memcpy(s->data.bg, bg, 12);
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_photons(rt_scene *s, const rt_photon *photons, uint32_t n_stored)
+{
+    rt_status st = check_idle(s, "rt_scene_set_photons");
+    if (st) return st;
+    if (n_stored > 0 && !photons) return fail(RT_ERR_ARG, "rt_scene_set_photons: photons is NULL");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (n_stored == 0) s->data.photons.clear();
+    else s->data.photons.assign(photons, photons + (size_t)n_stored + 1);
+    s->invalidate(false, true);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_load_xml(rt_scene *s, const char *path)
+{
+    rt_status st = check_idle(s, "rt_scene_load_xml");
+    if (st) return st;
+    if (!path) return fail(RT_ERR_ARG, "rt_scene_load_xml: path is NULL");
+    rt::Scene graph;
+    std::string err;
+    if (!rt::LoadScene(graph, path, &err)) return fail(RT_ERR_IO, "rt_scene_load_xml(%s): %s", path, err.c_str());
+    rt::SceneData d;
+    if (!rt::Lower(graph, d, &err)) return fail(RT_ERR_ARG, "rt_scene_load_xml(%s): %s", path, err.c_str());
+    std::lock_guard<std::mutex> lk(s->mu);
+    d.photons = s->data.photons;
+    s->data = std::move(d);
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_get_camera(const rt_scene *s, rt_camera *out)
+{
+    if (!s || !out) return fail(RT_ERR_ARG, "rt_scene_get_camera: NULL argument");
+    if (!s->data.has_camera) return fail(RT_ERR_STATE, "rt_scene_get_camera: the scene has no camera (not loaded from XML)");
+    *out = s->data.camera;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_counts(const rt_scene *s, int32_t *n_nodes, int32_t *n_meshes, int32_t *n_materials,
+                                     int32_t *n_lights, uint32_t *n_photons)
+{
+    if (!s) return fail(RT_ERR_ARG, "rt_scene_counts: scene is NULL");
+    if (n_nodes) *n_nodes = (int32_t)s->data.nodes.size();
+    if (n_meshes) *n_meshes = (int32_t)s->data.meshes.size();
+    if (n_materials) *n_materials = (int32_t)s->data.materials.size();
+    if (n_lights) *n_lights = (int32_t)s->data.lights.size();
+    if (n_photons) *n_photons = s->data.photons.empty() ? 0u : (uint32_t)(s->data.photons.size() - 1);
+    return RT_OK;
+}
+
+template <class T> static rt_status copy_out(const std::vector<T> &v, T *out, int32_t cap, const char *who)
+{
+    if (!out) return fail(RT_ERR_ARG, "%s: out is NULL", who);
+    if ((size_t)cap < v.size()) return fail(RT_ERR_ARG, "%s: capacity %d < %zu", who, cap, v.size());
+    if (!v.empty()) memcpy(out, v.data(), sizeof(T) * v.size());
+    return RT_OK;
+}
+extern "C" rt_status rt_scene_get_nodes(const rt_scene *s, rt_node *out, int32_t cap) { return s ? copy_out(s->data.nodes, out, cap, "rt_scene_get_nodes") : fail(RT_ERR_ARG, "NULL scene"); }
+extern "C" rt_status rt_scene_get_materials(const rt_scene *s, rt_blinn *out, int32_t cap) { return s ? copy_out(s->data.materials, out, cap, "rt_scene_get_materials") : fail(RT_ERR_ARG, "NULL scene"); }
+extern "C" rt_status rt_scene_get_lights(const rt_scene *s, rt_light *out, int32_t cap) { return s ? copy_out(s->data.lights, out, cap, "rt_scene_get_lights") : fail(RT_ERR_ARG, "NULL scene"); }
+
+extern "C" rt_status rt_scene_mesh_counts(const rt_scene *s, int32_t mesh, int32_t *nv, int32_t *nf, int32_t *nvn, int32_t *nnodes)
+{
+    if (!s || mesh < 0 || (size_t)mesh >= s->data.meshes.size()) return fail(RT_ERR_ARG, "rt_scene_mesh_counts: bad mesh index");
+    const rt::MeshData &m = s->data.meshes[mesh];
+    if (nv) *nv = (int32_t)(m.v.size() / 3);
+    if (nf) *nf = (int32_t)(m.f.size() / 3);
+    if (nvn) *nvn = (int32_t)(m.vn.size() / 3);
+    if (nnodes) *nnodes = (int32_t)m.nodes.size();
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_get_mesh(const rt_scene *s, int32_t mesh, float *v, uint32_t *f, float *vn, uint32_t *fn,
+                                       rt_bvh_node *nodes, uint32_t *elements)
+{
+    if (!s || mesh < 0 || (size_t)mesh >= s->data.meshes.size()) return fail(RT_ERR_ARG, "rt_scene_get_mesh: bad mesh index");
+    const rt::MeshData &m = s->data.meshes[mesh];
+    if (v) memcpy(v, m.v.data(), m.v.size() * 4);
+    if (f) memcpy(f, m.f.data(), m.f.size() * 4);
+    if (vn) memcpy(vn, m.vn.data(), m.vn.size() * 4);
+    if (fn) memcpy(fn, m.fn.data(), m.fn.size() * 4);
+    if (nodes) memcpy(nodes, m.nodes.data(), m.nodes.size() * sizeof(rt_bvh_node));
+    if (elements) memcpy(elements, m.elements.data(), m.elements.size() * 4);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_bvh_build(const float *v, int32_t nv, const uint32_t *f, int32_t nf, int32_t max_per_leaf,
+                                  rt_bvh_node *nodes_out, int32_t *nnodes, uint32_t *elements_out)
+{
+    if (!v || !f || nf <= 0 || nv <= 0 || !nodes_out || !nnodes || !elements_out) return fail(RT_ERR_ARG, "rt_bvh_build: NULL/empty argument");
+    for (int64_t i = 0; i < 3LL * nf; i++) if (f[i] >= (uint32_t)nv) return fail(RT_ERR_ARG, "rt_bvh_build: face index out of range");
+    std::vector<rt_bvh_node> nodes;
+    std::vector<uint32_t> el;
+    rt::BuildMeanSplitBVH(v, f, (unsigned)nf, (unsigned)max_per_leaf, nodes, el);
+    memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(rt_bvh_node));
+    memcpy(elements_out, el.data(), el.size() * 4);
+    *nnodes = (int32_t)nodes.size();
+    return RT_OK;
+}
+
+extern "C" rt_status rt_photon_balance(rt_photon *in, uint32_t n, rt_photon *out)
+{
+    if (!in || !out) return fail(RT_ERR_ARG, "rt_photon_balance: NULL argument");
+    rt::BalancePhotons(in, n, out);
+    return RT_OK;
+}
+
+// ---- lowering to the device ---------------------------------------------------------------------------
+static DeviceState *device_state(rt_scene *s, int device)
+{
+    for (DeviceState *d : s->devs) if (d->device == device) return d;
+    DeviceState *d = new DeviceState;
+    d->device = device;
+    s->devs.push_back(d);
+    return d;
+}
+
+// reference node tree -> device BVH: children's boxes live in the parent, triangles in leaf order
+static rt_status convert_bvh(const rt::MeshData &m, std::vector<DevBvhNode> &out, uint32_t &root_ref, int &depth_out)
+{
+    struct Rec {
+        const rt::MeshData &m; std::vector<DevBvhNode> &out; int max_depth = 0; bool bad = false;
+        uint32_t go(uint32_t id, int depth)
+        {
+            if (id == 0 || id >= m.nodes.size() || depth > 512) { bad = true; return LEAFREF(0, 1); }
+            if (depth > max_depth) max_depth = depth;
+            const rt_bvh_node &n = m.nodes[id];
+            if (n.data & 0x80000000u) {
+                const uint32_t cnt = ((n.data >> 28) & 7u) + 1, off = n.data & 0x0FFFFFFFu;
+                if ((size_t)off + cnt > m.elements.size()) { bad = true; return LEAFREF(0, 1); }
+                return LEAFREF(off, cnt);
+            }
+            const uint32_t c = n.data & 0x7FFFFFFFu;
+            if (c == 0 || (size_t)c + 1 >= m.nodes.size() + 0 || c + 1 >= m.nodes.size()) { bad = true; return LEAFREF(0, 1); }
+            const uint32_t me = (uint32_t)out.size();
+            out.push_back(DevBvhNode{});
+            DevBvhNode d{};
+            memcpy(d.lo0, m.nodes[c].box, 12); memcpy(d.hi0, m.nodes[c].box + 3, 12);
+            memcpy(d.lo1, m.nodes[c + 1].box, 12); memcpy(d.hi1, m.nodes[c + 1].box + 3, 12);
+            d.c0 = go(c, depth + 1);
+            d.c1 = go(c + 1, depth + 1);
+            out[me] = d;
+            return me;
+        }
+        static uint32_t LEAFREF(uint32_t off, uint32_t cnt) { return 0x80000000u | ((cnt - 1) << 28) | (off & 0x0FFFFFFFu); }
+    } r{m, out};
+    root_ref = r.go(1, 1);
+    depth_out = r.max_depth;
+    if (r.bad) return fail(RT_ERR_ARG, "mesh BVH is malformed (child/element index out of range)");
+    return RT_OK;
+}
+
+static rt_status upload_scene(rt_scene *s, DeviceState *D)
+{
+    const rt::SceneData &sd = s->data;
+    if (sd.nodes.empty()) return fail(RT_ERR_STATE, "scene has no nodes");
+    if (sd.nodes.size() > 65535) return fail(RT_ERR_LIMIT, "too many scene nodes (%zu)", sd.nodes.size());
+    const int nn = (int)sd.nodes.size();
+    std::vector<DevNodeXf> xf(nn);
+    std::vector<int32_t> node_mat(nn, 0);
+    std::vector<DevObject> objs;
+    for (int i = 0; i < nn; i++) {
+        const rt_node &n = sd.nodes[i];
+        memcpy(xf[i].itm, n.itm, 36); memcpy(xf[i].pos, n.pos, 12); memcpy(xf[i].tm, n.tm, 36);
+        xf[i].pad[0] = xf[i].pad[1] = xf[i].pad[2] = 0;
+        if (n.obj_type == RT_OBJ_NONE) continue;
+        if (n.material < 0 || (size_t)n.material >= sd.materials.size())
+            return fail(RT_ERR_ARG, "node %d carries an object but its material index %d is invalid", i, n.material);
+        node_mat[i] = n.material;
+        DevObject o{};
+        o.type = n.obj_type; o.mesh = -1; o.material = n.material; o.node = i;
+        if (n.obj_type == RT_OBJ_MESH) {
+            if (n.mesh < 0 || (size_t)n.mesh >= sd.meshes.size() || sd.meshes[n.mesh].f.empty())
+                return fail(RT_ERR_ARG, "node %d references mesh %d which was never set", i, n.mesh);
+            o.mesh = n.mesh;
+        }
+        int chain[64], len = 0;
+        for (int a = i; a >= 0; a = sd.nodes[a].parent) { if (len >= 64) break; chain[len++] = a; }
+        if (len > RT_MAX_DEPTH) return fail(RT_ERR_LIMIT, "node %d is nested %d deep; the device supports %d levels", i, len, RT_MAX_DEPTH);
+        o.chain_len = len;
+        for (int c = 0; c < len; c++) o.chain[c] = chain[len - 1 - c];      // root .. self
+        objs.push_back(o);
+    }
+    if (objs.size() > RT_MAX_OBJECTS) return fail(RT_ERR_LIMIT, "too many objects (%zu)", objs.size());
+
+    rt_status st;
+    if ((st = D->nodes.upload(xf.data(), xf.size() * sizeof(DevNodeXf)))) return st;
+    if ((st = D->objects.upload(objs.data(), objs.size() * sizeof(DevObject)))) return st;
+    if ((st = D->node_material.upload(node_mat.data(), node_mat.size() * 4))) return st;
+    if ((st = D->materials.upload(sd.materials.data(), sd.materials.size() * sizeof(rt_blinn)))) return st;
+    if ((st = D->lights.upload(sd.lights.data(), sd.lights.size() * sizeof(rt_light)))) return st;
+
+    for (auto &mb : D->mesh_bufs) { mb.nodes.release(); mb.tris.release(); mb.tri_face.release(); mb.nrm.release(); }
+    D->mesh_bufs.assign(sd.meshes.size(), DevMeshBufs());
+    std::vector<DevMesh> dm(sd.meshes.size());
+    for (size_t mi = 0; mi < sd.meshes.size(); mi++) {
+        const rt::MeshData &m = sd.meshes[mi];
+        memset(&dm[mi], 0, sizeof(DevMesh));
+        if (m.f.empty()) continue;
+        std::vector<DevBvhNode> bn;
+        uint32_t root_ref = 0;
+        int depth = 0;
+        if ((st = convert_bvh(m, bn, root_ref, depth))) return st;
+        if (depth > RT_BVH_STACK) return fail(RT_ERR_LIMIT, "mesh %zu: BVH depth %d exceeds the device traversal stack (%d)", mi, depth, RT_BVH_STACK);
+        const size_t nf = m.f.size() / 3;
+        std::vector<DevTri> tris(nf);
+        std::vector<uint32_t> tri_face(nf);
+        std::vector<float> nrm(9 * nf);
+        for (size_t sidx = 0; sidx < nf; sidx++) {
+            const uint32_t face = m.elements[sidx];
+            tri_face[sidx] = face;
+            rt::Point3 P[3];
+            for (int k = 0; k < 3; k++) { const float *q = &m.v[3 * (size_t)m.f[3 * (size_t)face + k]]; P[k] = rt::Point3(q[0], q[1], q[2]); }
+            rt::Point3 N = (P[1] - P[0]).Cross(P[2] - P[0]);      // FIN/include/objects.h:234-235
+            N.Normalize();
+            DevTri &T = tris[sidx];
+            T.A[0] = P[0].x; T.A[1] = P[0].y; T.A[2] = P[0].z; T.B[0] = P[1].x; T.B[1] = P[1].y; T.B[2] = P[1].z;
+            T.C[0] = P[2].x; T.C[1] = P[2].y; T.C[2] = P[2].z; T.N[0] = N.x; T.N[1] = N.y; T.N[2] = N.z;
+        }
+        for (size_t face = 0; face < nf; face++)
+            for (int k = 0; k < 3; k++) memcpy(&nrm[9 * face + 3 * k], &m.vn[3 * (size_t)m.fn[3 * face + k]], 12);
+        DevMeshBufs &mb = D->mesh_bufs[mi];
+        if ((st = mb.nodes.upload(bn.data(), bn.size() * sizeof(DevBvhNode)))) return st;
+        if ((st = mb.tris.upload(tris.data(), tris.size() * sizeof(DevTri)))) return st;
+        if ((st = mb.tri_face.upload(tri_face.data(), tri_face.size() * 4))) return st;
+        if ((st = mb.nrm.upload(nrm.data(), nrm.size() * 4))) return st;
+        dm[mi].nodes = (const DevBvhNode *)mb.nodes.p; dm[mi].tris = (const DevTri *)mb.tris.p;
+        dm[mi].tri_face = (const uint32_t *)mb.tri_face.p; dm[mi].nrm = (const float *)mb.nrm.p;
+        memcpy(dm[mi].root_box, m.nodes[1].box, 24);
+        dm[mi].root_ref = root_ref; dm[mi].n_tris = (uint32_t)nf;
+    }
+    if ((st = D->meshes.upload(dm.data(), dm.size() * sizeof(DevMesh)))) return st;
+
+    DevScene &S = D->scene;
+    S.nodes = (const DevNodeXf *)D->nodes.p; S.objects = (const DevObject *)D->objects.p;
+    S.meshes = (const DevMesh *)D->meshes.p; S.materials = (const rt_blinn *)D->materials.p;
+    S.lights = (const rt_light *)D->lights.p; S.node_material = (const int32_t *)D->node_material.p;
+    S.n_nodes = nn; S.n_objects = (int)objs.size(); S.n_meshes = (int)sd.meshes.size();
+    S.n_materials = (int)sd.materials.size(); S.n_lights = (int)sd.lights.size();
+    memcpy(S.env, sd.env, 12); memcpy(S.bg, sd.bg, 12);
+    D->scene_valid = true;
+    return RT_OK;
+}
+
+// Photon::GetDirection (FIN/include/cyPhotonMap.h:158-180), including the reference's
+// `dirX*dirX + dirY-dirY` (:162): z is derived from x alone.
+static void photon_direction(const rt_photon &p, float d[3])
+{
+    const int dirX = p.dir_x, dirY = p.dir_y;
+    d[0] = (float)dirX / (float)0x7FFF;
+    d[1] = (float)dirY / (float)0x7FFF;
+    int dirXY2 = dirX * dirX + dirY - dirY;
+    if (dirXY2 > 0x3FFF0001) dirXY2 = 0x3FFF0001;
+    const int dirZ2 = 0x3FFF0001 - dirXY2;
+    int dirZ = 0, place = 0x40000000, remainder = dirZ2;
+    while (place > remainder) place >>= 2;
+    while (place) {
+        if (remainder >= dirZ + place) { remainder -= dirZ + place; dirZ += place << 1; }
+        dirZ >>= 1;
+        place >>= 2;
+    }
+    d[2] = (float)dirZ / (float)0x7FFF;
+    if (p.plane_and_dirz & 0x8) d[2] = -d[2];
+}
+
+struct PRec { float pos[3], dir[3], maxp, pw[3]; };
+
+// Gather structure: the photons LocatePhotons can reach (it descends only while index <
+// halfStoredPhotons = n/2 - 1, cyPhotonMap.h:217,371, so indices >= 2*half are never visited)
+// re-sorted by recursive median splits into 2^D leaves of <= 64 photons, with the tight box of
+// every subtree in heap order.
+static rt_status upload_photons(rt_scene *s, DeviceState *D)
+{
+    DevPhotonMap &pm = D->scene.pm;
+    memset(&pm, 0, sizeof pm);
+    D->photons_valid = true;
+    const std::vector<rt_photon> &ph = s->data.photons;
+    if (ph.size() < 2) return RT_OK;
+    const uint32_t n = (uint32_t)ph.size() - 1;
+    const long long half = (long long)(n / 2) - 1;
+    long long reach = 2 * half - 1;
+    if (reach < 1) reach = 1;
+    if (reach > (long long)n) reach = n;
+    std::vector<PRec> recs((size_t)reach);
+    for (long long i = 1; i <= reach; i++) {
+        const rt_photon &p = ph[(size_t)i];
+        PRec &r = recs[(size_t)i - 1];
+        memcpy(r.pos, p.position, 12);
+        photon_direction(p, r.dir);
+        r.maxp = p.power;                                               // GetMaxPower :60
+        for (int c = 0; c < 3; c++) r.pw[c] = (p.color[c] / 255.0f) * p.power;   // GetPower :58
+    }
+    uint32_t n_leaves = 1;
+    while ((size_t)n_leaves * RT_LEAF_PHOTONS < recs.size()) n_leaves <<= 1;
+    if (n_leaves > 65536) return fail(RT_ERR_LIMIT, "photon map too large for the gather structure (%zu photons)", recs.size());
+    std::vector<float> tbox(6 * 2 * (size_t)n_leaves);
+    std::vector<float4> pa((size_t)n_leaves * RT_LEAF_PHOTONS), pb(pa.size());
+    std::vector<float2> pc(pa.size());
+    for (size_t i = 0; i < pa.size(); i++) { pa[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0); pb[i] = make_float4(0, 0, 0, 0); pc[i] = make_float2(0, 0); }
+    struct Build {
+        std::vector<PRec> &r; std::vector<float> &tbox; std::vector<float4> &pa, &pb; std::vector<float2> &pc; uint32_t n_leaves;
+        void go(uint32_t node, size_t lo, size_t hi)
+        {
+            float *b = &tbox[6 * (size_t)node];
+            b[0] = b[1] = b[2] = 3.0e38f; b[3] = b[4] = b[5] = -3.0e38f;
+            for (size_t i = lo; i < hi; i++) for (int a = 0; a < 3; a++) { b[a] = std::min(b[a], r[i].pos[a]); b[3 + a] = std::max(b[3 + a], r[i].pos[a]); }
+            if (node >= n_leaves) {
+                const size_t base = (size_t)(node - n_leaves) * RT_LEAF_PHOTONS;
+                for (size_t i = lo; i < hi; i++) {
+                    const PRec &q = r[i];
+                    pa[base + (i - lo)] = make_float4(q.pos[0], q.pos[1], q.pos[2], q.dir[0]);
+                    pb[base + (i - lo)] = make_float4(q.dir[1], q.dir[2], q.maxp, q.pw[0]);
+                    pc[base + (i - lo)] = make_float2(q.pw[1], q.pw[2]);
+                }
+                return;
+            }
+            int axis = 0;
+            const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+            if (ey > ex && ey >= ez) axis = 1; else if (ez > ex && ez > ey) axis = 2;
+            const size_t mid = lo + (hi - lo + 1) / 2;
+            if (hi - lo > 1) std::nth_element(r.begin() + lo, r.begin() + mid, r.begin() + hi,
+                                              [axis](const PRec &x, const PRec &y) { return x.pos[axis] < y.pos[axis]; });
+            go(2 * node, lo, mid);
+            go(2 * node + 1, mid, hi);
+        }
+    } B{recs, tbox, pa, pb, pc, n_leaves};
+    B.go(1, 0, recs.size());
+    rt_status st;
+    if ((st = D->pa.upload(pa.data(), pa.size() * sizeof(float4)))) return st;
+    if ((st = D->pb.upload(pb.data(), pb.size() * sizeof(float4)))) return st;
+    if ((st = D->pc.upload(pc.data(), pc.size() * sizeof(float2)))) return st;
+    if ((st = D->tbox.upload(tbox.data(), tbox.size() * 4))) return st;
+    pm.pa = (const float4 *)D->pa.p; pm.pb = (const float4 *)D->pb.p; pm.pc = (const float2 *)D->pc.p; pm.tbox = (const float *)D->tbox.p;
+    pm.n_leaves = n_leaves; pm.n_photons = (uint32_t)recs.size();
+    return RT_OK;
+}
+
+static rt_status prepare_device(rt_scene *s, int device, DeviceState **out)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(RT_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)"); }
+    if (device < 0 || device >= n) return fail(RT_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    if (!device_is_gfx950(device)) return fail(RT_ERR_NO_DEVICE, "device %d is not gfx950 (MI355X); kernels are built for gfx950 only", device);
+    HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceState *D = device_state(s, device);
+    if (!D->stream) HIP_TRY(hipStreamCreateWithFlags(&D->stream, hipStreamNonBlocking));
+    rt_status st;
+    if (!D->scene_valid) { const DevPhotonMap keep = D->scene.pm; if ((st = upload_scene(s, D))) return st; D->scene.pm = keep; }
+    if (!D->photons_valid) if ((st = upload_photons(s, D))) return st;
+    *out = D;
+    return RT_OK;
+}
+
+// ---- render orchestration ---------------------------------------------------------------------------------
+static size_t chunk_samples_limit()
+{
+    const char *e = getenv("RT_CHUNK_SAMPLES");
+    long long v = e ? atoll(e) : 0;
+    if (v < 4096) v = 4LL << 20;
+    return (size_t)v;
+}
+
+static rt_status ensure_workspace(DeviceState *D, size_t samples, int bounce, size_t list_pixels)
+{
+    rt_status st;
+    if (bounce < 0) bounce = 0;
+    if (bounce > 12) return fail(RT_ERR_LIMIT, "bounce limit %d > 12", bounce);
+    unsigned long long rq_cap = (unsigned long long)samples << bounce;            // worst case: every hit spawns 2 rays
+    unsigned long long pq_cap = ((unsigned long long)samples << (bounce + 1));    // hits on levels 1..bounce
+    const unsigned long long lim = 1ull << 28;
+    if (rq_cap > lim) rq_cap = lim;
+    if (pq_cap > lim) pq_cap = lim;
+    if (rq_cap < 64) rq_cap = 64;
+    if (pq_cap < 64) pq_cap = 64;
+    if ((st = D->sample_rgb.ensure(samples * 12))) return st;
+    if ((st = D->sample_z.ensure(samples * 4))) return st;
+    if ((st = D->sample_hit.ensure(samples))) return st;
+    for (int i = 0; i < 2; i++) for (int k = 0; k < 4; k++) if ((st = D->rq[i][k].ensure((size_t)rq_cap * 16))) return st;
+    for (int k = 0; k < 3; k++) if ((st = D->pq[k].ensure((size_t)pq_cap * 16))) return st;
+    if ((st = D->counts.ensure(CNT_TOTAL * 4))) return st;
+    if ((st = D->pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
+    if (!D->stats.p) { if ((st = D->stats.ensure(ST_COUNT * 8))) return st; }
+    D->ws_samples = samples; D->ws_rq_cap = (uint32_t)rq_cap; D->ws_pq_cap = (uint32_t)pq_cap;
+    return RT_OK;
+}
+
+static DevWork make_work(DeviceState *D)
+{
+    DevWork W;
+    W.sample_rgb = (float *)D->sample_rgb.p; W.sample_z = (float *)D->sample_z.p; W.sample_hit = (uint8_t *)D->sample_hit.p;
+    for (int i = 0; i < 2; i++) {
+        W.rq[i].a = (float4 *)D->rq[i][0].p; W.rq[i].b = (float4 *)D->rq[i][1].p; W.rq[i].c = (float4 *)D->rq[i][2].p;
+        W.rq[i].d = (uint4 *)D->rq[i][3].p; W.rq[i].cap = D->ws_rq_cap;
+    }
+    W.pq.qa = (float4 *)D->pq[0].p; W.pq.qb = (float4 *)D->pq[1].p; W.pq.qc = (float4 *)D->pq[2].p; W.pq.cap = D->ws_pq_cap;
+    W.counts = (uint32_t *)D->counts.p; W.pixel_list = (uint32_t *)D->pixel_list.p;
+    W.stats = (unsigned long long *)D->stats.p;
+    return W;
+}
+
+// camera set-up of RenderPixel, FIN/main.cpp:205-224 (tan in double, everything else float)
+static void camera_setup(const rt_camera &cam, DevCamera &dc)
+{
+    using rt::Point3;
+    const float theta = cam.fov;
+    const float l = cam.focaldist;
+    const float h = (float)(2 * l * tan(theta / 2 * (M_PI / 180)));
+    const float w = h * (float)cam.width / cam.height;
+    Point3 b(-w / 2, h / 2, -l);
+    const float u = w / cam.width;
+    const float v = -h / cam.height;
+    const float du = u / 2, dv = v / 2;
+    b.x += du; b.y += dv;
+    Point3 up(cam.up[0], cam.up[1], cam.up[2]);
+    Point3 z_new = Point3(cam.dir[0], cam.dir[1], cam.dir[2]) * (float)-1;
+    Point3 x_new = up ^ z_new;
+    up.Normalize(); z_new.Normalize(); x_new.Normalize();
+    memcpy(dc.pos, cam.pos, 12);
+    dc.m[0] = x_new.x; dc.m[1] = x_new.y; dc.m[2] = x_new.z;
+    dc.m[3] = up.x; dc.m[4] = up.y; dc.m[5] = up.z;
+    dc.m[6] = z_new.x; dc.m[7] = z_new.y; dc.m[8] = z_new.z;
+    dc.b[0] = b.x; dc.b[1] = b.y; dc.b[2] = b.z;
+    dc.u = u; dc.v = v; dc.width = cam.width; dc.height = cam.height;
+}
+
+static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *t)
+{
+    if (!cam || !p || !t) return fail(RT_ERR_ARG, "render: camera, params and tile range are required");
+    if (cam->width <= 0 || cam->height <= 0 || (long long)cam->width * cam->height > (1LL << 28)) return fail(RT_ERR_ARG, "render: bad image size %dx%d", cam->width, cam->height);
+    if (cam->dof != 0) return fail(RT_ERR_LIMIT, "render: depth of field (camera.dof != 0) is not implemented on the device yet");
+    if (p->min_sample < 1 || p->max_sample < p->min_sample || p->max_sample > 4096) return fail(RT_ERR_ARG, "render: need 1 <= min_sample <= max_sample <= 4096");
+    if (p->shade_model != RT_SHADE_FIN) return fail(RT_ERR_LIMIT, "render: only RT_SHADE_FIN shading is implemented on the device yet");
+    if (p->knn_k < 1 || p->knn_k > 65536 || !(p->knn_radius > 0)) return fail(RT_ERR_ARG, "render: bad photon gather parameters");
+    if (!(p->gamma > 0)) return fail(RT_ERR_ARG, "render: gamma must be positive");
+    if (t->tile_w <= 0 || t->tile_h <= 0 || t->stride <= 0 || t->first < 0) return fail(RT_ERR_ARG, "render: bad tile range");
+    for (const rt_light &l : s->data.lights)
+        if (l.type == RT_LIGHT_POINT && l.size != 0) return fail(RT_ERR_LIMIT, "render: area lights (size != 0) are not implemented on the device yet");
+    return RT_OK;
+}
+
+struct Timing { std::vector<hipEvent_t> ev; std::vector<int> cls; };
+
+static rt_status run_pipeline(DeviceState *D, hipStream_t st, const DevWork &W, const rt_params &P, Timing *tm,
+                              const DevCamera &dc, const DevTiles &dt, uint32_t q0, uint32_t npix, int j0, int ns,
+                              int max_sample, int mode, const float *rays_dev)
+{
+    const int max_blocks = 256 * 5;
+    auto mark = [&](int cls) -> rt_status {
+        if (!tm) return RT_OK;
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventRecord(e, st));
+        tm->ev.push_back(e); tm->cls.push_back(cls);
+        return RT_OK;
+    };
+    rt_status s;
+    // queue counters for levels 0..15 and the photon queue are reset; the pixel list count survives
+    HIP_TRY(hipMemsetAsync(W.counts, 0, (CNT_PHOTONQ + 1) * 4, st));
+    if ((s = mark(-1))) return s;
+    rtk_launch_primary(st, D->scene, W, P, W.rq[1], W.counts + 1, dc, dt, q0, npix, j0, ns, max_sample, mode, rays_dev, max_blocks);
+    for (int level = 1; level <= P.bounce && level < 15; level++)
+        rtk_launch_bounce(st, D->scene, W, P, W.rq[level & 1], W.rq[(level + 1) & 1], W.counts + level + 1, level, max_blocks);
+    if ((s = mark(0))) return s;
+    if (D->scene.pm.n_leaves) {
+        rtk_launch_gather(st, D->scene.pm, W.pq.qa, W.pq.qb, W.pq.qc, W.counts + CNT_PHOTONQ, W.pq.cap, P.knn_k, P.knn_radius,
+                          W.sample_rgb, nullptr, nullptr, 0, W.stats, 256 * 4);
+        if ((s = mark(1))) return s;
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles, int device,
+                              hipStream_t user_stream, bool use_user_stream, uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
+                              bool sync, rt_stats *stats_out, rt_job *job)
+{
+    rt_status st = validate_render(s, cam, p, tiles);
+    if (st) return st;
+    if (!rgb8_dev || !z_dev || !count_dev) return fail(RT_ERR_ARG, "render: output buffers are required");
+    DeviceState *D = nullptr;
+    if ((st = prepare_device(s, device, &D))) return st;
+    hipStream_t stream = use_user_stream ? user_stream : D->stream;
+
+    DevCamera dc;
+    camera_setup(*cam, dc);
+    DevTiles dt;
+    dt.tile_w = tiles->tile_w; dt.tile_h = tiles->tile_h; dt.first = tiles->first; dt.stride = tiles->stride;
+    dt.tiles_x = (cam->width + dt.tile_w - 1) / dt.tile_w;
+    const int tiles_y = (cam->height + dt.tile_h - 1) / dt.tile_h;
+    dt.tiles_total = dt.tiles_x * tiles_y;
+    dt.n_tiles = dt.first >= dt.tiles_total ? 0 : (dt.tiles_total - dt.first + dt.stride - 1) / dt.stride;
+    const uint64_t tile_px = (uint64_t)dt.tile_w * dt.tile_h;
+    const uint64_t total_px = tile_px * (uint64_t)dt.n_tiles;
+
+    const size_t limit = chunk_samples_limit();
+    uint64_t ppc = std::max<uint64_t>(1, limit / (uint64_t)p->max_sample);
+    ppc = std::max<uint64_t>(tile_px, ppc / tile_px * tile_px);
+    ppc = std::min<uint64_t>(ppc, std::max<uint64_t>(total_px, 1));
+    if ((st = ensure_workspace(D, (size_t)ppc * p->max_sample, p->bounce, (size_t)ppc))) return st;
+    const DevWork W = make_work(D);
+    const bool want_stats = stats_out != nullptr || job != nullptr;
+    Timing tm;
+    hipEvent_t e_begin = nullptr, e_end = nullptr;
+    if (want_stats) {
+        HIP_TRY(hipMemsetAsync(W.stats, 0, ST_COUNT * 8, stream));
+        HIP_TRY(hipEventCreate(&e_begin)); HIP_TRY(hipEventCreate(&e_end));
+        HIP_TRY(hipEventRecord(e_begin, stream));
+    }
+    const float inv_gamma = (float)(1.0 / p->gamma);        // powf(x, 1.0/gamma): double quotient narrowed to float
+    uint64_t samples = 0;
+    double ms_resolve = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> resolve_ev;
+    for (uint64_t q0 = 0; q0 < total_px; q0 += ppc) {
+        if (job && job->stop.load()) break;
+        const uint32_t npix = (uint32_t)std::min<uint64_t>(ppc, total_px - q0);
+        HIP_TRY(hipMemsetAsync(W.counts + CNT_PIXLIST, 0, 4, stream));
+        if ((st = run_pipeline(D, stream, W, *p, want_stats ? &tm : nullptr, dc, dt, (uint32_t)q0, npix, 0, p->min_sample, p->max_sample, 0, nullptr))) return st;
+        auto timed_resolve = [&](int phase) -> rt_status {
+            hipEvent_t r0 = nullptr, r1 = nullptr;
+            if (want_stats) { HIP_TRY(hipEventCreate(&r0)); HIP_TRY(hipEventCreate(&r1)); HIP_TRY(hipEventRecord(r0, stream)); }
+            rtk_launch_resolve(stream, W, dc, dt, (uint32_t)q0, npix, p->min_sample, p->max_sample, p->threshold, inv_gamma, phase,
+                               D->scene.bg, rgb8_dev, z_dev, count_dev, 2048);
+            if (want_stats) { HIP_TRY(hipEventRecord(r1, stream)); resolve_ev.emplace_back(r0, r1); }
+            return RT_OK;
+        };
+        if ((st = timed_resolve(0))) return st;
+        if (p->max_sample > p->min_sample) {
+            if ((st = run_pipeline(D, stream, W, *p, want_stats ? &tm : nullptr, dc, dt, (uint32_t)q0, npix, p->min_sample,
+                                   p->max_sample - p->min_sample, p->max_sample, 1, nullptr))) return st;
+            if ((st = timed_resolve(1))) return st;
+        }
+        HIP_TRY(hipGetLastError());
+        samples += (uint64_t)npix * p->min_sample;
+        if (job) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            // pixels of this chunk that lie inside the image
+            int done = 0;
+            for (uint64_t q = q0; q < q0 + npix; q += tile_px) {
+                const int t = dt.first + (int)(q / tile_px) * dt.stride;
+                const int tx = t % dt.tiles_x, ty = t / dt.tiles_x;
+                const int w = std::min(dt.tile_w, cam->width - tx * dt.tile_w), h = std::min(dt.tile_h, cam->height - ty * dt.tile_h);
+                if (w > 0 && h > 0) done += w * h;
+            }
+            job->progress.fetch_add(done);
+        }
+    }
+    if (want_stats) HIP_TRY(hipEventRecord(e_end, stream));
+    if (sync || want_stats) HIP_TRY(hipStreamSynchronize(stream));
+    if (want_stats) {
+        rt_stats R;
+        memset(&R, 0, sizeof R);
+        unsigned long long hs[ST_COUNT];
+        HIP_TRY(hipMemcpy(hs, W.stats, sizeof hs, hipMemcpyDeviceToHost));
+        R.rays_primary = hs[ST_RAYS_PRIMARY]; R.rays_shadow = hs[ST_RAYS_SHADOW]; R.rays_reflect = hs[ST_RAYS_REFLECT];
+        R.rays_refract = hs[ST_RAYS_REFRACT]; R.instance_visits = hs[ST_INSTANCE_VISITS]; R.bvh_nodes_visited = hs[ST_BVH_NODES];
+        R.tris_tested = hs[ST_TRIS]; R.photon_queries = hs[ST_PHOTON_QUERIES]; R.photons_visited = hs[ST_PHOTONS_VISITED];
+        R.pixels = 0; R.samples = hs[ST_RAYS_PRIMARY];
+        for (size_t i = 1; i < tm.ev.size(); i++) {
+            if (tm.cls[i] < 0) continue;
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, tm.ev[i - 1], tm.ev[i]));
+            if (tm.cls[i] == 0) { R.ms_trace += ms; R.launches_trace++; } else { R.ms_gather += ms; R.launches_gather++; }
+        }
+        for (auto &pr : resolve_ev) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+            ms_resolve += ms; R.launches_resolve++;
+            (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+        }
+        R.ms_resolve = ms_resolve;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e_begin, e_end));
+        R.ms_total = ms;
+        for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(e_begin); (void)hipEventDestroy(e_end);
+        for (uint64_t k = 0; k < (uint64_t)dt.n_tiles; k++) {
+            const int t = dt.first + (int)k * dt.stride;
+            const int tx = t % dt.tiles_x, ty = t / dt.tiles_x;
+            const int w = std::min(dt.tile_w, cam->width - tx * dt.tile_w), h = std::min(dt.tile_h, cam->height - ty * dt.tile_h);
+            if (w > 0 && h > 0) R.pixels += (uint64_t)w * h;
+        }
+        if (hs[ST_QUEUE_OVERFLOW]) return fail(RT_ERR_LIMIT, "render: a ray/photon queue overflowed (%llu drops); raise RT_CHUNK_SAMPLES granularity", hs[ST_QUEUE_OVERFLOW]);
+        if (stats_out) *stats_out = R;
+        if (job) job->stats = R;
+    }
+    return RT_OK;
+}
+
+extern "C" rt_status rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles,
+                                            int device, void *hip_stream, uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
+                                            int sync, rt_stats *stats_out)
+{
+    if (!s) return fail(RT_ERR_ARG, "rt_render_tiles_device: scene is NULL");
+    return render_tiles(s, cam, p, tiles, device, (hipStream_t)hip_stream, hip_stream != nullptr, rgb8_dev, z_dev, count_dev,
+                        sync != 0, stats_out, nullptr);
+}
+
+extern "C" rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles, int device,
+                                     uint8_t *rgb8, float *z, uint8_t *count, rt_job **out)
+{
+    if (!s || !out) return fail(RT_ERR_ARG, "rt_render_begin: scene/out is NULL");
+    rt_status st = validate_render(s, cam, p, tiles);
+    if (st) return st;
+    if (!rgb8 || !z || !count) return fail(RT_ERR_ARG, "rt_render_begin: output buffers are required");
+    DeviceState *D = nullptr;
+    if ((st = prepare_device(s, device, &D))) return st;      // fail early (and loudly) when there is no GPU
+    rt_job *job = new rt_job;
+    job->scene = s;
+    s->live_jobs.fetch_add(1);
+    const rt_camera camv = *cam; const rt_params pv = *p; const rt_tile_range tv = *tiles;
+    job->worker = std::thread([=]() {
+        rt_status r = RT_OK;
+        const size_t npx = (size_t)camv.width * camv.height;
+        uint8_t *d_rgb = nullptr, *d_cnt = nullptr; float *d_z = nullptr;
+        auto body = [&]() -> rt_status {
+            HIP_TRY(hipSetDevice(device));
+            HIP_TRY(hipMalloc((void **)&d_rgb, npx * 3)); HIP_TRY(hipMalloc((void **)&d_z, npx * 4)); HIP_TRY(hipMalloc((void **)&d_cnt, npx));
+            HIP_TRY(hipMemcpy(d_rgb, rgb8, npx * 3, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_z, z, npx * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_cnt, count, npx, hipMemcpyHostToDevice));
+            rt_status q = render_tiles(s, &camv, &pv, &tv, device, nullptr, false, d_rgb, d_z, d_cnt, true, nullptr, job);
+            if (q) return q;
+            HIP_TRY(hipMemcpy(rgb8, d_rgb, npx * 3, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(z, d_z, npx * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(count, d_cnt, npx, hipMemcpyDeviceToHost));
+            return RT_OK;
+        };
+        r = body();
+        if (d_rgb) (void)hipFree(d_rgb);
+        if (d_z) (void)hipFree(d_z);
+        if (d_cnt) (void)hipFree(d_cnt);
+        job->status = r;
+        if (r) job->error = g_err;
+        job->done.store(true);
+        s->live_jobs.fetch_sub(1);
+    });
+    *out = job;
+    return RT_OK;
+}
+
+extern "C" int rt_render_progress(rt_job *j) { return j ? j->progress.load() : 0; }
+extern "C" rt_status rt_render_stop(rt_job *j) { if (!j) return fail(RT_ERR_ARG, "rt_render_stop: job is NULL"); j->stop.store(true); return RT_OK; }
+extern "C" rt_status rt_render_wait(rt_job *j)
+{
+    if (!j) return fail(RT_ERR_ARG, "rt_render_wait: job is NULL");
+    if (j->worker.joinable()) j->worker.join();
+    if (j->status) g_err = j->error;
+    return j->status;
+}
+extern "C" rt_status rt_job_stats(rt_job *j, rt_stats *out)
+{
+    if (!j || !out) return fail(RT_ERR_ARG, "rt_job_stats: NULL argument");
+    if (!j->done.load()) return fail(RT_ERR_STATE, "rt_job_stats: job still running");
+    *out = j->stats;
+    return RT_OK;
+}
+extern "C" void rt_job_destroy(rt_job *j)
+{
+    if (!j) return;
+    j->stop.store(true);
+    if (j->worker.joinable()) j->worker.join();
+    delete j;
+}
+
+// ---- single-stage entry points --------------------------------------------------------------------------
+extern "C" rt_status rt_trace_rays(rt_scene *s, int shade_model, int device, const float *rays, int64_t n, uint8_t *hit, float *z,
+                                   float *p, float *N, int32_t *node, uint8_t *front)
+{
+    if (!s || !rays || n < 0 || !hit || !z || !p || !N || !node || !front) return fail(RT_ERR_ARG, "rt_trace_rays: NULL argument");
+    if (shade_model != RT_SHADE_FIN && shade_model != RT_SHADE_P13) return fail(RT_ERR_ARG, "rt_trace_rays: unknown shade model");
+    DeviceState *D = nullptr;
+    rt_status st = prepare_device(s, device, &D);
+    if (st) return st;
+    if (n == 0) return RT_OK;
+    const size_t sizes[6] = {(size_t)n, (size_t)n * 4, (size_t)n * 12, (size_t)n * 12, (size_t)n * 4, (size_t)n};
+    if ((st = D->t_in.upload(rays, (size_t)n * 24))) return st;
+    for (int k = 0; k < 6; k++) if ((st = D->t_out[k].ensure(sizes[k]))) return st;
+    rtk_launch_trace(D->stream, D->scene, shade_model, (const float *)D->t_in.p, n, (uint8_t *)D->t_out[0].p, (float *)D->t_out[1].p,
+                     (float *)D->t_out[2].p, (float *)D->t_out[3].p, (int32_t *)D->t_out[4].p, (uint8_t *)D->t_out[5].p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(D->stream));
+    void *dst[6] = {hit, z, p, N, node, front};
+    for (int k = 0; k < 6; k++) HIP_TRY(hipMemcpy(dst[k], D->t_out[k].p, sizes[k], hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, float radius, const float *pos, const float *normal,
+                                            int64_t n, float *irr, float *dir)
+{
+    if (!s || !pos || !normal || n < 0 || !irr || !dir) return fail(RT_ERR_ARG, "rt_estimate_irradiance: NULL argument");
+    if (k < 1 || k > 65536 || !(radius > 0)) return fail(RT_ERR_ARG, "rt_estimate_irradiance: bad k/radius");
+    DeviceState *D = nullptr;
+    rt_status st = prepare_device(s, device, &D);
+    if (st) return st;
+    if (n == 0) return RT_OK;
+    if (n > (1LL << 28)) return fail(RT_ERR_LIMIT, "rt_estimate_irradiance: too many queries");
+    if (!D->scene.pm.n_leaves) { memset(irr, 0, (size_t)n * 12); memset(dir, 0, (size_t)n * 12); return RT_OK; }
+    std::vector<float4> qa((size_t)n), qb((size_t)n), qc((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        qa[i] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], normal[3 * i]);
+        qb[i] = make_float4(normal[3 * i + 1], normal[3 * i + 2], 0, 0);
+        qc[i] = make_float4(0, 0, 0, 0);
+    }
+    const uint32_t cnt = (uint32_t)n;
+    if ((st = D->t_out[0].upload(qa.data(), (size_t)n * 16))) return st;
+    if ((st = D->t_out[1].upload(qb.data(), (size_t)n * 16))) return st;
+    if ((st = D->t_out[2].upload(qc.data(), (size_t)n * 16))) return st;
+    if ((st = D->t_out[3].ensure((size_t)n * 12))) return st;
+    if ((st = D->t_out[4].ensure((size_t)n * 12))) return st;
+    if ((st = D->t_in.upload(&cnt, 4))) return st;
+    rtk_launch_gather(D->stream, D->scene.pm, (const float4 *)D->t_out[0].p, (const float4 *)D->t_out[1].p, (const float4 *)D->t_out[2].p,
+                      (const uint32_t *)D->t_in.p, cnt, k, radius, nullptr, (float *)D->t_out[3].p, (float *)D->t_out[4].p, 1, nullptr, 256 * 4);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(D->stream));
+    HIP_TRY(hipMemcpy(irr, D->t_out[3].p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dir, D->t_out[4].p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, const float *rays, int64_t n, uint8_t *hit, float *rgb, float *z)
+{
+    if (!s || !p || !rays || n < 0 || !hit || !rgb || !z) return fail(RT_ERR_ARG, "rt_shade_rays: NULL argument");
+    rt_camera cam;
+    memset(&cam, 0, sizeof cam);
+    cam.width = 1; cam.height = 1; cam.fov = 40; cam.focaldist = 1; cam.dir[2] = -1; cam.up[1] = 1;
+    rt_tile_range tr = {1, 1, 0, 1};
+    rt_params pv = *p;
+    pv.min_sample = pv.max_sample = 1;
+    rt_status st = validate_render(s, &cam, &pv, &tr);
+    if (st) return st;
+    DeviceState *D = nullptr;
+    if ((st = prepare_device(s, device, &D))) return st;
+    if (n == 0) return RT_OK;
+    const size_t limit = chunk_samples_limit();
+    const size_t chunk = (size_t)std::min<int64_t>(n, (int64_t)limit);
+    if ((st = ensure_workspace(D, chunk, pv.bounce, 1))) return st;
+    const DevWork W = make_work(D);
+    DevCamera dc; camera_setup(cam, dc);
+    DevTiles dt; memset(&dt, 0, sizeof dt);
+    HIP_TRY(hipMemsetAsync(W.stats, 0, ST_COUNT * 8, D->stream));
+    for (int64_t off = 0; off < n; off += (int64_t)chunk) {
+        const uint32_t m = (uint32_t)std::min<int64_t>((int64_t)chunk, n - off);
+        if ((st = D->t_in.upload(rays + 6 * off, (size_t)m * 24))) return st;
+        HIP_TRY(hipMemsetAsync(W.sample_hit, 0, m, D->stream));
+        HIP_TRY(hipMemsetAsync(W.sample_rgb, 0, (size_t)m * 12, D->stream));
+        if ((st = run_pipeline(D, D->stream, W, pv, nullptr, dc, dt, 0, m, 0, 1, 1, 2, (const float *)D->t_in.p))) return st;
+        HIP_TRY(hipStreamSynchronize(D->stream));
+        HIP_TRY(hipMemcpy(hit + off, W.sample_hit, m, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rgb + 3 * off, W.sample_rgb, (size_t)m * 12, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(z + off, W.sample_z, (size_t)m * 4, hipMemcpyDeviceToHost));
+    }
+    unsigned long long hs[ST_COUNT];
+    HIP_TRY(hipMemcpy(hs, W.stats, sizeof hs, hipMemcpyDeviceToHost));
+    if (hs[ST_QUEUE_OVERFLOW]) return fail(RT_ERR_LIMIT, "rt_shade_rays: queue overflow");
+    for (int64_t i = 0; i < n; i++) if (!hit[i]) z[i] = 1.0e30f;
+    return RT_OK;
+}

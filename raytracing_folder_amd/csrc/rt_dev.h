@@ -1,0 +1,128 @@
+// rt_dev.h -- device-side data layout of a lowered scene, shared by rt_api.cpp (which builds
+// and uploads it) and rt_kernels.hip (which reads it).  gfx950 only.
+//
+// HBM layout (all arrays are plain hipMalloc allocations owned by the rt_scene):
+//   nodes      DevNodeXf[n_nodes]      96 B each: itm(9) pos(3) tm(9) -- read with scalar loads
+//   objects    DevObject[n_objects]    one per node that carries an Object, in TraceNode order;
+//                                      `chain` = ancestor node indices root..self (every level's
+//                                      ToNodeCoords is applied in turn, exactly like the
+//                                      recursion in FIN/main.cpp:108-130)
+//   per mesh   DevBvhNode[ ]           64 B: both children's boxes + child refs (one visit = one
+//                                      64-byte read, no separate child fetch)
+//              DevTri[ ]               48 B: A, B, C, unit face normal -- in LEAF order, so a
+//                                      leaf's triangles are contiguous
+//              tri_face[ ]             face id per leaf-ordered triangle (read on accepted hits)
+//              nrm[ ]                  36 B per face: the three vertex normals (read once per ray)
+//   photons    DevPhoton slots in leaf-major order, 64 slots per leaf (padded with +inf
+//              positions), pa = (pos.xyz, dir.x), pb = (dir.y, dir.z, maxPower, power.r),
+//              pc = (power.g, power.b); tbox = heap-ordered boxes of the complete binary tree
+//              over the leaves (root = 1, leaves at [n_leaves, 2 n_leaves))
+#ifndef RT_DEV_H
+#define RT_DEV_H
+
+#include <stdint.h>
+#include "../../include/rt_mi355x.h"
+
+#define RT_MAX_DEPTH      8      // scene-graph nesting supported on the device
+#define RT_MAX_OBJECTS    4096
+#define RT_BVH_STACK      32     // per-lane traversal stack entries (LDS)
+#define RT_BLOCK          256    // threads per workgroup of the trace/shade kernels
+#define RT_LEAF_PHOTONS   64     // photon slots per gather leaf = one wavefront
+#define RT_GATHER_WAVES   4      // waves per gather workgroup
+#define RT_LEAFLIST_CAP   64     // leaf ids kept per query in LDS before the slow path
+
+struct DevNodeXf { float itm[9]; float pos[3]; float tm[9]; float pad[3]; };
+
+struct DevObject {
+    int32_t type, mesh, material, node;
+    int32_t chain_len;
+    int32_t chain[RT_MAX_DEPTH];
+    int32_t pad[3];
+};
+
+struct DevBvhNode {              // 64 bytes
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    uint32_t c0, c1;             // bit31: leaf (bits28-30 count-1, bits0-27 first triangle slot)
+    uint32_t pad[2];
+};
+
+struct DevTri { float A[3], B[3], C[3], N[3]; };   // 48 bytes
+
+struct DevMesh {
+    const DevBvhNode *nodes;
+    const DevTri     *tris;
+    const uint32_t   *tri_face;
+    const float      *nrm;       // 9 floats per face: vn[fn0], vn[fn1], vn[fn2]
+    float    root_box[6];
+    uint32_t root_ref;           // child-ref encoding of the root (leaf or node index)
+    uint32_t n_tris;
+};
+
+struct DevPhotonMap {
+    const float4 *pa;            // [n_leaves*64]
+    const float4 *pb;
+    const float2 *pc;
+    const float  *tbox;          // [2*n_leaves][6]
+    uint32_t n_leaves;           // power of two, 0 = no photon map
+    uint32_t n_photons;          // photons stored in the leaves
+};
+
+struct DevScene {
+    const DevNodeXf *nodes;
+    const DevObject *objects;
+    const DevMesh   *meshes;
+    const rt_blinn  *materials;
+    const rt_light  *lights;
+    const int32_t   *node_material;   // material index per node
+    int32_t n_nodes, n_objects, n_meshes, n_materials, n_lights;
+    float env[3], bg[3];
+    DevPhotonMap pm;
+};
+
+// camera set-up computed once on the host the way RenderPixel does it per thread
+// (FIN/main.cpp:205-224)
+struct DevCamera {
+    float pos[3];
+    float m[9];          // Matrix3(x_new, up, z_new), column-major
+    float b[3];          // pixel (0,0) sample origin incl. the half-pixel shift
+    float u, v;          // pixel pitch
+    int32_t width, height;
+};
+
+// tile walk of one rt_render_* call
+struct DevTiles {
+    int32_t tile_w, tile_h, first, stride;
+    int32_t tiles_x, tiles_total;
+    int32_t n_tiles;          // tiles owned by this call
+};
+
+// device-side statistics block (uint64 counters, see rt_stats)
+enum {
+    ST_RAYS_PRIMARY = 0, ST_RAYS_SHADOW, ST_RAYS_REFLECT, ST_RAYS_REFRACT,
+    ST_INSTANCE_VISITS, ST_BVH_NODES, ST_TRIS, ST_PHOTON_QUERIES, ST_PHOTONS_VISITED,
+    ST_QUEUE_OVERFLOW, ST_COUNT
+};
+
+// ray queue: structure of arrays of float4 (one 16-byte coalesced read per lane per array)
+//   a = (o.xyz, d.x)   b = (d.yz, thr.r, thr.g)   c = (thr.b, absorb.rgb)   d = (slot, bounce|kind<<8, -, -) as uint bits
+struct DevRayQueue { float4 *a, *b, *c; uint4 *d; uint32_t cap; };
+// photon query queue: qa = (pos.xyz, N.x)  qb = (N.yz, w.r, w.g)  qc = (w.b, slot bits, -, -)
+struct DevPhotonQueue { float4 *qa, *qb, *qc; uint32_t cap; };
+
+// per-chunk working set
+struct DevWork {
+    float   *sample_rgb;      // [chunk_pixels*max_sample*3]
+    float   *sample_z;        // [chunk_pixels*max_sample]
+    uint8_t *sample_hit;      // [chunk_pixels*max_sample]
+    DevRayQueue rq[2];
+    DevPhotonQueue pq;
+    uint32_t *counts;         // [0..15] ray-queue counts per level, [16] photon queue, [17] pixel list
+    uint32_t *pixel_list;     // pixels (chunk-local) that take the second sample batch
+    unsigned long long *stats;
+};
+#define CNT_PHOTONQ 16
+#define CNT_PIXLIST 17
+#define CNT_TOTAL   32
+
+#endif

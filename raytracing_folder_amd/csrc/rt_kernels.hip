@@ -1,0 +1,1055 @@
+// rt_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the render path.
+//
+//   k_primary   K1+K2+K3+K4  primary-ray generation, closest-hit traversal, Blinn shade with an
+//                            any-hit shadow ray per light, child-ray spawn (wave-aggregated push)
+//   k_bounce    K2+K3+K4     the same for one level of the reflection/refraction ray tree
+//   k_gather    K5           k-nearest photon gather, one query per wavefront step
+//   k_resolve   K6           per-pixel average / variance gate / gamma / Color24 pack
+//   k_trace     K2           closest-hit only (parity entry point rt_trace_rays)
+//
+// The arithmetic of every device function follows the reference operation by operation (same
+// expression order, thresholds and quirks; file:line cited per function, FIN = /root/reference/
+// RayTracingFinal/RayTracingFinal) and the file is compiled with -ffp-contract=off, so hit
+// records agree with the CPU oracle bit for bit and colours to the last ulp of powf/expf.
+// What differs is control: the recursion of TraceNode/TraceBVHNode/Shade becomes loops, ray
+// queues and a per-lane LDS stack; zero-weight subtrees are not traced; the shadow ray is an
+// any-hit query; BVH boxes are culled against the closest hit so far.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "rt_dev.h"
+
+#define BIGFLOAT 1.0e30f
+#define LEAF_BIT 0x80000000u
+
+// ------------------------------------------------------------------------------------------------
+// float3 algebra in the reference's evaluation order (cyPoint.h:259-350, cyMatrix.h:542-546)
+// ------------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 p) { return mk(a.y * p.z - a.z * p.y, a.z * p.x - a.x * p.z, a.x * p.y - a.y * p.x); }
+__device__ __forceinline__ float len2(V3 a) { return dot(a, a); }
+__device__ __forceinline__ V3 normalize(V3 a) { return a / sqrtf(len2(a)); }
+__device__ __forceinline__ V3 mmul(const float *d, V3 p)
+{
+    return mk(p.x * d[0] + p.y * d[3] + p.z * d[6], p.x * d[1] + p.y * d[4] + p.z * d[7], p.x * d[2] + p.y * d[5] + p.z * d[8]);
+}
+__device__ __forceinline__ V3 mtmul(const float *d, V3 v)      // TransposeMult, scene.h:254-261
+{
+    return mk(dot(mk(d[0], d[1], d[2]), v), dot(mk(d[3], d[4], d[5]), v), dot(mk(d[6], d[7], d[8]), v));
+}
+#define RMAX(a, b) ((a) > (b) ? (a) : (b))     // the reference's macros, scene.h:48-54
+#define RMIN(a, b) ((a) < (b) ? (a) : (b))
+
+struct Counters { uint32_t inst, nodes, tris, shadow; };
+
+struct Hit { float z; V3 p, N; int node; int front; };
+
+// ------------------------------------------------------------------------------------------------
+// primitives (object space)
+// ------------------------------------------------------------------------------------------------
+// Sphere::IntersectRay, FIN/include/objects.h:24-70
+__device__ __forceinline__ bool sphere_hit(V3 rp, V3 rd, float &z, V3 &hp, V3 &hN, int &front)
+{
+    const float a = dot(rd, rd);
+    const float c = dot(rp, rp) - 1;
+    const float b = 2 * dot(rp, rd);
+    const float insqrt = b * b - (4 * a * c);
+    const float zero = 0.001f;
+    if (insqrt >= zero) {
+        const float sq = sqrtf(insqrt);
+        const float t1 = (-b + sq) / (a * 2);
+        const float t2 = (-b - sq) / (a * 2);
+        const float prez = z;
+        if (t2 >= prez) return false;
+        if (t1 > zero && t2 < zero && t1 < prez) {
+            z = t1; front = 0;
+            hp = rd * z + rp; hN = normalize(hp);
+            return true;
+        } else if (t1 > zero && t2 > zero && t2 < prez) {
+            z = t2; front = 1;
+            hp = rd * z + rp; hN = normalize(hp);
+            return true;
+        }
+    }
+    return false;
+}
+
+// Plane::IntersectRay, FIN/include/objects.h:84-111 (P13 flips `front`, P13/include/objects.h:98-101)
+__device__ __forceinline__ bool plane_hit(int model, V3 P, V3 d, float &z, V3 &hp, V3 &hN, int &front)
+{
+    const float zero = 0.001f;
+    const float t = -(P.z / d.z);
+    if (t >= zero && t < BIGFLOAT && t < z) {
+        const V3 Hitp = P + d * t;
+        if (Hitp.x >= -1 && Hitp.x <= 1 && Hitp.y >= -1 && Hitp.y <= 1) {
+            z = t; hp = Hitp; hN = mk(0, 0, 1);
+            const float nd = dot(mk(0, 0, 1), d);
+            front = (model == RT_SHADE_P13) ? ((nd < 0.0f) ? 0 : 1) : ((nd <= 0.0f) ? 1 : 0);
+            return true;
+        }
+    }
+    return false;
+}
+
+// Slab test against a node box.  Box::IntersectRay (FIN/scene.cpp:11-65) is only conservative
+// (accepts boxes behind the ray, never culls by distance); this one culls against the closest
+// hit so far and is padded by 2e-6 relative so that reciprocal rounding never rejects a box
+// whose triangle the exact test would accept.  Returns the entry distance, or BIGFLOAT*2.
+__device__ __forceinline__ float box_entry(const float *lo, const float *hi, V3 o, V3 inv, float zbest)
+{
+    const float t0x = (lo[0] - o.x) * inv.x, t1x = (hi[0] - o.x) * inv.x;
+    const float t0y = (lo[1] - o.y) * inv.y, t1y = (hi[1] - o.y) * inv.y;
+    const float t0z = (lo[2] - o.z) * inv.z, t1z = (hi[2] - o.z) * inv.z;
+    // fminf/fmaxf drop NaN operands (0*inf when the origin lies on a slab plane and dir == 0)
+    const float tenter = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    const float texit = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    const bool hit = (texit >= 0.0f) && (tenter <= texit * 1.000002f) && (tenter * 0.999998f <= zbest);
+    return hit ? tenter : 3.0e30f;
+}
+
+// TriObj::TriangleArea, FIN/include/objects.h:146-157
+__device__ __forceinline__ float tri_area(int i, V3 A, V3 B, V3 C)
+{
+    if (i == 0) return (B.y - A.y) * (C.z - A.z) - (C.y - A.y) * (B.z - A.z);
+    if (i == 1) return (B.x - A.x) * (C.z - A.z) - (C.x - A.x) * (B.z - A.z);
+    return (B.x - A.x) * (C.y - A.y) - (C.x - A.x) * (B.y - A.y);
+}
+
+// TriObj::IntersectTriangle, FIN/include/objects.h:226-267.  N (unit face normal) is precomputed
+// with the same expression on the host.  Returns barycentrics; normal interpolation is deferred.
+__device__ __forceinline__ bool tri_hit_fin(const DevTri &T, V3 rp, V3 rd, float &z, V3 &hp, V3 &bc, int &front)
+{
+    const V3 A = ld3(T.A), B = ld3(T.B), C = ld3(T.C), N = ld3(T.N);
+    const float dz = dot(rd, N);
+    if (fabsf(dz) < 1e-7f) return false;
+    const float pz = dot(rp - A, N);
+    const float t = -pz / dz;
+    if (t <= 0.001f) return false;
+    if (t < z) {
+        const V3 p = rp + rd * t;
+        int ign;
+        const float ax = fabsf(N.x), ay = fabsf(N.y), az = fabsf(N.z);
+        if (ax > ay && ax > az) ign = 0; else if (ay > az) ign = 1; else ign = 2;
+        const float s = 1.f / tri_area(ign, A, B, C);
+        const float a = tri_area(ign, p, B, C) * s;
+        const float b = tri_area(ign, p, C, A) * s;
+        const float c = 1.f - a - b;
+        if (a < 0 || b < 0 || c < 0) return false;
+        z = t; hp = p; bc = mk(a, b, c); front = (dz <= 0) ? 1 : 0;
+        return true;
+    }
+    return false;
+}
+
+// TriObj::IntersectTriangle, P13/include/objects.h:148-206 (back-face culled, bias 1e-7)
+__device__ __forceinline__ bool tri_hit_p13(const DevTri &T, V3 rp, V3 rd, float &z, V3 &hp, V3 &bc, int &front)
+{
+    const float bias = 1e-7f;
+    const V3 A = ld3(T.A), B = ld3(T.B), C = ld3(T.C), tN = ld3(T.N);
+    if (dot(tN, rp - A) < bias) return false;
+    const float den = dot(tN, rd);
+    if (den == 0) return false;
+    const float t = dot(tN, C - rp) / den;
+    if (t < bias || t >= z || t >= BIGFLOAT) return false;
+    const float fx = fabsf(tN.x), fy = fabsf(tN.y), fz = fabsf(tN.z);
+    const float maxN = fmaxf(fz, fmaxf(fx, fy));
+    const V3 P = rp + rd * t;
+    float pax, pay, pbx, pby, pcx, pcy, ppx, ppy;
+    if (maxN == fx)      { pax = A.y; pay = A.z; pbx = B.y; pby = B.z; pcx = C.y; pcy = C.z; ppx = P.y; ppy = P.z; }
+    else if (maxN == fy) { pax = A.x; pay = A.z; pbx = B.x; pby = B.z; pcx = C.x; pcy = C.z; ppx = P.x; ppy = P.z; }
+    else                 { pax = A.x; pay = A.y; pbx = B.x; pby = B.y; pcx = C.x; pcy = C.y; ppx = P.x; ppy = P.y; }
+    const float area_tri = (pax - pcx) * (pby - pcy) - (pay - pcy) * (pbx - pcx);
+    const float area_bcp = (ppx - pcx) * (pby - pcy) - (ppy - pcy) * (pbx - pcx);
+    const float area_acp = (pax - pcx) * (ppy - pcy) - (pay - pcy) * (ppx - pcx);
+    const float alpha = area_bcp / area_tri;
+    const float beta = area_acp / area_tri;
+    const float gam = (float)(1.0 - (double)alpha - (double)beta);
+    if (alpha < -bias || beta < -bias || gam < -bias || alpha > 1.0f || beta > 1.0f || gam > 1.0f) return false;
+    z = t; bc = mk(alpha, beta, gam); front = 1;
+    hp = A * alpha + B * beta + C * gam;
+    return true;
+}
+
+// TriObj::IntersectRay -> TraceBVHNode (FIN/include/objects.h:127-133, 271-302) as an iterative,
+// near-first traversal with a per-lane stack in LDS.  ANY: stop at the first accepted triangle.
+template <bool ANY>
+__device__ bool mesh_hit(const DevMesh &M, int model, V3 o, V3 d, float &z, V3 &hp, V3 &hN, int &front,
+                         uint32_t *stack, Counters &cnt)
+{
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (box_entry(M.root_box, M.root_box + 3, o, inv, z) > 2.0e30f) return false;
+    uint32_t cur = M.root_ref;
+    int sp = 0;
+    bool any = false;
+    uint32_t best_slot = 0;
+    V3 bc = mk(0, 0, 0);
+    for (;;) {
+        if (cur & LEAF_BIT) {
+            const uint32_t count = ((cur >> 28) & 7u) + 1;
+            const uint32_t first = cur & 0x0FFFFFFFu;
+            for (uint32_t i = 0; i < count; i++) {
+                const DevTri T = M.tris[first + i];
+                cnt.tris++;
+                const bool h = (model == RT_SHADE_P13) ? tri_hit_p13(T, o, d, z, hp, bc, front)
+                                                       : tri_hit_fin(T, o, d, z, hp, bc, front);
+                if (h) { any = true; best_slot = first + i; }
+            }
+            if (ANY && any) return true;
+            if (sp == 0) break;
+            cur = stack[(--sp) * RT_BLOCK];
+        } else {
+            const DevBvhNode nd = M.nodes[cur];
+            cnt.nodes++;
+            const float e0 = box_entry(nd.lo0, nd.hi0, o, inv, z);
+            const float e1 = box_entry(nd.lo1, nd.hi1, o, inv, z);
+            const bool h0 = e0 < 2.0e30f, h1 = e1 < 2.0e30f;
+            if (h0 && h1) {
+                const bool first0 = e0 <= e1;
+                if (sp < RT_BVH_STACK) stack[(sp++) * RT_BLOCK] = first0 ? nd.c1 : nd.c0;
+                cur = first0 ? nd.c0 : nd.c1;
+            } else if (h0) cur = nd.c0;
+            else if (h1) cur = nd.c1;
+            else { if (sp == 0) break; cur = stack[(--sp) * RT_BLOCK]; }
+        }
+    }
+    if (!any) return false;
+    // cyTriMesh::GetNormal = vn[fn0]*bc.x + vn[fn1]*bc.y + vn[fn2]*bc.z (cyTriMesh.h:167,191)
+    const float *n9 = M.nrm + 9 * (size_t)M.tri_face[best_slot];
+    const V3 Ni = ld3(n9) * bc.x + ld3(n9 + 3) * bc.y + ld3(n9 + 6) * bc.z;
+    hN = (model == RT_SHADE_P13) ? normalize(Ni) : Ni;     // FIN leaves it un-normalised (:262)
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TraceNode(rootNode, ray, hit), FIN/main.cpp:108-130, flattened: for every node that carries an
+// Object (in the recursion's visiting order) the ray is taken through ToNodeCoords of each
+// ancestor in turn (scene.h:502-508; direction NOT renormalised, so t is shared by all spaces),
+// and the closest hit is brought back through FromNodeCoords of each ancestor (scene.h:509-513).
+// ------------------------------------------------------------------------------------------------
+template <bool ANY>
+__device__ bool trace(const DevScene &S, int model, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt)
+{
+    float z = zinit;
+    int best = -1, bfront = 1;
+    V3 bp = mk(0, 0, 0), bN = mk(0, 0, 0);
+    for (int oi = 0; oi < S.n_objects; oi++) {
+        const DevObject &ob = S.objects[oi];
+        V3 lp = o, ldir = d;
+        for (int c = 0; c < ob.chain_len; c++) {
+            const DevNodeXf &X = S.nodes[ob.chain[c]];
+            const V3 pos = ld3(X.pos);
+            const V3 rp = mmul(X.itm, lp - pos);
+            ldir = mmul(X.itm, (lp + ldir) - pos) - rp;
+            lp = rp;
+        }
+        cnt.inst++;
+        V3 hp, hN;
+        int fr = 1;
+        bool hit = false;
+        if (ob.type == RT_OBJ_SPHERE) hit = sphere_hit(lp, ldir, z, hp, hN, fr);
+        else if (ob.type == RT_OBJ_PLANE) hit = plane_hit(model, lp, ldir, z, hp, hN, fr);
+        else if (ob.type == RT_OBJ_MESH) hit = mesh_hit<ANY>(S.meshes[ob.mesh], model, lp, ldir, z, hp, hN, fr, stack, cnt);
+        if (hit) {
+            if (ANY) return true;
+            best = oi; bp = hp; bN = hN; bfront = fr;
+        }
+    }
+    if (best < 0) return false;
+    const DevObject &ob = S.objects[best];
+    for (int c = ob.chain_len - 1; c >= 0; c--) {
+        const DevNodeXf &X = S.nodes[ob.chain[c]];
+        bp = mmul(X.tm, bp) + ld3(X.pos);
+        bN = normalize(mtmul(X.itm, bN));
+    }
+    h.z = z; h.p = bp; h.N = bN; h.node = ob.node; h.front = bfront;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// queues: wave-aggregated append (one atomic per wave, __ballot + popcount for the lane offset)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_push(bool pred, uint32_t *counter)
+{
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) return 0xFFFFFFFFu;
+    const int lane = __lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    const uint32_t off = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    return pred ? base + off : 0xFFFFFFFFu;
+}
+
+#define KIND_REFLECT 0u
+#define KIND_REFRACT 1u
+
+struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; bool primary; };
+
+struct ShadeCtx {
+    DevScene S; DevWork W; rt_params P;
+    DevRayQueue qout; uint32_t *qout_count;
+};
+
+// Attenuation, FIN/include/materials.h:60-66 (exp on floats resolves to the float overload)
+__device__ __forceinline__ V3 attenuation(V3 a, float l) { return mk(expf(-a.x * l), expf(-a.y * l), expf(-a.z * l)); }
+
+// Light::Direction (FIN/include/lights.h:35,51,159)
+__device__ __forceinline__ V3 light_direction(const rt_light &l, V3 p)
+{
+    if (l.type == RT_LIGHT_POINT) return normalize(p - ld3(l.position));
+    if (l.type == RT_LIGHT_DIRECT) return ld3(l.direction);
+    return mk(0, 0, 0);
+}
+
+// Light::Illuminate (FIN/include/lights.h:34,50,67-131; P13/include/lights.h:65-91) for light
+// size 0: the MIN_SHADOW_SAMPLES sample rays coincide (every disc offset has length 0), their mean
+// is exactly 0 or 1 and the refinement loop never runs, so ONE any-hit shadow query (GenLight::
+// Shadow, FIN/main.cpp:499-513: occluded iff 1e-14 < z < t_max) decides it.  size > 0 is rejected
+// by the host API for now (stochastic soft shadows: SURVEY 8(f3)).
+__device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &l, V3 p, uint32_t *stack, Counters &cnt)
+{
+    const V3 I = ld3(l.intensity);
+    if (l.type == RT_LIGHT_AMBIENT) return I;
+    Hit dummy;
+    if (l.type == RT_LIGHT_DIRECT) {
+        cnt.shadow++;
+        const bool occ = trace<true>(S, P.shade_model, p, -ld3(l.direction), BIGFLOAT, dummy, stack, cnt);
+        return I * (occ ? 0.0f : 1.0f);
+    }
+    const V3 position = ld3(l.position);
+    cnt.shadow++;
+    const bool occ = trace<true>(S, P.shade_model, p, position - p, 1.0f, dummy, stack, cnt);
+    const int ns = P.shadow_samples > 0 ? P.shadow_samples : 4;
+    float coefsum = 0.0f;
+    for (int i = 0; i < ns; i++) coefsum += occ ? 0.0f : 1.0f;     // the ns identical samples
+    if (P.shade_model == RT_SHADE_P13)                              // intensity*coef/SAMPLES, then /dist^2
+        return ((I * coefsum) / (float)ns) / len2(p - position);
+    const float shadow = coefsum / (float)ns;
+    return (I * shadow) / len2(p - position);                       // lights.h:130
+}
+
+__device__ __forceinline__ void add_sample(const ShadeCtx &C, uint32_t slot, V3 c, bool primary)
+{
+    float *dst = C.W.sample_rgb + 3 * (size_t)slot;
+    if (primary) { dst[0] = c.x; dst[1] = c.y; dst[2] = c.z; }
+    else { atomicAdd(dst, c.x); atomicAdd(dst + 1, c.y); atomicAdd(dst + 2, c.z); }
+}
+
+__device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 d, V3 thr, V3 absorb,
+                                         uint32_t slot, int bounce, uint32_t kind)
+{
+    const uint32_t idx = wave_push(pred, C.qout_count);
+    if (pred) {
+        if (idx < C.qout.cap) {
+            C.qout.a[idx] = make_float4(o.x, o.y, o.z, d.x);
+            C.qout.b[idx] = make_float4(d.y, d.z, thr.x, thr.y);
+            C.qout.c[idx] = make_float4(thr.z, absorb.x, absorb.y, absorb.z);
+            C.qout.d[idx] = make_uint4(slot, (uint32_t)bounce | (kind << 8), 0u, 0u);
+        } else atomicAdd(&C.W.stats[ST_QUEUE_OVERFLOW], 1ull);
+    }
+}
+
+__device__ __forceinline__ void push_photon_query(const ShadeCtx &C, bool pred, V3 p, V3 N, V3 w, uint32_t slot)
+{
+    const uint32_t idx = wave_push(pred, C.W.counts + CNT_PHOTONQ);
+    if (pred) {
+        if (idx < C.W.pq.cap) {
+            C.W.pq.qa[idx] = make_float4(p.x, p.y, p.z, N.x);
+            C.W.pq.qb[idx] = make_float4(N.y, N.z, w.x, w.y);
+            C.W.pq.qc[idx] = make_float4(w.z, __uint_as_float(slot), 0.f, 0.f);
+        } else atomicAdd(&C.W.stats[ST_QUEUE_OVERFLOW], 1ull);
+    }
+}
+
+// One node of the ray tree: Trace + MtlBlinn::Shade (FIN/main.cpp:294-297, 516-708) with the
+// recursion unrolled into queue pushes.  Shade is linear in its children (color += K*child), so a
+// ray carries the product `thr` of the K factors above it and adds thr*local colour to its sample;
+// the child's own K = rK*Attenuation(parent absorption, child z) when the child hit is a back face
+// (:620,:632) is folded in here, where the child hit is known.
+__device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uint32_t *stack, Counters &cnt)
+{
+    const DevScene &S = C.S;
+    const rt_params &P = C.P;
+    Hit h;
+    bool hit = false;
+    if (active) hit = trace<false>(S, P.shade_model, in.o, in.d, BIGFLOAT, h, stack, cnt);
+    V3 thr = in.thr;
+    bool want_refl = false, want_refr = false, want_photon = false;
+    V3 rK = mk(0, 0, 0), tK = mk(0, 0, 0), rDir = mk(0, 0, 0), tDir = mk(0, 0, 0), kd = mk(0, 0, 0), N = mk(0, 0, 0), absorption = mk(0, 0, 0);
+    if (active && !hit) {
+        if (in.primary) C.W.sample_hit[in.slot] = 0;
+        else if (in.kind == KIND_REFRACT) add_sample(C, in.slot, thr * ld3(S.env), false);   // :635, SampleEnvironment without a texture
+    }
+    if (active && hit) {
+        if (in.primary) { C.W.sample_hit[in.slot] = 1; C.W.sample_z[in.slot] = h.z; }
+        else if (!h.front) thr = thr * attenuation(in.absorb, h.z);
+        const rt_blinn &m = S.materials[S.node_material[h.node]];
+        V3 color = ld3(m.emission);                                         // :517
+        const V3 p = h.p;
+        N = normalize(h.N);                                                 // :521-522
+        const V3 direction = normalize(-in.d);                              // :523-524
+        kd = ld3(m.diffuse);
+        const V3 ks = ld3(m.specular);
+        const float gloss = m.glossiness;
+        const V3 reflection = ld3(m.reflection), refraction = ld3(m.refraction);
+        const float ior = m.ior;
+        absorption = ld3(m.absorption);
+        const float coef = S.n_lights == 0 ? 1.0f : 1.0f / S.n_lights;      // :545
+        for (int li = 0; li < S.n_lights; li++) {
+            const rt_light &light = S.lights[li];
+            if (!h.front) {
+                // the reference still calls Illuminate (its shadow rays) but uses the result only
+                // for front hits (:551-553); nothing to add for a back-face hit
+                continue;
+            }
+            const V3 Il = illuminate(S, P, light, p, stack, cnt);
+            if (light.type != RT_LIGHT_AMBIENT) {
+                const V3 intensity = Il * coef;                             // :551
+                V3 L = light_direction(light, p) * (float)(-1);             // :556
+                L = normalize(L);
+                const V3 H = normalize(L + direction);
+                const float cosNL = RMAX(0.f, dot(N, L));
+                const float cosNH = RMAX(0.f, dot(N, H));
+                const V3 diffuse = (kd * intensity) * cosNL;                // :563
+                const V3 specular = ((ks * intensity) * powf(cosNH, gloss)) * cosNL;   // :564 (std::pow(float,float))
+                color = color + (diffuse + specular);                       // :566
+            } else {
+                color = color + kd * Il;                                    // :568-569
+            }
+        }
+        // reflection / refraction set-up, :577-610
+        float ein = 1, eout = ior;
+        if (!h.front) { ein = ior; eout = 1; }
+        const float eta = ein / eout;
+        const float cosI = dot(N, direction);
+        const V3 Y = cosI > 0.f ? N : -N;
+        const V3 Z = cross(direction, Y);
+        const V3 X = normalize(cross(Y, Z));
+        // sqrtf(1 - cosI*cosI) is NaN in the reference when |cosI| exceeds 1 by rounding (:592);
+        // clamped at 0 here (documented deviation)
+        const float sinI = sqrtf(fmaxf(0.0f, 1 - cosI * cosI));
+        const float sinO = RMAX(0.f, RMIN(1.f, sinI * eta));
+        const float cosO = sqrtf(1.f - sinO * sinO);
+        tDir = (-X) * sinO - Y * cosO;                                      // :596
+        rDir = (N * 2.f) * cosI - direction;                                // :597
+        const float C0 = (eta - 1.f) * (eta - 1.f) / ((eta + 1.f) * (eta + 1.f));
+        const float rC = C0 + (1.f - C0) * powf(1.f - fabsf(cosI), 5.f);    // :601
+        const float tC = 1.f - rC;
+        const bool totReflection = (eta * sinI) > 1.001f;                   // materials.h:20
+        tK = totReflection ? mk(0.f, 0.f, 0.f) : refraction * tC;
+        rK = totReflection ? (reflection + refraction) : (reflection + refraction * rC);
+        const float th = 0.001f;                                            // materials.h:21-22
+        want_refl = in.bounce > 0 && (rK.x > th || rK.y > th || rK.z > th); // :613
+        want_refr = in.bounce > 0 && (tK.x > th || tK.y > th || tK.z > th); // :625
+        // :642-693: at bounceCount == BOUNCE the hemisphere loop's result is assigned to a shadowing
+        // variable and contributes exactly 0 -- not traced.  :695-705: every other hit adds
+        // kd * irradiance * max(0, N.(-dir)); queued for k_gather with weight thr*kd.
+        const V3 w = thr * kd;
+        want_photon = (in.bounce != P.bounce) && S.pm.n_leaves != 0 && (w.x != 0.f || w.y != 0.f || w.z != 0.f);
+        add_sample(C, in.slot, thr * color, in.primary);
+        // a child whose accumulated weight is exactly zero cannot change the pixel
+        const V3 wr = thr * rK, wt = thr * tK;
+        want_refl = want_refl && (wr.x != 0.f || wr.y != 0.f || wr.z != 0.f);
+        want_refr = want_refr && (wt.x != 0.f || wt.y != 0.f || wt.z != 0.f);
+    }
+    // pushes are wave-collective: every lane of the wave reaches them
+    push_ray(C, want_refl, h.p, normalize(rDir), thr * rK, absorption, in.slot, in.bounce - 1, KIND_REFLECT);
+    push_ray(C, want_refr, h.p, normalize(tDir), thr * tK, absorption, in.slot, in.bounce - 1, KIND_REFRACT);
+    push_photon_query(C, want_photon, h.p, N, thr * kd, in.slot);
+}
+
+__device__ __forceinline__ void flush_counters(unsigned long long *stats, const Counters &c, uint32_t nprim, uint32_t nrefl, uint32_t nrefr)
+{
+    uint32_t v[7] = {c.inst, c.nodes, c.tris, c.shadow, nprim, nrefl, nrefr};
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        uint32_t x = v[i];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        v[i] = x;
+    }
+    if (__lane_id() == 0) {
+        if (v[0]) atomicAdd(&stats[ST_INSTANCE_VISITS], (unsigned long long)v[0]);
+        if (v[1]) atomicAdd(&stats[ST_BVH_NODES], (unsigned long long)v[1]);
+        if (v[2]) atomicAdd(&stats[ST_TRIS], (unsigned long long)v[2]);
+        if (v[3]) atomicAdd(&stats[ST_RAYS_SHADOW], (unsigned long long)v[3]);
+        if (v[4]) atomicAdd(&stats[ST_RAYS_PRIMARY], (unsigned long long)v[4]);
+        if (v[5]) atomicAdd(&stats[ST_RAYS_REFLECT], (unsigned long long)v[5]);
+        if (v[6]) atomicAdd(&stats[ST_RAYS_REFRACT], (unsigned long long)v[6]);
+    }
+}
+
+// Halton, FIN/include/scene.h:131-140
+__device__ __forceinline__ float halton(int index, int base)
+{
+    float r = 0;
+    float f = 1.0f / (float)base;
+    for (int i = index; i > 0; i /= base) { r += f * (i % base); f /= (float)base; }
+    return r;
+}
+
+// chunk-local pixel q -> image pixel, walking this call's tiles (tile-major, row-major inside)
+__device__ __forceinline__ bool pixel_of(const DevTiles &T, const DevCamera &cam, uint32_t q, int &x, int &y)
+{
+    const uint32_t per = (uint32_t)(T.tile_w * T.tile_h);
+    const uint32_t k = q / per, w = q % per;
+    if (k >= (uint32_t)T.n_tiles) return false;
+    const int t = T.first + (int)k * T.stride;
+    const int tx = t % T.tiles_x, ty = t / T.tiles_x;
+    x = tx * T.tile_w + (int)(w % (uint32_t)T.tile_w);
+    y = ty * T.tile_h + (int)(w / (uint32_t)T.tile_w);
+    return x < cam.width && y < cam.height;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: one thread per (pixel, sample).  generateSample + ray build, FIN/main.cpp:147-162, 281-292
+// (dof == 0).  Lanes of a wave hold consecutive samples of the same pixel(s): coherent traversal.
+//   mode 0: pixels q0..q0+npix of the chunk, samples j0..j0+ns
+//   mode 1: pixels from W.pixel_list[0..counts[CNT_PIXLIST]), samples j0..j0+ns   (second batch)
+//   mode 2: rays[] supplied by the caller, one sample each (rt_shade_rays)
+// ------------------------------------------------------------------------------------------------
+struct PrimaryArgs {
+    DevCamera cam; DevTiles tiles;
+    uint32_t q0, npix;           // chunk range (mode 0)
+    int j0, ns, max_sample, mode;
+    const float *rays;           // mode 2
+};
+
+__global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
+{
+    __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
+    uint32_t *stack = s_stack + threadIdx.x;
+    Counters cnt = {0, 0, 0, 0};
+    uint32_t nprim = 0;
+    const uint32_t npix = (A.mode == 1) ? C.W.counts[CNT_PIXLIST] : A.npix;
+    const unsigned long long total = (unsigned long long)npix * (unsigned long long)A.ns;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    // every lane iterates the same number of times (wave-collective pushes inside shade_path)
+    for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < total; base += stride) {
+        const unsigned long long gid = base + threadIdx.x;
+        bool active = gid < total;
+        PathIn in;
+        in.thr = mk(1.f, 1.f, 1.f); in.absorb = mk(0, 0, 0); in.bounce = C.P.bounce; in.kind = KIND_REFLECT; in.primary = true;
+        in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.slot = 0;
+        if (active) {
+            const uint32_t pi = (uint32_t)(gid / (unsigned long long)A.ns);
+            const int j = A.j0 + (int)(gid % (unsigned long long)A.ns);
+            const uint32_t ql = (A.mode == 1) ? C.W.pixel_list[pi] : pi;      // chunk-local pixel
+            in.slot = ql * (uint32_t)A.max_sample + (uint32_t)j;
+            if (A.mode == 2) {
+                const float *r = A.rays + 6 * (size_t)ql;
+                in.o = ld3(r); in.d = ld3(r + 3);
+            } else {
+                int x, y;
+                if (!pixel_of(A.tiles, A.cam, A.q0 + ql, x, y)) active = false;
+                else {
+                    const V3 tmp = mk(x * A.cam.u, y * A.cam.v, 0) + ld3(A.cam.b);     // :235-236
+                    float sx = halton(j, 2) * A.cam.u;                                 // :153
+                    float sy = A.cam.v * halton(j, 3);                                 // :154
+                    sx += tmp.x; sy += tmp.y;
+                    const V3 sample = mk(sx, sy, tmp.z);
+                    in.o = ld3(A.cam.pos);                                             // camera.pos + 0
+                    in.d = normalize(mmul(A.cam.m, sample));                           // :289-292
+                }
+            }
+        }
+        if (active) nprim++;
+        shade_path(C, in, active, stack, cnt);
+    }
+    flush_counters(C.W.stats, cnt, nprim, 0, 0);
+}
+
+// K2-K4 for one level of the ray tree: reads queue `qin` (count in counts[level]).
+__global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin, int level)
+{
+    __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
+    uint32_t *stack = s_stack + threadIdx.x;
+    Counters cnt = {0, 0, 0, 0};
+    uint32_t nrefl = 0, nrefr = 0;
+    uint32_t total = C.W.counts[level];
+    if (total > qin.cap) total = qin.cap;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += stride) {
+        const uint32_t gid = base + threadIdx.x;
+        const bool active = gid < total;
+        PathIn in;
+        in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
+        in.slot = 0; in.bounce = 0; in.kind = 0;
+        if (active) {
+            const float4 a = qin.a[gid], b = qin.b[gid], c = qin.c[gid];
+            const uint4 dd = qin.d[gid];
+            in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
+            in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
+            in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu;
+            if (in.kind == KIND_REFRACT) nrefr++; else nrefl++;
+        }
+        shade_path(C, in, active, stack, cnt);
+    }
+    flush_counters(C.W.stats, cnt, 0, nrefl, nrefr);
+}
+
+// K2 alone: n closest-hit queries (rt_trace_rays)
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, int model, const float *rays, long long n,
+                                                    uint8_t *hit, float *z, float *p, float *N, int32_t *node, uint8_t *front)
+{
+    __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
+    uint32_t *stack = s_stack + threadIdx.x;
+    Counters cnt = {0, 0, 0, 0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        Hit h;
+        h.z = BIGFLOAT; h.p = mk(0, 0, 0); h.N = mk(0, 0, 0); h.node = -1; h.front = 1;
+        const bool ok = trace<false>(S, model, ld3(rays + 6 * i), ld3(rays + 6 * i + 3), BIGFLOAT, h, stack, cnt);
+        hit[i] = ok ? 1 : 0;
+        z[i] = ok ? h.z : BIGFLOAT;
+        p[3 * i] = h.p.x; p[3 * i + 1] = h.p.y; p[3 * i + 2] = h.p.z;
+        N[3 * i] = h.N.x; N[3 * i + 1] = h.N.y; N[3 * i + 2] = h.N.z;
+        node[i] = ok ? h.node : -1;
+        front[i] = (uint8_t)h.front;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: PhotonMap::EstimateIrradiance<k>(irr, dir, radius, pos, &N, 1, CONSTANT)
+// (FIN/include/cyPhotonMap.h:288-336, LocatePhotons :365-440).
+//
+// The reference walks its heap-ordered kd-tree recursively per query and keeps the k nearest
+// accepted photons (inside the radius, photonDir.N < 0) in a max-heap; the estimate only needs
+//   sum of power, sum of dir*maxPower over that set, and r_k^2 (= radius^2 while at most k photons
+//   qualify, else the k-th smallest squared distance).
+// Here each wavefront serves 64 queries.  Phase A, one query per lane: a stackless walk of the
+// complete binary tree of leaf boxes lists the leaves within the radius (ids in LDS).  Phase B,
+// the whole wave per query: every listed leaf is one coalesced 64-photon read (lane = photon);
+// pass 1 counts candidates into a 256-bin histogram of the fixed-point distance key (LDS) while
+// summing all of them; if more than k qualify the bin holding the k-th is found with a wave scan,
+// pass 2 sums the bins below it and collects that one bin (<= 64 entries, else one more 8-bit
+// level) for an exact rank selection.  Sums are per-lane partials combined by a fixed butterfly,
+// so the result is deterministic.
+// ------------------------------------------------------------------------------------------------
+struct GatherArgs {
+    DevPhotonMap pm;
+    const float4 *qa, *qb, *qc;      // query queue
+    const uint32_t *count_ptr;       // number of queries (device)
+    uint32_t count_cap;
+    int k; float radius;
+    float *sample_rgb;               // mode 0: atomicAdd w * irr * max(0, N.(-dir)) into the slot
+    float *out_irr, *out_dir;        // mode 1: write irr[3], dir[3] per query (rt_estimate_irradiance)
+    int mode;
+    unsigned long long *stats;
+};
+
+__device__ __forceinline__ float wave_sum(float x)
+{
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_sum_u(uint32_t x)
+{
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+__device__ __forceinline__ float box_dist2(const float *b, float px, float py, float pz)
+{
+    const float dx = fmaxf(fmaxf(b[0] - px, px - b[3]), 0.0f);
+    const float dy = fmaxf(fmaxf(b[1] - py, py - b[4]), 0.0f);
+    const float dz = fmaxf(fmaxf(b[2] - pz, pz - b[5]), 0.0f);
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// LDS hand-off between lanes of ONE wavefront: LDS operations of a wave complete in issue order, so
+// only the compiler has to be kept from reordering, plus a wait for outstanding LDS returns.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+struct GatherLds {
+    uint16_t leaves[64][RT_LEAFLIST_CAP];   // per query (lane) leaf ids
+    uint32_t hist[256];
+    float    sel_d[64];
+    uint32_t sel_i[64];
+    uint32_t sel_n;
+};
+
+__global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
+{
+    __shared__ GatherLds lds_all[RT_GATHER_WAVES];
+    GatherLds &L = lds_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    uint32_t nq = *G.count_ptr;
+    if (nq > G.count_cap) nq = G.count_cap;
+    const uint32_t n_leaves = G.pm.n_leaves;
+    const float r2 = G.radius * G.radius;
+    const float kscale = 16777216.0f / r2;                 // 24-bit fixed-point distance key
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long visited = 0;
+
+    for (uint32_t qbase = wave_global * 64u; qbase < nq; qbase += n_waves * 64u) {
+        // ---------------- phase A: one query per lane, list the leaves in range ----------------
+        const uint32_t qi = qbase + lane;
+        const bool have = qi < nq;
+        float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
+        if (have) { a = G.qa[qi]; b = G.qb[qi]; c = G.qc[qi]; }
+        uint32_t nl = 0;
+        if (have && n_leaves) {
+            uint32_t node = 1;
+            while (node) {
+                bool descend = false;
+                if (box_dist2(G.pm.tbox + 6 * (size_t)node, a.x, a.y, a.z) < r2) {
+                    if (node >= n_leaves) {
+                        if (nl < RT_LEAFLIST_CAP) L.leaves[lane][nl] = (uint16_t)(node - n_leaves);
+                        nl++;
+                    } else { node = 2 * node; descend = true; }
+                }
+                if (!descend) {
+                    while (node & 1u) node >>= 1;          // climb while we are a right child
+                    if (node) node += 1;                   // then step to the right sibling
+                }
+            }
+        }
+        wave_sync();
+        // ---------------- phase B: the wave takes the queries one by one ------------------------
+        const int nhere = (int)min(64u, nq - qbase);
+        for (int q = 0; q < nhere; q++) {
+            const float px = __shfl(a.x, q), py = __shfl(a.y, q), pz = __shfl(a.z, q);
+            const float nx = __shfl(a.w, q), ny = __shfl(b.x, q), nz = __shfl(b.y, q);
+            const uint32_t qnl = __shfl(nl, q);
+            const bool slow = qnl > RT_LEAFLIST_CAP;       // list overflowed: test every leaf box
+            const uint32_t n_iter = slow ? n_leaves : qnl;
+
+            float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // sums of ALL candidates
+            uint32_t my_cnt = 0;
+            for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
+            wave_sync();
+            // pass 1
+            for (uint32_t it = 0; it < n_iter; it++) {
+                uint32_t leaf;
+                if (slow) { leaf = it; if (!(box_dist2(G.pm.tbox + 6 * (size_t)(n_leaves + leaf), px, py, pz) < r2)) continue; }
+                else leaf = L.leaves[q][it];
+                const size_t s = (size_t)leaf * RT_LEAF_PHOTONS + lane;
+                const float4 pa = G.pm.pa[s];
+                const float4 pb = G.pm.pb[s];
+                const float dfx = pa.x - px, dfy = pa.y - py, dfz = pa.z - pz;          // dif = p.position - np.pos
+                const float d2 = dfx * dfx + dfy * dfy + dfz * dfz;                     // LengthSquared
+                const bool ok = (d2 < r2) && !((pa.w * nx + pb.x * ny + pb.y * nz) >= 0);   // :386-392
+                if (ok) {
+                    const float2 pc = G.pm.pc[s];
+                    s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
+                    s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
+                    my_cnt++;
+                    uint32_t key = (uint32_t)(d2 * kscale);
+                    key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
+                    atomicAdd(&L.hist[key >> 16], 1u);
+                }
+                visited += 1;
+            }
+            const uint32_t M = wave_sum_u(my_cnt);
+            float area_d2 = r2;                            // dist2[0]
+            if (M > (uint32_t)G.k) {
+                // ---- locate the k-th smallest: refine 8 bits of the key per level --------------
+                uint32_t need = (uint32_t)G.k;             // rank (1-based) inside the current range
+                uint32_t prefix = 0;                       // key bits fixed so far
+                int shift = 16;                            // the level's digit = (key >> shift) & 255
+                uint32_t in_bin = 0;
+                for (;;) {
+                    wave_sync();
+                    // bins 4*lane .. 4*lane+3
+                    const uint32_t h0 = L.hist[4 * lane], h1 = L.hist[4 * lane + 1], h2 = L.hist[4 * lane + 2], h3 = L.hist[4 * lane + 3];
+                    const uint32_t mine = h0 + h1 + h2 + h3;
+                    uint32_t incl = mine;
+                    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+                    const uint32_t excl = incl - mine;
+                    const unsigned long long m = __ballot(incl >= need);
+                    const int owner = __ffsll((long long)m) - 1;          // first lane whose range reaches `need`
+                    uint32_t digit = 0, before = 0, cntb = 0;
+                    if (lane == owner) {
+                        uint32_t cum = excl;
+                        if (cum + h0 >= need) { digit = 4 * lane; before = cum; cntb = h0; }
+                        else if (cum + h0 + h1 >= need) { digit = 4 * lane + 1; before = cum + h0; cntb = h1; }
+                        else if (cum + h0 + h1 + h2 >= need) { digit = 4 * lane + 2; before = cum + h0 + h1; cntb = h2; }
+                        else { digit = 4 * lane + 3; before = cum + h0 + h1 + h2; cntb = h3; }
+                    }
+                    digit = __shfl(digit, owner); before = __shfl(before, owner); cntb = __shfl(cntb, owner);
+                    need -= before;
+                    prefix |= digit << shift;
+                    in_bin = cntb;
+                    if (in_bin <= 64u || shift == 0) break;
+                    // one more level: histogram of the next 8 bits over the photons inside this bin
+                    shift -= 8;
+                    wave_sync();
+                    for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
+                    wave_sync();
+                    const uint32_t hi_mask = ~((1u << (shift + 8)) - 1u) & 0xFFFFFFu;
+                    for (uint32_t it = 0; it < n_iter; it++) {
+                        uint32_t leaf;
+                        if (slow) { leaf = it; if (!(box_dist2(G.pm.tbox + 6 * (size_t)(n_leaves + leaf), px, py, pz) < r2)) continue; }
+                        else leaf = L.leaves[q][it];
+                        const size_t s = (size_t)leaf * RT_LEAF_PHOTONS + lane;
+                        const float4 pa = G.pm.pa[s];
+                        const float4 pb = G.pm.pb[s];
+                        const float dfx = pa.x - px, dfy = pa.y - py, dfz = pa.z - pz;
+                        const float d2 = dfx * dfx + dfy * dfy + dfz * dfz;
+                        const bool ok = (d2 < r2) && !((pa.w * nx + pb.x * ny + pb.y * nz) >= 0);
+                        if (ok) {
+                            uint32_t key = (uint32_t)(d2 * kscale);
+                            key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
+                            if ((key & hi_mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
+                        }
+                        visited += 1;
+                    }
+                }
+                // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
+                const uint32_t bin_mask = ~((1u << shift) - 1u) & 0xFFFFFFu;
+                s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
+                if (lane == 0) L.sel_n = 0;
+                wave_sync();
+                uint32_t tie_taken = 0;                    // only used when in_bin > 64 (identical keys)
+                float tmax = 0.0f;
+                for (uint32_t it = 0; it < n_iter; it++) {
+                    uint32_t leaf;
+                    if (slow) { leaf = it; if (!(box_dist2(G.pm.tbox + 6 * (size_t)(n_leaves + leaf), px, py, pz) < r2)) continue; }
+                    else leaf = L.leaves[q][it];
+                    const size_t s = (size_t)leaf * RT_LEAF_PHOTONS + lane;
+                    const float4 pa = G.pm.pa[s];
+                    const float4 pb = G.pm.pb[s];
+                    const float dfx = pa.x - px, dfy = pa.y - py, dfz = pa.z - pz;
+                    const float d2 = dfx * dfx + dfy * dfy + dfz * dfz;
+                    const bool ok = (d2 < r2) && !((pa.w * nx + pb.x * ny + pb.y * nz) >= 0);
+                    uint32_t key = (uint32_t)(d2 * kscale);
+                    key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
+                    const uint32_t kb = key & bin_mask;
+                    bool take = ok && kb < prefix;
+                    const bool inb = ok && kb == prefix;
+                    if (in_bin <= 64u) {
+                        const unsigned long long mb = __ballot(inb);
+                        if (mb) {
+                            uint32_t base = 0;
+                            const int leader = __ffsll((long long)mb) - 1;
+                            if (lane == leader) { base = L.sel_n; L.sel_n = base + (uint32_t)__popcll(mb); }
+                            base = __shfl(base, leader);
+                            if (inb) {
+                                const uint32_t at = base + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                                if (at < 64u) { L.sel_d[at] = d2; L.sel_i[at] = (uint32_t)s; }
+                            }
+                        }
+                    } else {
+                        // more than 64 photons share all 24 key bits: take the first `need` in scan order
+                        const unsigned long long mb = __ballot(inb);
+                        const uint32_t rank = tie_taken + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                        if (inb && rank < need) { take = true; tmax = fmaxf(tmax, d2); }
+                        tie_taken += (uint32_t)__popcll(mb);
+                    }
+                    if (take) {
+                        const float2 pc = G.pm.pc[s];
+                        s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
+                        s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
+                    }
+                    visited += 1;
+                }
+                wave_sync();
+                if (in_bin <= 64u) {
+                    // exact selection: rank by (d2, list position); take ranks < need
+                    const uint32_t n_sel = min(L.sel_n, 64u);
+                    const bool mine = (uint32_t)lane < n_sel;
+                    const float md = mine ? L.sel_d[lane] : 3.0e38f;
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < n_sel; j++) {
+                        const float od = L.sel_d[j];
+                        rank += (od < md || (od == md && j < (uint32_t)lane)) ? 1u : 0u;
+                    }
+                    if (mine && rank < need) {
+                        const size_t s = L.sel_i[lane];
+                        const float4 pa = G.pm.pa[s];
+                        const float4 pb = G.pm.pb[s];
+                        const float2 pc = G.pm.pc[s];
+                        s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
+                        s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
+                        tmax = md;
+                    }
+                }
+                for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+                area_d2 = tmax;                            // np.dist2[0] = largest kept distance
+            }
+            float irr_r = wave_sum(s_pr), irr_g = wave_sum(s_pg), irr_b = wave_sum(s_pb);
+            float dx = wave_sum(s_dx), dy = wave_sum(s_dy), dz = wave_sum(s_dz);
+            if (M > 0) {
+                const float area = (float)M_PI * area_d2;                  // :326
+                if (area > 0) { const float inv = 1.0f / area; irr_r *= inv; irr_g *= inv; irr_b *= inv; }
+                const float l = sqrtf(dx * dx + dy * dy + dz * dz);        // direction.Normalize() :334
+                dx /= l; dy /= l; dz /= l;
+            }
+            if (lane == 0) {
+                const uint32_t qq = qbase + (uint32_t)q;
+                if (G.mode == 1) {
+                    G.out_irr[3 * (size_t)qq] = irr_r; G.out_irr[3 * (size_t)qq + 1] = irr_g; G.out_irr[3 * (size_t)qq + 2] = irr_b;
+                    G.out_dir[3 * (size_t)qq] = dx; G.out_dir[3 * (size_t)qq + 1] = dy; G.out_dir[3 * (size_t)qq + 2] = dz;
+                }
+            }
+            if (G.mode == 0) {
+                // idr_Color += kd * photonrad * max(0, N.(-dir)) (FIN/main.cpp:701-704), times the ray weight
+                const float wr = __shfl(b.z, q), wg = __shfl(b.w, q), wb = __shfl(c.x, q);
+                const uint32_t slot = __float_as_uint(__shfl(c.y, q));
+                float theta = nx * (-dx) + ny * (-dy) + nz * (-dz);
+                theta = theta > 0.0f ? theta : 0.0f;
+                if (lane < 3) {
+                    const float w = lane == 0 ? wr : (lane == 1 ? wg : wb);
+                    const float ir = lane == 0 ? irr_r : (lane == 1 ? irr_g : irr_b);
+                    atomicAdd(G.sample_rgb + 3 * (size_t)slot + lane, (w * ir) * theta);
+                }
+            }
+            wave_sync();
+        }
+    }
+    if (lane == 0 && G.stats && visited) atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * 64ull);
+    if (G.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&G.stats[ST_PHOTON_QUERIES], (unsigned long long)nq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: per pixel, the tail of RenderPixel (FIN/main.cpp:273-338): hits-only average
+// (averageColor :191-199), VariantOverThreshold (:164-189) gate for the second batch, gamma
+// (powf(c, 1.0/gamma) :318-320), Color24 pack (cyColor.h:245-246), z of the last hit sample,
+// sample-count byte (:312-315), background for all-miss pixels (:326-337).
+//   phase 0: after the first batch (samples 0..min-1): either finalise or list the pixel
+//   phase 1: after the second batch: finalise listed pixels with all samples
+// ------------------------------------------------------------------------------------------------
+struct ResolveArgs {
+    DevCamera cam; DevTiles tiles;
+    uint32_t q0, npix;
+    int min_sample, max_sample;
+    float threshold; float inv_gamma;
+    int phase;
+    float bg[3];
+    uint8_t *rgb8; float *z; uint8_t *count;
+    int direct_mode;            // rt_shade_rays: no image, leave samples as they are
+};
+
+__device__ __forceinline__ uint8_t float_to_byte(float r)
+{
+    const float s = r * 255;
+    if (!(s == s)) return 0;
+    if (s <= -2147483648.0f) return 0;
+    if (s >= 2147483647.0f) return 255;
+    const int v = (int)s;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
+{
+    const uint32_t npix = A.phase == 1 ? W.counts[CNT_PIXLIST] : A.npix;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const uint32_t ql = A.phase == 1 ? W.pixel_list[i] : i;
+        int x, y;
+        if (!pixel_of(A.tiles, A.cam, A.q0 + ql, x, y)) continue;
+        const size_t index = (size_t)y * A.cam.width + x;
+        const float *rgb = W.sample_rgb + 3 * (size_t)ql * A.max_sample;
+        const uint8_t *hitf = W.sample_hit + (size_t)ql * A.max_sample;
+        const float *zs = W.sample_z + (size_t)ql * A.max_sample;
+        const int ns = A.phase == 1 ? A.max_sample : A.min_sample;
+        int n = 0;
+        float hitz = 0;
+        for (int j = 0; j < ns; j++) if (hitf[j]) { n++; hitz = zs[j]; }
+        if (A.phase == 0 && n > 0 && A.min_sample != A.max_sample) {
+            // VariantOverThreshold over the hit colours of the first batch
+            const float ninverse = (float)(1.0 / n);
+            float sum[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
+            for (int j = 0; j < ns; j++) if (hitf[j])
+                for (int c = 0; c < 3; c++) {
+                    const float t = rgb[3 * j + c];
+                    sum[c] += t;
+                    sq[c] = (float)((double)sq[c] + (double)t * (double)t);       // pow(float,int) -> double
+                }
+            bool over = false;
+            for (int c = 0; c < 3; c++) {
+                const float avg = ninverse * sum[c];
+                const float var = (float)((double)(sq[c] * ninverse) + (double)avg * (double)avg - (double)(2 * avg * ninverse * sum[c]));
+                if (var > A.threshold) over = true;
+            }
+            if (over) { W.pixel_list[atomicAdd(&W.counts[CNT_PIXLIST], 1u)] = ql; continue; }
+        }
+        float g[3];
+        if (n > 0) {
+            const float inv = 1 / (float)n;
+            float c0 = 0, c1 = 0, c2 = 0;
+            for (int j = 0; j < ns; j++) if (hitf[j]) { c0 += rgb[3 * j] * inv; c1 += rgb[3 * j + 1] * inv; c2 += rgb[3 * j + 2] * inv; }
+            g[0] = powf(c0, A.inv_gamma); g[1] = powf(c1, A.inv_gamma); g[2] = powf(c2, A.inv_gamma);
+            A.count[index] = (n <= A.min_sample) ? 0 : 255;
+            A.z[index] = hitz;
+        } else {
+            g[0] = powf(A.bg[0], A.inv_gamma); g[1] = powf(A.bg[1], A.inv_gamma); g[2] = powf(A.bg[2], A.inv_gamma);
+            A.count[index] = 0;
+            A.z[index] = BIGFLOAT;
+        }
+        A.rgb8[3 * index] = float_to_byte(g[0]); A.rgb8[3 * index + 1] = float_to_byte(g[1]); A.rgb8[3 * index + 2] = float_to_byte(g[2]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launch wrappers (C++ linkage, used by rt_api.cpp)
+// ------------------------------------------------------------------------------------------------
+static inline int grid_for(unsigned long long work, int block, int max_blocks)
+{
+    unsigned long long b = (work + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > (unsigned long long)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
+                        const DevRayQueue &qout, uint32_t *qout_count, const DevCamera &cam,
+                        const DevTiles &tiles, uint32_t q0, uint32_t npix, int j0, int ns,
+                        int max_sample, int mode, const float *rays, int max_blocks)
+{
+    ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
+    PrimaryArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.j0 = j0; A.ns = ns;
+    A.max_sample = max_sample; A.mode = mode; A.rays = rays;
+    const int grid = grid_for((unsigned long long)npix * ns, RT_BLOCK, max_blocks);
+    hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
+}
+
+void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
+                       const DevRayQueue &qin, const DevRayQueue &qout, uint32_t *qout_count,
+                       int level, int max_blocks)
+{
+    ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
+    hipLaunchKernelGGL(k_bounce, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
+}
+
+void rtk_launch_trace(hipStream_t st, const DevScene &S, int model, const float *rays, long long n,
+                      uint8_t *hit, float *z, float *p, float *N, int32_t *node, uint8_t *front)
+{
+    const int grid = grid_for((unsigned long long)n, RT_BLOCK, 4096);
+    hipLaunchKernelGGL(k_trace, dim3(grid), dim3(RT_BLOCK), 0, st, S, model, rays, n, hit, z, p, N, node, front);
+}
+
+void rtk_launch_gather(hipStream_t st, const DevPhotonMap &pm, const float4 *qa, const float4 *qb,
+                       const float4 *qc, const uint32_t *count_ptr, uint32_t count_cap, int k,
+                       float radius, float *sample_rgb, float *out_irr, float *out_dir, int mode,
+                       unsigned long long *stats, int blocks)
+{
+    GatherArgs G; G.pm = pm; G.qa = qa; G.qb = qb; G.qc = qc; G.count_ptr = count_ptr; G.count_cap = count_cap;
+    G.k = k; G.radius = radius; G.sample_rgb = sample_rgb; G.out_irr = out_irr; G.out_dir = out_dir; G.mode = mode; G.stats = stats;
+    hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(64 * RT_GATHER_WAVES), 0, st, G);
+}
+
+void rtk_launch_resolve(hipStream_t st, const DevWork &W, const DevCamera &cam, const DevTiles &tiles,
+                        uint32_t q0, uint32_t npix, int min_sample, int max_sample, float threshold,
+                        float inv_gamma, int phase, const float bg[3], uint8_t *rgb8, float *z,
+                        uint8_t *count, int max_blocks)
+{
+    ResolveArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.min_sample = min_sample;
+    A.max_sample = max_sample; A.threshold = threshold; A.inv_gamma = inv_gamma; A.phase = phase;
+    A.bg[0] = bg[0]; A.bg[1] = bg[1]; A.bg[2] = bg[2]; A.rgb8 = rgb8; A.z = z; A.count = count; A.direct_mode = 0;
+    const int grid = grid_for(npix, 256, max_blocks);
+    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, st, W, A);
+}

@@ -1,0 +1,128 @@
+"""CPU tests of the host layer and the C-ABI surface (no compute calls: there is no GPU here).
+Golden data: tests/golden/*.npz, produced by the reference's own code (oracle/gen_golden.py)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracing_folder_amd import capi, photons
+from tests import scenes
+
+ROOT = scenes.ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rt_mi355x.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"rt_status"}
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    lib = capi.lib()
+    for name in declared:
+        assert getattr(lib, name)
+    assert lib.rt_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(capi.Camera) == 56 and C.sizeof(capi.Params) == 64
+    assert C.sizeof(capi.TileRange) == 16 and C.sizeof(capi.Stats) == 18 * 8
+    p = capi.default_params()
+    assert (p.min_sample, p.max_sample, p.bounce, p.knn_k, p.shadow_samples) == (4, 8, 4, 400, 4)
+    assert p.threshold == np.float32(1e-3) and p.gamma == 2.2 and p.knn_radius == 1.0
+
+
+def test_xml_loader_reproduces_reference_transforms(gold):
+    s, cam = scenes.load_cornell()
+    e = s.export()
+    g = gold("node.npz")
+    names = ["box_group", "wall_bottom", "wall_top", "wall_back", "wall_left", "wall_right", "teapot", "sphere1"]
+    assert list(e["nodes"]["parent"]) == [-1, 0, 1, 1, 1, 1, 1, 0, 0, 0]
+    assert list(e["nodes"]["obj_type"]) == [0, 0, 2, 2, 2, 2, 2, 3, 1, 1]
+    for i, nm in enumerate(names):
+        n = e["nodes"][i + 1]
+        for f in ("tm", "itm", "pos"):
+            assert n[f].tobytes() == g[f"{nm}_{f}"].tobytes(), (nm, f)
+    root = e["nodes"][0]
+    assert (root["tm"] == np.eye(3, dtype=np.float32).ravel()).all() and (root["pos"] == 0).all()
+    # camera as LoadScene leaves it (dir, up orthonormal)
+    assert list(cam.pos) == [0, -60, 12] and list(cam.dir) == [0, 1, 0] and list(cam.up) == [0, 0, 1]
+    assert (cam.fov, cam.focaldist, cam.dof, cam.width, cam.height) == (30, 1, 0, 800, 600)
+    m = e["materials"]
+    assert np.allclose(m["diffuse"][3], [1.0, 0.3, 0.3]) and np.allclose(m["specular"][3], 0.7)
+    assert (m["reflection"][4] == 1).all() and (m["refraction"][5] == 1).all() and m["ior"][5] == np.float32(1.52)
+    assert (m["specular"][4] == 1).all()              # <specular vakye="1.0"/> -> default (1,1,1)
+    l = e["lights"]
+    assert l["type"][0] == capi.LIGHT_POINT and l["intensity"][0][0] == np.float32(100.5) and l["size"][0] == 0
+
+
+def test_obj_loader_and_bvh_match_reference(gold):
+    s, _ = scenes.load_cornell()
+    m = s.export()["meshes"][0]
+    g = gold("mesh_teapot_fin.npz")
+    for k in ("v", "f", "vn", "fn", "elements"):
+        assert (m[k] == g[k]).all(), k
+    assert m["nodes"][1:].tobytes() == g["nodes"][1:].tobytes()
+    nodes, el = capi.bvh_build(g["v"], g["f"], 4)
+    assert nodes[1:].tobytes() == g["nodes"][1:].tobytes() and (el == g["elements"]).all()
+
+
+def test_obj_loader_polygons_negative_indices_and_missing_normals(tmp_path):
+    obj = tmp_path / "quad.obj"
+    obj.write_text("# a quad and a pentagon, relative indices, no normals\n"
+                   "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv -0.5 0.5 0\n"
+                   "f 1 2 3 4\nf -5 -4 -3 -2 -1\n")
+    xml = tmp_path / "s.xml"
+    xml.write_text('<xml><scene><object type="obj" name="quad.obj" material="m"/>'
+                   '<material type="blinn" name="m"/></scene><camera/></xml>')
+    s = capi.Scene()
+    s.load_xml(str(xml))
+    m = s.export()["meshes"][0]
+    assert m["f"].tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2], [0, 2, 3], [0, 3, 4]]
+    assert np.allclose(m["vn"], [[0, 0, 1]] * 5)       # ComputeNormals
+    assert (m["fn"] == m["f"]).all()
+
+
+@pytest.mark.parametrize("tag", ["k8", "k50", "k400"])
+def test_photon_pack_and_balance_match_reference(gold, tag):
+    g = gold(f"photon_{tag}.npz")
+    ph = g["photons_in"]
+    packed = photons.pack_photons(ph[:, :3], ph[:, 3:6], ph[:, 6:9])
+    packed["power"] *= g["scale"]
+    assert packed.tobytes() == g["packed"].tobytes()
+    bal = capi.photon_balance(np.concatenate([np.zeros(1, capi.PHOTON), packed]))
+    assert bal[1:].tobytes() == g["balanced"][1:].tobytes()
+
+
+def test_xml_errors_are_reported(tmp_path):
+    s = capi.Scene()
+    with pytest.raises(capi.RtError) as e:
+        s.load_xml(str(tmp_path / "missing.xml"))
+    assert e.value.status == -5
+    bad = tmp_path / "bad.xml"
+    bad.write_text("<xml><scene></scene></xml>")
+    with pytest.raises(capi.RtError, match="camera"):
+        s.load_xml(str(bad))
+    with pytest.raises(capi.RtError):
+        s.set_nodes(np.zeros(2, capi.NODE))            # node 0 must have parent -1
+
+
+def test_render_fails_loudly_without_a_gpu():
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    s, cam = scenes.load_cornell(64, 48)
+    with pytest.raises(capi.RtError) as e:
+        s.render(cam, capi.default_params())
+    assert e.value.status == -3                        # RT_ERR_NO_DEVICE: no CPU fallback
+    with pytest.raises(capi.RtError):
+        s.trace_rays(np.zeros((1, 6), np.float32))
+
+
+def test_synthetic_photon_map_is_well_formed():
+    bal = photons.synth_cornell_photon_map(5000, seed=3)
+    assert len(bal) == 5001
+    p = bal["position"][1:]
+    assert p[:, 0].min() >= -15 and p[:, 0].max() <= 15 and p[:, 2].min() >= 0 and p[:, 2].max() <= 24
+    # heap order: the root splits the widest axis
+    axis = bal["plane_and_dirz"][1] & 3
+    assert axis in (0, 1, 2)
