@@ -917,7 +917,8 @@ extern "C" void rt_job_destroy(rt_job *j)
 extern "C" rt_status rt_trace_rays(rt_scene *s, int shade_model, int device, const float *rays, int64_t n, uint8_t *hit, float *z,
                                    float *p, float *N, int32_t *node, uint8_t *front)
 {
-    if (!s || !rays || n < 0 || !hit || !z || !p || !N || !node || !front) return fail(RT_ERR_ARG, "rt_trace_rays: NULL argument");
+    if (!s || n < 0) return fail(RT_ERR_ARG, "rt_trace_rays: NULL scene or negative count");
+    if (n > 0 && (!rays || !hit || !z || !p || !N || !node || !front)) return fail(RT_ERR_ARG, "rt_trace_rays: NULL argument");
     if (shade_model != RT_SHADE_FIN && shade_model != RT_SHADE_P13) return fail(RT_ERR_ARG, "rt_trace_rays: unknown shade model");
     DeviceState *D = nullptr;
     rt_status st = prepare_device(s, device, &D);
@@ -938,7 +939,8 @@ extern "C" rt_status rt_trace_rays(rt_scene *s, int shade_model, int device, con
 extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, float radius, const float *pos, const float *normal,
                                             int64_t n, float *irr, float *dir)
 {
-    if (!s || !pos || !normal || n < 0 || !irr || !dir) return fail(RT_ERR_ARG, "rt_estimate_irradiance: NULL argument");
+    if (!s || n < 0) return fail(RT_ERR_ARG, "rt_estimate_irradiance: NULL scene or negative count");
+    if (n > 0 && (!pos || !normal || !irr || !dir)) return fail(RT_ERR_ARG, "rt_estimate_irradiance: NULL argument");
     if (k < 1 || k > 65536 || !(radius > 0)) return fail(RT_ERR_ARG, "rt_estimate_irradiance: bad k/radius");
     DeviceState *D = nullptr;
     rt_status st = prepare_device(s, device, &D);
@@ -970,7 +972,8 @@ extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, 
 
 extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, const float *rays, int64_t n, uint8_t *hit, float *rgb, float *z)
 {
-    if (!s || !p || !rays || n < 0 || !hit || !rgb || !z) return fail(RT_ERR_ARG, "rt_shade_rays: NULL argument");
+    if (!s || !p || n < 0) return fail(RT_ERR_ARG, "rt_shade_rays: NULL scene/params or negative count");
+    if (n > 0 && (!rays || !hit || !rgb || !z)) return fail(RT_ERR_ARG, "rt_shade_rays: NULL argument");
     rt_camera cam;
     memset(&cam, 0, sizeof cam);
     cam.width = 1; cam.height = 1; cam.fov = 40; cam.focaldist = 1; cam.dir[2] = -1; cam.up[1] = 1;
