@@ -1,0 +1,102 @@
+"""Multi-GPU sharding of a frame: interleaved tiles + one all-gather of the finished tiles.
+
+The reference parallelises over pixels with one shared atomic counter (FIN/main.cpp:65-85; FIN =
+/root/reference/RayTracingFinal/RayTracingFinal).  Here the image is cut into tile_w x tile_h
+tiles numbered row-major; rank r of R renders tiles r, r+R, r+2R, ... (interleaved, so that the
+expensive glass/mirror pixels spread over all ranks), every rank holds the whole scene and photon
+map, and the only exchange is ONE all_gather of each rank's finished tiles -- 8 bytes per pixel
+(RGB8 + float z + sample-count byte) -- over RCCL/xGMI (backend "nccl" on ROCm) or gloo on CPU.
+torch is plumbing here: device buffers, the stream handle and torch.distributed.
+"""
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+BYTES_PER_PIXEL = 8          # 3 (Color24) + 4 (float z) + 1 (sample count)
+
+
+def tile_grid(width, height, tile_w=32, tile_h=8):
+    tiles_x = (width + tile_w - 1) // tile_w
+    tiles_y = (height + tile_h - 1) // tile_h
+    return tiles_x, tiles_y, tiles_x * tiles_y
+
+
+def tiles_of_rank(rank, world, n_tiles):
+    return torch.arange(rank, n_tiles, world)
+
+
+def _padded_tiles(rgb, z, cnt, tile_w, tile_h):
+    """(H,W,3) u8, (H,W) f32, (H,W) u8  ->  (n_tiles, tile_h, tile_w, 8) u8 view-copy"""
+    h, w = z.shape
+    tx, ty, _ = tile_grid(w, h, tile_w, tile_h)
+    ph, pw = ty * tile_h, tx * tile_w
+    px = torch.zeros((ph, pw, BYTES_PER_PIXEL), dtype=torch.uint8, device=z.device)
+    px[:h, :w, 0:3] = rgb
+    px[:h, :w, 3:7] = z.contiguous().view(torch.uint8).reshape(h, w, 4)
+    px[:h, :w, 7] = cnt
+    return px.reshape(ty, tile_h, tx, tile_w, BYTES_PER_PIXEL).permute(0, 2, 1, 3, 4).reshape(tx * ty, tile_h, tile_w, BYTES_PER_PIXEL)
+
+
+def pack_own_tiles(rgb, z, cnt, rank, world, tile_w=32, tile_h=8):
+    """Compact buffer of this rank's tiles, padded to the per-rank maximum so that every rank
+    contributes the same number of bytes to the all-gather."""
+    tiles = _padded_tiles(rgb, z, cnt, tile_w, tile_h)
+    n = tiles.shape[0]
+    per_rank = (n + world - 1) // world
+    out = torch.zeros((per_rank, tile_h, tile_w, BYTES_PER_PIXEL), dtype=torch.uint8, device=z.device)
+    mine = tiles[rank::world]
+    out[: mine.shape[0]] = mine
+    return out.contiguous()
+
+
+def unpack_gathered(gathered, width, height, world, tile_w=32, tile_h=8):
+    """gathered: (world, per_rank, tile_h, tile_w, 8) u8 -> rgb (H,W,3) u8, z (H,W) f32, cnt (H,W) u8"""
+    tx, ty, n = tile_grid(width, height, tile_w, tile_h)
+    tiles = torch.zeros((n, tile_h, tile_w, BYTES_PER_PIXEL), dtype=torch.uint8, device=gathered.device)
+    for r in range(world):
+        k = len(range(r, n, world))
+        tiles[r::world] = gathered[r, :k]
+    px = tiles.reshape(ty, tx, tile_h, tile_w, BYTES_PER_PIXEL).permute(0, 2, 1, 3, 4).reshape(ty * tile_h, tx * tile_w, BYTES_PER_PIXEL)
+    px = px[:height, :width]
+    rgb = px[..., 0:3].contiguous()
+    z = px[..., 3:7].contiguous().view(torch.float32).reshape(height, width)
+    cnt = px[..., 7].contiguous()
+    return rgb, z, cnt
+
+
+def gather_frame(rgb, z, cnt, rank, world, tile_w=32, tile_h=8):
+    """All-gather the finished tiles; every rank returns the complete frame."""
+    h, w = z.shape
+    if world == 1:
+        return rgb, z, cnt
+    mine = pack_own_tiles(rgb, z, cnt, rank, world, tile_w, tile_h)
+    gathered = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(gathered, mine)          # rank r's tiles land in rows [r*per_rank, (r+1)*per_rank)
+    return unpack_gathered(gathered.reshape((world,) + tuple(mine.shape)), w, h, world, tile_w, tile_h)
+
+
+class ShardedRenderer:
+    """One process per GPU: renders this rank's tiles into device tensors and gathers the frame."""
+
+    def __init__(self, scene, cam, params, rank, world, device_index, tile_w=32, tile_h=8):
+        self.scene, self.cam, self.params = scene, cam, params
+        self.rank, self.world, self.device_index = rank, world, device_index
+        self.tile_w, self.tile_h = tile_w, tile_h
+        dev = torch.device("cuda", device_index)
+        h, w = cam.height, cam.width
+        self.rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+        self.z = torch.zeros((h, w), dtype=torch.float32, device=dev)
+        self.cnt = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+
+    def render_own_tiles(self, want_stats=True):
+        tiles = capi.TileRange(self.tile_w, self.tile_h, self.rank, self.world)
+        stream = torch.cuda.current_stream(self.device_index).cuda_stream
+        return self.scene.render_tiles_device(self.cam, self.params, tiles, self.device_index, self.rgb.data_ptr(),
+                                              self.z.data_ptr(), self.cnt.data_ptr(), stream=stream, sync=True,
+                                              want_stats=want_stats)
+
+    def step(self):
+        st = self.render_own_tiles()
+        frame = gather_frame(self.rgb, self.z, self.cnt, self.rank, self.world, self.tile_w, self.tile_h)
+        return st, frame
