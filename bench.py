@@ -118,7 +118,7 @@ def main():
     dt = time.perf_counter() - t0
 
     keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "photon_queries", "photons_visited",
-            "bvh_nodes_visited", "tris_tested", "instance_visits"]
+            "bvh_nodes_visited", "tris_tested", "instance_visits", "gather_rounds", "gather_slow", "gather_leaf_reads"]
     tot = {k: float(sum(x[k] for x in stats)) for k in keys}
     ms = {k: float(sum(x[k] for x in stats)) for k in ("ms_trace", "ms_gather", "ms_resolve", "ms_total")}
     launches_g = float(sum(x["launches_gather"] for x in stats))
@@ -163,6 +163,7 @@ def main():
             "frame_ms": round(dt / a.steps * 1e3, 2),
             "rays_per_frame": {k: int(tot[k] / a.steps) for k in keys[:4]},
             "photon_queries_per_frame": int(tot["photon_queries"] / a.steps),
+            "gather_per_frame": {k: int(tot[k] / a.steps) for k in ("photons_visited", "gather_rounds", "gather_slow", "gather_leaf_reads")},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -157,6 +157,9 @@ typedef struct rt_stats {
     double   ms_resolve;            /* resolve kernels                                    */
     double   ms_total;              /* wall time of the job on its stream (events)        */
     uint64_t launches_trace, launches_gather, launches_resolve;
+    uint64_t gather_rounds;         /* (query, trial radius) pairs processed by the gather          */
+    uint64_t gather_slow;           /* of those, how many overflowed the LDS leaf list               */
+    uint64_t gather_leaf_reads;     /* 64-photon leaf reads, all passes                              */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;   /* opaque */

@@ -55,7 +55,8 @@ class Stats(C.Structure):
                                            "instance_visits", "bvh_nodes_visited", "tris_tested",
                                            "photon_queries", "photons_visited", "pixels", "samples")] +
                 [(n, C.c_double) for n in ("ms_trace", "ms_gather", "ms_resolve", "ms_total")] +
-                [(n, C.c_uint64) for n in ("launches_trace", "launches_gather", "launches_resolve")])
+                [(n, C.c_uint64) for n in ("launches_trace", "launches_gather", "launches_resolve",
+                                           "gather_rounds", "gather_slow", "gather_leaf_reads")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

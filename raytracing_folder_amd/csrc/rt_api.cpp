@@ -806,6 +806,7 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
         R.rays_refract = hs[ST_RAYS_REFRACT]; R.instance_visits = hs[ST_INSTANCE_VISITS]; R.bvh_nodes_visited = hs[ST_BVH_NODES];
         R.tris_tested = hs[ST_TRIS]; R.photon_queries = hs[ST_PHOTON_QUERIES]; R.photons_visited = hs[ST_PHOTONS_VISITED];
         R.pixels = 0; R.samples = hs[ST_RAYS_PRIMARY];
+        R.gather_rounds = hs[ST_GATHER_ROUNDS]; R.gather_slow = hs[ST_GATHER_SLOW]; R.gather_leaf_reads = hs[ST_GATHER_LEAF_READS];
         for (size_t i = 1; i < tm.ev.size(); i++) {
             if (tm.cls[i] < 0) continue;
             float ms = 0;

@@ -20,6 +20,9 @@
 
 #define BIGFLOAT 1.0e30f
 #define LEAF_BIT 0x80000000u
+#ifndef RT_GATHER_UNROLL
+#define RT_GATHER_UNROLL 1
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // float3 algebra in the reference's evaluation order (cyPoint.h:259-350, cyMatrix.h:542-546)
@@ -621,17 +624,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, int model, const
 // (FIN/include/cyPhotonMap.h:288-336, LocatePhotons :365-440).
 //
 // The reference walks its heap-ordered kd-tree recursively per query and keeps the k nearest
-// accepted photons (inside the radius, photonDir.N < 0) in a max-heap; the estimate only needs
+// accepted photons (inside the radius, photonDir.N < 0) in a max-heap, shrinking the search radius
+// once the heap is full; the estimate only needs
 //   sum of power, sum of dir*maxPower over that set, and r_k^2 (= radius^2 while at most k photons
 //   qualify, else the k-th smallest squared distance).
-// Here each wavefront serves 64 queries.  Phase A, one query per lane: a stackless walk of the
-// complete binary tree of leaf boxes lists the leaves within the radius (ids in LDS).  Phase B,
-// the whole wave per query: every listed leaf is one coalesced 64-photon read (lane = photon);
-// pass 1 counts candidates into a 256-bin histogram of the fixed-point distance key (LDS) while
-// summing all of them; if more than k qualify the bin holding the k-th is found with a wave scan,
-// pass 2 sums the bins below it and collects that one bin (<= 64 entries, else one more 8-bit
-// level) for an exact rank selection.  Sums are per-lane partials combined by a fixed butterfly,
-// so the result is deterministic.
+// Here each wavefront serves 64 queries at a time.
+//   Phase A, one query per lane: a stackless walk of the complete binary tree of leaf boxes lists
+//     the leaves within the query's CURRENT trial radius (ids in LDS).
+//   Phase B, the whole wave per query: every listed leaf is one coalesced 64-photon read
+//     (lane = photon).  Pass 1 counts the accepted photons into a 256-bin histogram of a 24-bit
+//     fixed-point distance key (LDS atomics) while summing all of them.  If the trial radius is
+//     smaller than the requested one and at most k photons qualified, the query is retried with a
+//     larger radius predicted from the count (photons lie on surfaces: count ~ r^2); a trial that
+//     finds MORE than k is exact, because the k nearest all lie inside it.  If more than k qualify,
+//     the bin holding the k-th is located with a wave scan, pass 2 sums the bins below it and
+//     collects that bin (<= 64 entries, else one more 8-bit level) for an exact rank selection.
+// Sums are per-lane partials combined by a fixed butterfly: deterministic.
 // ------------------------------------------------------------------------------------------------
 struct GatherArgs {
     DevPhotonMap pm;
@@ -681,6 +689,53 @@ struct GatherLds {
     uint32_t sel_n;
 };
 
+// one lane's photon of one leaf against one query (the test of LocatePhotons :383-392)
+struct Cand { bool ok; float d2; uint32_t key; float4 pa, pb; };
+struct GatherQuery { float px, py, pz, nx, ny, nz, rq2, kscale; };
+__device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuery &Q, bool valid)
+{
+    Cand c;
+    c.pa = pa; c.pb = pb;
+    const float dfx = pa.x - Q.px, dfy = pa.y - Q.py, dfz = pa.z - Q.pz;       // dif = p.position - np.pos
+    c.d2 = dfx * dfx + dfy * dfy + dfz * dfz;                                   // LengthSquared
+    c.ok = valid && (c.d2 < Q.rq2) && !((pa.w * Q.nx + pb.x * Q.ny + pb.y * Q.nz) >= 0);   // dist2 < dist2[0]; dir.N >= 0 rejects
+    uint32_t key = (uint32_t)(c.d2 * Q.kscale);
+    c.key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
+    return c;
+}
+
+// Visit every photon slot of the query's leaves: f(candidate, slot) is called wave-uniformly (all 64
+// lanes, same leaf) so it may use ballots.  RT_GATHER_UNROLL leaves are fetched per step (more
+// loads in flight per lane vs. registers/occupancy; measured on MI355X: 1 beats 4).
+template <class F>
+__device__ __forceinline__ void scan_leaves(const DevPhotonMap &pm, const uint16_t *list, uint32_t n_iter, bool slow,
+                                            int lane, const GatherQuery &Q, F &&f)
+{
+    if (!slow) {
+        uint32_t it = 0;
+#if RT_GATHER_UNROLL >= 2
+        for (; it + 2 <= n_iter; it += 2) {
+            const size_t s0 = (size_t)list[it] * RT_LEAF_PHOTONS + lane, s1 = (size_t)list[it + 1] * RT_LEAF_PHOTONS + lane;
+            const float4 a0 = pm.pa[s0], a1 = pm.pa[s1];
+            const float4 b0 = pm.pb[s0], b1 = pm.pb[s1];
+            f(make_cand(a0, b0, Q, true), s0); f(make_cand(a1, b1, Q, true), s1);
+        }
+#endif
+        for (; it < n_iter; it++) {
+            const size_t s0 = (size_t)list[it] * RT_LEAF_PHOTONS + lane;
+            f(make_cand(pm.pa[s0], pm.pb[s0], Q, true), s0);
+        }
+    } else {
+        // leaf list overflowed: test every leaf box (rare: trial radii keep the lists short)
+        const uint32_t n_leaves = pm.n_leaves;
+        for (uint32_t leaf = 0; leaf < n_leaves; leaf++) {
+            if (!(box_dist2(pm.tbox + 6 * (size_t)(n_leaves + leaf), Q.px, Q.py, Q.pz) < Q.rq2)) continue;
+            const size_t s0 = (size_t)leaf * RT_LEAF_PHOTONS + lane;
+            f(make_cand(pm.pa[s0], pm.pb[s0], Q, true), s0);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
 {
     __shared__ GatherLds lds_all[RT_GATHER_WAVES];
@@ -690,228 +745,218 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     if (nq > G.count_cap) nq = G.count_cap;
     const uint32_t n_leaves = G.pm.n_leaves;
     const float r2 = G.radius * G.radius;
-    const float kscale = 16777216.0f / r2;                 // 24-bit fixed-point distance key
+    const uint32_t K = (uint32_t)G.k;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long visited = 0;
+    uint32_t n_rounds = 0, n_slow = 0, n_reads = 0;       // wave-uniform tallies
 
     for (uint32_t qbase = wave_global * 64u; qbase < nq; qbase += n_waves * 64u) {
-        // ---------------- phase A: one query per lane, list the leaves in range ----------------
         const uint32_t qi = qbase + lane;
         const bool have = qi < nq;
         float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
         if (have) { a = G.qa[qi]; b = G.qb[qi]; c = G.qc[qi]; }
-        uint32_t nl = 0;
-        if (have && n_leaves) {
-            uint32_t node = 1;
-            while (node) {
-                bool descend = false;
-                if (box_dist2(G.pm.tbox + 6 * (size_t)node, a.x, a.y, a.z) < r2) {
-                    if (node >= n_leaves) {
-                        if (nl < RT_LEAFLIST_CAP) L.leaves[lane][nl] = (uint16_t)(node - n_leaves);
-                        nl++;
-                    } else { node = 2 * node; descend = true; }
-                }
-                if (!descend) {
-                    while (node & 1u) node >>= 1;          // climb while we are a right child
-                    if (node) node += 1;                   // then step to the right sibling
-                }
-            }
-        }
-        wave_sync();
-        // ---------------- phase B: the wave takes the queries one by one ------------------------
-        const int nhere = (int)min(64u, nq - qbase);
-        for (int q = 0; q < nhere; q++) {
-            const float px = __shfl(a.x, q), py = __shfl(a.y, q), pz = __shfl(a.z, q);
-            const float nx = __shfl(a.w, q), ny = __shfl(b.x, q), nz = __shfl(b.y, q);
-            const uint32_t qnl = __shfl(nl, q);
-            const bool slow = qnl > RT_LEAFLIST_CAP;       // list overflowed: test every leaf box
-            const uint32_t n_iter = slow ? n_leaves : qnl;
+        bool pending = have;
+        float r2cur = r2 * 0.0625f;                        // first trial: a quarter of the radius
+        if (n_leaves <= 1) r2cur = r2;
 
-            float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // sums of ALL candidates
-            uint32_t my_cnt = 0;
-            for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
-            wave_sync();
-            // pass 1
-            for (uint32_t it = 0; it < n_iter; it++) {
-                uint32_t leaf;
-                if (slow) { leaf = it; if (!(box_dist2(G.pm.tbox + 6 * (size_t)(n_leaves + leaf), px, py, pz) < r2)) continue; }
-                else leaf = L.leaves[q][it];
-                const size_t s = (size_t)leaf * RT_LEAF_PHOTONS + lane;
-                const float4 pa = G.pm.pa[s];
-                const float4 pb = G.pm.pb[s];
-                const float dfx = pa.x - px, dfy = pa.y - py, dfz = pa.z - pz;          // dif = p.position - np.pos
-                const float d2 = dfx * dfx + dfy * dfy + dfz * dfz;                     // LengthSquared
-                const bool ok = (d2 < r2) && !((pa.w * nx + pb.x * ny + pb.y * nz) >= 0);   // :386-392
-                if (ok) {
-                    const float2 pc = G.pm.pc[s];
-                    s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
-                    s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
-                    my_cnt++;
-                    uint32_t key = (uint32_t)(d2 * kscale);
-                    key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
-                    atomicAdd(&L.hist[key >> 16], 1u);
+        while (__ballot(pending)) {
+            // ---------------- phase A: pending lanes list the leaves inside their trial radius ----
+            uint32_t nl = 0;
+            if (pending && n_leaves) {
+                uint32_t node = 1;
+                while (node) {
+                    bool descend = false;
+                    if (box_dist2(G.pm.tbox + 6 * (size_t)node, a.x, a.y, a.z) < r2cur) {
+                        if (node >= n_leaves) {
+                            if (nl < RT_LEAFLIST_CAP) L.leaves[lane][nl] = (uint16_t)(node - n_leaves);
+                            nl++;
+                        } else { node = 2 * node; descend = true; }
+                    }
+                    if (!descend) {
+                        while (node & 1u) node >>= 1;      // climb while we are a right child
+                        if (node) node += 1;               // then step to the right sibling
+                    }
                 }
-                visited += 1;
             }
-            const uint32_t M = wave_sum_u(my_cnt);
-            float area_d2 = r2;                            // dist2[0]
-            if (M > (uint32_t)G.k) {
-                // ---- locate the k-th smallest: refine 8 bits of the key per level --------------
-                uint32_t need = (uint32_t)G.k;             // rank (1-based) inside the current range
-                uint32_t prefix = 0;                       // key bits fixed so far
-                int shift = 16;                            // the level's digit = (key >> shift) & 255
-                uint32_t in_bin = 0;
-                for (;;) {
-                    wave_sync();
-                    // bins 4*lane .. 4*lane+3
-                    const uint32_t h0 = L.hist[4 * lane], h1 = L.hist[4 * lane + 1], h2 = L.hist[4 * lane + 2], h3 = L.hist[4 * lane + 3];
-                    const uint32_t mine = h0 + h1 + h2 + h3;
-                    uint32_t incl = mine;
-                    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-                    const uint32_t excl = incl - mine;
-                    const unsigned long long m = __ballot(incl >= need);
-                    const int owner = __ffsll((long long)m) - 1;          // first lane whose range reaches `need`
-                    uint32_t digit = 0, before = 0, cntb = 0;
-                    if (lane == owner) {
-                        uint32_t cum = excl;
-                        if (cum + h0 >= need) { digit = 4 * lane; before = cum; cntb = h0; }
-                        else if (cum + h0 + h1 >= need) { digit = 4 * lane + 1; before = cum + h0; cntb = h1; }
-                        else if (cum + h0 + h1 + h2 >= need) { digit = 4 * lane + 2; before = cum + h0 + h1; cntb = h2; }
-                        else { digit = 4 * lane + 3; before = cum + h0 + h1 + h2; cntb = h3; }
-                    }
-                    digit = __shfl(digit, owner); before = __shfl(before, owner); cntb = __shfl(cntb, owner);
-                    need -= before;
-                    prefix |= digit << shift;
-                    in_bin = cntb;
-                    if (in_bin <= 64u || shift == 0) break;
-                    // one more level: histogram of the next 8 bits over the photons inside this bin
-                    shift -= 8;
-                    wave_sync();
-                    for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
-                    wave_sync();
-                    const uint32_t hi_mask = ~((1u << (shift + 8)) - 1u) & 0xFFFFFFu;
-                    for (uint32_t it = 0; it < n_iter; it++) {
-                        uint32_t leaf;
-                        if (slow) { leaf = it; if (!(box_dist2(G.pm.tbox + 6 * (size_t)(n_leaves + leaf), px, py, pz) < r2)) continue; }
-                        else leaf = L.leaves[q][it];
-                        const size_t s = (size_t)leaf * RT_LEAF_PHOTONS + lane;
-                        const float4 pa = G.pm.pa[s];
-                        const float4 pb = G.pm.pb[s];
-                        const float dfx = pa.x - px, dfy = pa.y - py, dfz = pa.z - pz;
-                        const float d2 = dfx * dfx + dfy * dfy + dfz * dfz;
-                        const bool ok = (d2 < r2) && !((pa.w * nx + pb.x * ny + pb.y * nz) >= 0);
-                        if (ok) {
-                            uint32_t key = (uint32_t)(d2 * kscale);
-                            key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
-                            if ((key & hi_mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
-                        }
-                        visited += 1;
-                    }
-                }
-                // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
-                const uint32_t bin_mask = ~((1u << shift) - 1u) & 0xFFFFFFu;
-                s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
-                if (lane == 0) L.sel_n = 0;
+            wave_sync();
+            // ---------------- phase B: the wave takes the pending queries one by one --------------
+            unsigned long long todo = __ballot(pending);
+            while (todo) {
+                const int q = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                GatherQuery Q;
+                Q.px = __shfl(a.x, q); Q.py = __shfl(a.y, q); Q.pz = __shfl(a.z, q);
+                Q.nx = __shfl(a.w, q); Q.ny = __shfl(b.x, q); Q.nz = __shfl(b.y, q);
+                Q.rq2 = __shfl(r2cur, q);
+                Q.kscale = 16777216.0f / Q.rq2;            // 24-bit fixed-point distance key
+                const float rq2 = Q.rq2, nx = Q.nx, ny = Q.ny, nz = Q.nz;
+                const uint32_t qnl = __shfl(nl, q);
+                const bool final_round = rq2 >= r2;
+                const bool slow = qnl > RT_LEAFLIST_CAP;   // list overflowed: test every leaf box instead
+                const uint32_t n_iter = slow ? 0u : qnl;
+                const uint16_t *list = L.leaves[q];
+                n_rounds++; n_slow += slow ? 1u : 0u; n_reads += slow ? G.pm.n_leaves : qnl;
+
+                float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // sums over ALL candidates
+                uint32_t my_cnt = 0;
+                for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                 wave_sync();
-                uint32_t tie_taken = 0;                    // only used when in_bin > 64 (identical keys)
-                float tmax = 0.0f;
-                for (uint32_t it = 0; it < n_iter; it++) {
-                    uint32_t leaf;
-                    if (slow) { leaf = it; if (!(box_dist2(G.pm.tbox + 6 * (size_t)(n_leaves + leaf), px, py, pz) < r2)) continue; }
-                    else leaf = L.leaves[q][it];
-                    const size_t s = (size_t)leaf * RT_LEAF_PHOTONS + lane;
-                    const float4 pa = G.pm.pa[s];
-                    const float4 pb = G.pm.pb[s];
-                    const float dfx = pa.x - px, dfy = pa.y - py, dfz = pa.z - pz;
-                    const float d2 = dfx * dfx + dfy * dfy + dfz * dfz;
-                    const bool ok = (d2 < r2) && !((pa.w * nx + pb.x * ny + pb.y * nz) >= 0);
-                    uint32_t key = (uint32_t)(d2 * kscale);
-                    key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
-                    const uint32_t kb = key & bin_mask;
-                    bool take = ok && kb < prefix;
-                    const bool inb = ok && kb == prefix;
-                    if (in_bin <= 64u) {
-                        const unsigned long long mb = __ballot(inb);
-                        if (mb) {
-                            uint32_t base = 0;
-                            const int leader = __ffsll((long long)mb) - 1;
-                            if (lane == leader) { base = L.sel_n; L.sel_n = base + (uint32_t)__popcll(mb); }
-                            base = __shfl(base, leader);
-                            if (inb) {
-                                const uint32_t at = base + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                                if (at < 64u) { L.sel_d[at] = d2; L.sel_i[at] = (uint32_t)s; }
-                            }
-                        }
-                    } else {
-                        // more than 64 photons share all 24 key bits: take the first `need` in scan order
-                        const unsigned long long mb = __ballot(inb);
-                        const uint32_t rank = tie_taken + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                        if (inb && rank < need) { take = true; tmax = fmaxf(tmax, d2); }
-                        tie_taken += (uint32_t)__popcll(mb);
-                    }
-                    if (take) {
+                // pass 1
+                scan_leaves(G.pm, list, n_iter, slow, lane, Q, [&](const Cand &cd, size_t s) {
+                    if (cd.ok) {
                         const float2 pc = G.pm.pc[s];
-                        s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
-                        s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
+                        s_pr += cd.pb.w; s_pg += pc.x; s_pb += pc.y;
+                        s_dx += cd.pa.w * cd.pb.z; s_dy += cd.pb.x * cd.pb.z; s_dz += cd.pb.y * cd.pb.z;
+                        my_cnt++;
+                        atomicAdd(&L.hist[cd.key >> 16], 1u);
                     }
                     visited += 1;
+                });
+                const uint32_t M = wave_sum_u(my_cnt);
+                if (!final_round && M <= K) {
+                    // not enough inside the trial radius: grow it (count ~ r^2 on a surface) and retry
+                    float grow = 1.5f * (float)K / (float)(M > 0 ? M : 1u);
+                    grow = fminf(fmaxf(grow, 2.0f), 16.0f);
+                    if (lane == q) r2cur = fminf(rq2 * grow, r2);
+                    continue;
                 }
-                wave_sync();
-                if (in_bin <= 64u) {
-                    // exact selection: rank by (d2, list position); take ranks < need
-                    const uint32_t n_sel = min(L.sel_n, 64u);
-                    const bool mine = (uint32_t)lane < n_sel;
-                    const float md = mine ? L.sel_d[lane] : 3.0e38f;
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < n_sel; j++) {
-                        const float od = L.sel_d[j];
-                        rank += (od < md || (od == md && j < (uint32_t)lane)) ? 1u : 0u;
+                float area_d2 = rq2;                       // dist2[0]; only reached with rq2 == r2 when M <= K
+                if (M > K) {
+                    // ---- locate the k-th smallest: refine 8 bits of the key per level --------------
+                    uint32_t need = K;                     // rank (1-based) inside the current range
+                    uint32_t prefix = 0;                   // key bits fixed so far
+                    int shift = 16;                        // the level's digit = (key >> shift) & 255
+                    uint32_t in_bin = 0;
+                    for (;;) {
+                        wave_sync();
+                        const uint32_t h0 = L.hist[4 * lane], h1 = L.hist[4 * lane + 1], h2 = L.hist[4 * lane + 2], h3 = L.hist[4 * lane + 3];
+                        const uint32_t mine = h0 + h1 + h2 + h3;
+                        uint32_t incl = mine;
+                        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+                        const uint32_t excl = incl - mine;
+                        const unsigned long long m = __ballot(incl >= need);
+                        const int owner = __ffsll((long long)m) - 1;      // first lane whose range reaches `need`
+                        uint32_t digit = 0, before = 0, cntb = 0;
+                        if (lane == owner) {
+                            const uint32_t cum = excl;
+                            if (cum + h0 >= need) { digit = 4 * lane; before = cum; cntb = h0; }
+                            else if (cum + h0 + h1 >= need) { digit = 4 * lane + 1; before = cum + h0; cntb = h1; }
+                            else if (cum + h0 + h1 + h2 >= need) { digit = 4 * lane + 2; before = cum + h0 + h1; cntb = h2; }
+                            else { digit = 4 * lane + 3; before = cum + h0 + h1 + h2; cntb = h3; }
+                        }
+                        digit = __shfl(digit, owner); before = __shfl(before, owner); cntb = __shfl(cntb, owner);
+                        need -= before;
+                        prefix |= digit << shift;
+                        in_bin = cntb;
+                        if (in_bin <= 64u || shift == 0) break;
+                        // one more level: histogram of the next 8 bits over the photons inside this bin
+                        shift -= 8;
+                        wave_sync();
+                        for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
+                        wave_sync();
+                        const uint32_t hi_mask = ~((1u << (shift + 8)) - 1u) & 0xFFFFFFu;
+                        scan_leaves(G.pm, list, n_iter, slow, lane, Q, [&](const Cand &cd, size_t) {
+                            if (cd.ok && (cd.key & hi_mask) == prefix) atomicAdd(&L.hist[(cd.key >> shift) & 255u], 1u);
+                        });
                     }
-                    if (mine && rank < need) {
-                        const size_t s = L.sel_i[lane];
-                        const float4 pa = G.pm.pa[s];
-                        const float4 pb = G.pm.pb[s];
-                        const float2 pc = G.pm.pc[s];
-                        s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
-                        s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
-                        tmax = md;
+                    n_reads += slow ? G.pm.n_leaves : qnl;
+                    // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
+                    const uint32_t bin_mask = ~((1u << shift) - 1u) & 0xFFFFFFu;
+                    s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
+                    if (lane == 0) L.sel_n = 0;
+                    wave_sync();
+                    uint32_t tie_taken = 0;                // only used when in_bin > 64 (identical keys)
+                    float tmax = 0.0f;
+                    scan_leaves(G.pm, list, n_iter, slow, lane, Q, [&](const Cand &cd, size_t s) {
+                        const uint32_t kb = cd.key & bin_mask;
+                        bool take = cd.ok && kb < prefix;
+                        const bool inb = cd.ok && kb == prefix;
+                        const unsigned long long mb = __ballot(inb);
+                        if (in_bin <= 64u) {
+                            if (mb) {
+                                uint32_t base = 0;
+                                const int leader = __ffsll((long long)mb) - 1;
+                                if (lane == leader) { base = L.sel_n; L.sel_n = base + (uint32_t)__popcll(mb); }
+                                base = __shfl(base, leader);
+                                if (inb) {
+                                    const uint32_t at = base + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                                    if (at < 64u) { L.sel_d[at] = cd.d2; L.sel_i[at] = (uint32_t)s; }
+                                }
+                            }
+                        } else {
+                            // more than 64 photons share all 24 key bits: take the first `need` in scan order
+                            const uint32_t rank = tie_taken + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                            if (inb && rank < need) { take = true; tmax = fmaxf(tmax, cd.d2); }
+                            tie_taken += (uint32_t)__popcll(mb);
+                        }
+                        if (take) {
+                            const float2 pc = G.pm.pc[s];
+                            s_pr += cd.pb.w; s_pg += pc.x; s_pb += pc.y;
+                            s_dx += cd.pa.w * cd.pb.z; s_dy += cd.pb.x * cd.pb.z; s_dz += cd.pb.y * cd.pb.z;
+                        }
+                    });
+                    wave_sync();
+                    if (in_bin <= 64u) {
+                        // exact selection: rank by (d2, list position); take ranks < need
+                        const uint32_t n_sel = min(L.sel_n, 64u);
+                        const bool mine = (uint32_t)lane < n_sel;
+                        const float md = mine ? L.sel_d[lane] : 3.0e38f;
+                        uint32_t rank = 0;
+                        for (uint32_t j = 0; j < n_sel; j++) {
+                            const float od = L.sel_d[j];
+                            rank += (od < md || (od == md && j < (uint32_t)lane)) ? 1u : 0u;
+                        }
+                        if (mine && rank < need) {
+                            const size_t s = L.sel_i[lane];
+                            const float4 pa = G.pm.pa[s];
+                            const float4 pb = G.pm.pb[s];
+                            const float2 pc = G.pm.pc[s];
+                            s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
+                            s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
+                            tmax = md;
+                        }
                     }
+                    for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+                    area_d2 = tmax;                        // np.dist2[0] = largest kept distance
                 }
-                for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
-                area_d2 = tmax;                            // np.dist2[0] = largest kept distance
-            }
-            float irr_r = wave_sum(s_pr), irr_g = wave_sum(s_pg), irr_b = wave_sum(s_pb);
-            float dx = wave_sum(s_dx), dy = wave_sum(s_dy), dz = wave_sum(s_dz);
-            if (M > 0) {
-                const float area = (float)M_PI * area_d2;                  // :326
-                if (area > 0) { const float inv = 1.0f / area; irr_r *= inv; irr_g *= inv; irr_b *= inv; }
-                const float l = sqrtf(dx * dx + dy * dy + dz * dz);        // direction.Normalize() :334
-                dx /= l; dy /= l; dz /= l;
-            }
-            if (lane == 0) {
-                const uint32_t qq = qbase + (uint32_t)q;
+                float irr_r = wave_sum(s_pr), irr_g = wave_sum(s_pg), irr_b = wave_sum(s_pb);
+                float dx = wave_sum(s_dx), dy = wave_sum(s_dy), dz = wave_sum(s_dz);
+                if (M > 0) {
+                    const float area = (float)M_PI * area_d2;              // :326
+                    if (area > 0) { const float inv = 1.0f / area; irr_r *= inv; irr_g *= inv; irr_b *= inv; }
+                    const float l = sqrtf(dx * dx + dy * dy + dz * dz);    // direction.Normalize() :334
+                    dx /= l; dy /= l; dz /= l;
+                }
                 if (G.mode == 1) {
-                    G.out_irr[3 * (size_t)qq] = irr_r; G.out_irr[3 * (size_t)qq + 1] = irr_g; G.out_irr[3 * (size_t)qq + 2] = irr_b;
-                    G.out_dir[3 * (size_t)qq] = dx; G.out_dir[3 * (size_t)qq + 1] = dy; G.out_dir[3 * (size_t)qq + 2] = dz;
+                    if (lane == 0) {
+                        const size_t qq = (size_t)qbase + (size_t)q;
+                        G.out_irr[3 * qq] = irr_r; G.out_irr[3 * qq + 1] = irr_g; G.out_irr[3 * qq + 2] = irr_b;
+                        G.out_dir[3 * qq] = dx; G.out_dir[3 * qq + 1] = dy; G.out_dir[3 * qq + 2] = dz;
+                    }
+                } else {
+                    // idr_Color += kd * photonrad * max(0, N.(-dir)) (FIN/main.cpp:701-704), times the ray weight
+                    const float wr = __shfl(b.z, q), wg = __shfl(b.w, q), wb = __shfl(c.x, q);
+                    const uint32_t slot = __float_as_uint(__shfl(c.y, q));
+                    float theta = nx * (-dx) + ny * (-dy) + nz * (-dz);
+                    theta = theta > 0.0f ? theta : 0.0f;
+                    if (lane < 3) {
+                        const float w = lane == 0 ? wr : (lane == 1 ? wg : wb);
+                        const float ir = lane == 0 ? irr_r : (lane == 1 ? irr_g : irr_b);
+                        atomicAdd(G.sample_rgb + 3 * (size_t)slot + lane, (w * ir) * theta);
+                    }
                 }
-            }
-            if (G.mode == 0) {
-                // idr_Color += kd * photonrad * max(0, N.(-dir)) (FIN/main.cpp:701-704), times the ray weight
-                const float wr = __shfl(b.z, q), wg = __shfl(b.w, q), wb = __shfl(c.x, q);
-                const uint32_t slot = __float_as_uint(__shfl(c.y, q));
-                float theta = nx * (-dx) + ny * (-dy) + nz * (-dz);
-                theta = theta > 0.0f ? theta : 0.0f;
-                if (lane < 3) {
-                    const float w = lane == 0 ? wr : (lane == 1 ? wg : wb);
-                    const float ir = lane == 0 ? irr_r : (lane == 1 ? irr_g : irr_b);
-                    atomicAdd(G.sample_rgb + 3 * (size_t)slot + lane, (w * ir) * theta);
-                }
+                if (lane == q) pending = false;
             }
             wave_sync();
         }
     }
-    if (lane == 0 && G.stats && visited) atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * 64ull);
+    if (lane == 0 && G.stats && visited) {
+        atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * 64ull);
+        atomicAdd(&G.stats[ST_GATHER_ROUNDS], (unsigned long long)n_rounds);
+        atomicAdd(&G.stats[ST_GATHER_SLOW], (unsigned long long)n_slow);
+        atomicAdd(&G.stats[ST_GATHER_LEAF_READS], (unsigned long long)n_reads);
+    }
     if (G.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&G.stats[ST_PHOTON_QUERIES], (unsigned long long)nq);
 }
 
