@@ -26,9 +26,11 @@ void rtk_launch_bounce(hipStream_t, const DevScene &, const DevWork &, const rt_
                        const DevRayQueue &, uint32_t *, int, int);
 void rtk_launch_trace(hipStream_t, const DevScene &, int, const float *, long long, uint8_t *, float *, float *, float *, int32_t *, uint8_t *);
 void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const float4 *, const float4 *, const uint32_t *,
-                       uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int);
+                       uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint16_t *, uint32_t *);
 void rtk_launch_resolve(hipStream_t, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
                         float, float, int, const float *, uint8_t *, float *, uint8_t *, int);
+
+#define GATHER_BLOCKS (256 * 4)
 
 // ---- errors ---------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -105,7 +107,7 @@ struct DeviceState {
     bool scene_valid = false, photons_valid = false;
     DevBuf nodes, objects, meshes, materials, lights, node_material;
     std::vector<DevMeshBufs> mesh_bufs;
-    DevBuf pa, pb, pc, tbox;
+    DevBuf pa, pb, pc, tbox, spill, grid;
     DevScene scene{};
     // workspace
     DevBuf sample_rgb, sample_z, sample_hit, rq[2][4], pq[3], counts, pixel_list, stats;
@@ -115,7 +117,7 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     void release()
     {
-        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &pa, &pb, &pc, &tbox,
+        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &pa, &pb, &pc, &tbox, &spill, &grid,
                           &sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); }
         for (int i = 0; i < 2; i++) for (int k = 0; k < 4; k++) rq[i][k].release();
@@ -582,6 +584,26 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D)
     if ((st = D->tbox.upload(tbox.data(), tbox.size() * 4))) return st;
     pm.pa = (const float4 *)D->pa.p; pm.pb = (const float4 *)D->pb.p; pm.pc = (const float2 *)D->pc.p; pm.tbox = (const float *)D->tbox.p;
     pm.n_leaves = n_leaves; pm.n_photons = (uint32_t)recs.size();
+    {   // density grid over the photons' bounding box, at most 64 cells along the longest axis
+        const float *rb = &tbox[6];
+        float ext = std::max(std::max(rb[3] - rb[0], rb[4] - rb[1]), rb[5] - rb[2]);
+        if (!(ext > 0)) ext = 1.0f;
+        const float cell = ext / 64.0f;
+        int dim[3];
+        for (int a = 0; a < 3; a++) dim[a] = std::min(64, std::max(1, (int)std::floor((rb[3 + a] - rb[a]) / cell) + 1));
+        std::vector<uint32_t> grid((size_t)dim[0] * dim[1] * dim[2], 0u);
+        for (const PRec &q : recs) {
+            int g[3];
+            for (int a = 0; a < 3; a++) g[a] = std::min(dim[a] - 1, std::max(0, (int)((q.pos[a] - rb[a]) / cell)));
+            grid[((size_t)g[2] * dim[1] + g[1]) * dim[0] + g[0]]++;
+        }
+        if ((st = D->grid.upload(grid.data(), grid.size() * 4))) return st;
+        pm.grid = (const uint32_t *)D->grid.p;
+        for (int a = 0; a < 3; a++) { pm.grid_min[a] = rb[a]; pm.grid_dim[a] = dim[a]; }
+        pm.cell = cell; pm.inv_cell = 1.0f / cell;
+    }
+    // spill lists: one per wave of the gather grid (GATHER_BLOCKS x RT_GATHER_WAVES), n_leaves ids each
+    if ((st = D->spill.ensure((size_t)GATHER_BLOCKS * RT_GATHER_WAVES * n_leaves * sizeof(uint16_t)))) return st;
     return RT_OK;
 }
 
@@ -714,7 +736,8 @@ static rt_status run_pipeline(DeviceState *D, hipStream_t st, const DevWork &W, 
     if ((s = mark(0))) return s;
     if (D->scene.pm.n_leaves) {
         rtk_launch_gather(st, D->scene.pm, W.pq.qa, W.pq.qb, W.pq.qc, W.counts + CNT_PHOTONQ, W.pq.cap, P.knn_k, P.knn_radius,
-                          W.sample_rgb, nullptr, nullptr, 0, W.stats, 256 * 4);
+                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, (uint16_t *)D->spill.p,
+                          W.counts + CNT_GATHER_NEXT);
         if ((s = mark(1))) return s;
     }
     HIP_TRY(hipGetLastError());
@@ -955,15 +978,16 @@ extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, 
         qb[i] = make_float4(normal[3 * i + 1], normal[3 * i + 2], 0, 0);
         qc[i] = make_float4(0, 0, 0, 0);
     }
-    const uint32_t cnt = (uint32_t)n;
+    const uint32_t cnt[2] = {(uint32_t)n, 0u};            // query count, work counter
     if ((st = D->t_out[0].upload(qa.data(), (size_t)n * 16))) return st;
     if ((st = D->t_out[1].upload(qb.data(), (size_t)n * 16))) return st;
     if ((st = D->t_out[2].upload(qc.data(), (size_t)n * 16))) return st;
     if ((st = D->t_out[3].ensure((size_t)n * 12))) return st;
     if ((st = D->t_out[4].ensure((size_t)n * 12))) return st;
-    if ((st = D->t_in.upload(&cnt, 4))) return st;
+    if ((st = D->t_in.upload(cnt, 8))) return st;
     rtk_launch_gather(D->stream, D->scene.pm, (const float4 *)D->t_out[0].p, (const float4 *)D->t_out[1].p, (const float4 *)D->t_out[2].p,
-                      (const uint32_t *)D->t_in.p, cnt, k, radius, nullptr, (float *)D->t_out[3].p, (float *)D->t_out[4].p, 1, nullptr, 256 * 4);
+                      (const uint32_t *)D->t_in.p, cnt[0], k, radius, nullptr, (float *)D->t_out[3].p, (float *)D->t_out[4].p, 1, nullptr, GATHER_BLOCKS,
+                      (uint16_t *)D->spill.p, (uint32_t *)D->t_in.p + 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(D->stream));
     HIP_TRY(hipMemcpy(irr, D->t_out[3].p, (size_t)n * 12, hipMemcpyDeviceToHost));

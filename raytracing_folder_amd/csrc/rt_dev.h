@@ -66,6 +66,11 @@ struct DevPhotonMap {
     const float  *tbox;          // [2*n_leaves][6]
     uint32_t n_leaves;           // power of two, 0 = no photon map
     uint32_t n_photons;          // photons stored in the leaves
+    // coarse density grid (photon count per cubic cell of side `cell`) used only to pick the first
+    // trial radius of a query: any radius gives the exact answer, a good one saves work
+    const uint32_t *grid;
+    float grid_min[3]; float cell, inv_cell;
+    int32_t grid_dim[3];
 };
 
 struct DevScene {
@@ -121,6 +126,7 @@ struct DevWork {
     uint32_t *pixel_list;     // pixels (chunk-local) that take the second sample batch
     unsigned long long *stats;
 };
+#define CNT_GATHER_NEXT 15     // work counter of k_gather (64-query batches handed out so far)
 #define CNT_PHOTONQ 16
 #define CNT_PIXLIST 17
 #define CNT_TOTAL   32

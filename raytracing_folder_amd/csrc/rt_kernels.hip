@@ -645,12 +645,14 @@ struct GatherArgs {
     DevPhotonMap pm;
     const float4 *qa, *qb, *qc;      // query queue
     const uint32_t *count_ptr;       // number of queries (device)
+    uint32_t *next_batch;            // work counter, zero at launch
     uint32_t count_cap;
     int k; float radius;
     float *sample_rgb;               // mode 0: atomicAdd w * irr * max(0, N.(-dir)) into the slot
     float *out_irr, *out_dir;        // mode 1: write irr[3], dir[3] per query (rt_estimate_irradiance)
     int mode;
     unsigned long long *stats;
+    uint16_t *spill;                 // [waves in the grid][n_leaves]: leaf lists too long for LDS
 };
 
 __device__ __forceinline__ float wave_sum(float x)
@@ -708,31 +710,21 @@ __device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuer
 // lanes, same leaf) so it may use ballots.  RT_GATHER_UNROLL leaves are fetched per step (more
 // loads in flight per lane vs. registers/occupancy; measured on MI355X: 1 beats 4).
 template <class F>
-__device__ __forceinline__ void scan_leaves(const DevPhotonMap &pm, const uint16_t *list, uint32_t n_iter, bool slow,
+__device__ __forceinline__ void scan_leaves(const DevPhotonMap &pm, const uint16_t *list, uint32_t n_iter,
                                             int lane, const GatherQuery &Q, F &&f)
 {
-    if (!slow) {
-        uint32_t it = 0;
+    uint32_t it = 0;
 #if RT_GATHER_UNROLL >= 2
-        for (; it + 2 <= n_iter; it += 2) {
-            const size_t s0 = (size_t)list[it] * RT_LEAF_PHOTONS + lane, s1 = (size_t)list[it + 1] * RT_LEAF_PHOTONS + lane;
-            const float4 a0 = pm.pa[s0], a1 = pm.pa[s1];
-            const float4 b0 = pm.pb[s0], b1 = pm.pb[s1];
-            f(make_cand(a0, b0, Q, true), s0); f(make_cand(a1, b1, Q, true), s1);
-        }
+    for (; it + 2 <= n_iter; it += 2) {
+        const size_t s0 = (size_t)list[it] * RT_LEAF_PHOTONS + lane, s1 = (size_t)list[it + 1] * RT_LEAF_PHOTONS + lane;
+        const float4 a0 = pm.pa[s0], a1 = pm.pa[s1];
+        const float4 b0 = pm.pb[s0], b1 = pm.pb[s1];
+        f(make_cand(a0, b0, Q, true), s0); f(make_cand(a1, b1, Q, true), s1);
+    }
 #endif
-        for (; it < n_iter; it++) {
-            const size_t s0 = (size_t)list[it] * RT_LEAF_PHOTONS + lane;
-            f(make_cand(pm.pa[s0], pm.pb[s0], Q, true), s0);
-        }
-    } else {
-        // leaf list overflowed: test every leaf box (rare: trial radii keep the lists short)
-        const uint32_t n_leaves = pm.n_leaves;
-        for (uint32_t leaf = 0; leaf < n_leaves; leaf++) {
-            if (!(box_dist2(pm.tbox + 6 * (size_t)(n_leaves + leaf), Q.px, Q.py, Q.pz) < Q.rq2)) continue;
-            const size_t s0 = (size_t)leaf * RT_LEAF_PHOTONS + lane;
-            f(make_cand(pm.pa[s0], pm.pb[s0], Q, true), s0);
-        }
+    for (; it < n_iter; it++) {
+        const size_t s0 = (size_t)list[it] * RT_LEAF_PHOTONS + lane;
+        f(make_cand(pm.pa[s0], pm.pb[s0], Q, true), s0);
     }
 }
 
@@ -751,14 +743,32 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     unsigned long long visited = 0;
     uint32_t n_rounds = 0, n_slow = 0, n_reads = 0;       // wave-uniform tallies
 
-    for (uint32_t qbase = wave_global * 64u; qbase < nq; qbase += n_waves * 64u) {
+    // 64-query batches are handed out dynamically (one atomic per batch): query cost varies by two
+    // orders of magnitude with the local photon density, so a static split leaves a long tail
+    const uint32_t n_batches = (nq + 63u) / 64u;
+    const float guess_c = 1.4f * (float)K * G.pm.cell * G.pm.cell / (float)M_PI;
+
+    for (;;) {
+        uint32_t batch = 0;
+        if (lane == 0) batch = atomicAdd(G.next_batch, 1u);
+        batch = __shfl(batch, 0);
+        if (batch >= n_batches) break;
+        const uint32_t qbase = batch * 64u;
         const uint32_t qi = qbase + lane;
         const bool have = qi < nq;
         float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
         if (have) { a = G.qa[qi]; b = G.qb[qi]; c = G.qc[qi]; }
         bool pending = have;
-        float r2cur = r2 * 0.0625f;                        // first trial: a quarter of the radius
-        if (n_leaves <= 1) r2cur = r2;
+        // first trial radius from the density grid: about 1.4 k photons expected inside (count ~ r^2
+        // on a surface through a cell of side h: c photons per h^2)
+        float r2cur = r2;
+        if (have && n_leaves > 1) {
+            const int gx = min(max((int)((a.x - G.pm.grid_min[0]) * G.pm.inv_cell), 0), G.pm.grid_dim[0] - 1);
+            const int gy = min(max((int)((a.y - G.pm.grid_min[1]) * G.pm.inv_cell), 0), G.pm.grid_dim[1] - 1);
+            const int gz = min(max((int)((a.z - G.pm.grid_min[2]) * G.pm.inv_cell), 0), G.pm.grid_dim[2] - 1);
+            const uint32_t cnt = G.pm.grid[((size_t)gz * G.pm.grid_dim[1] + gy) * G.pm.grid_dim[0] + gx];
+            r2cur = fminf(fmaxf(guess_c / (float)(cnt > 0u ? cnt : 1u), r2 * 1.0e-4f), r2);
+        }
 
         while (__ballot(pending)) {
             // ---------------- phase A: pending lanes list the leaves inside their trial radius ----
@@ -793,17 +803,34 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 const float rq2 = Q.rq2, nx = Q.nx, ny = Q.ny, nz = Q.nz;
                 const uint32_t qnl = __shfl(nl, q);
                 const bool final_round = rq2 >= r2;
-                const bool slow = qnl > RT_LEAFLIST_CAP;   // list overflowed: test every leaf box instead
-                const uint32_t n_iter = slow ? 0u : qnl;
-                const uint16_t *list = L.leaves[q];
-                n_rounds++; n_slow += slow ? 1u : 0u; n_reads += slow ? G.pm.n_leaves : qnl;
+                const bool slow = qnl > RT_LEAFLIST_CAP;   // the LDS list overflowed
+                uint32_t n_iter = qnl;
+                uint16_t *spill = G.spill + (size_t)wave_global * n_leaves;
+                if (slow) {
+                    // rebuild the list in this wave's global scratch: 64 leaf boxes per step, ballot-compacted
+                    n_iter = 0;
+                    for (uint32_t base = 0; base < n_leaves; base += 64u) {
+                        const uint32_t leaf = base + (uint32_t)lane;
+                        const bool in = leaf < n_leaves && box_dist2(G.pm.tbox + 6 * (size_t)(n_leaves + leaf), Q.px, Q.py, Q.pz) < rq2;
+                        const unsigned long long m = __ballot(in);
+                        if (in) spill[n_iter + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)leaf;
+                        n_iter += (uint32_t)__popcll(m);
+                    }
+                    wave_sync();
+                }
+                n_rounds++; n_slow += slow ? 1u : 0u; n_reads += n_iter;
+                // run one pass over the query's leaves, from the LDS list or from the spill list
+                auto for_each = [&](auto &&f) {
+                    if (slow) scan_leaves(G.pm, spill, n_iter, lane, Q, f);
+                    else scan_leaves(G.pm, L.leaves[q], n_iter, lane, Q, f);
+                };
 
                 float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // sums over ALL candidates
                 uint32_t my_cnt = 0;
                 for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                 wave_sync();
                 // pass 1
-                scan_leaves(G.pm, list, n_iter, slow, lane, Q, [&](const Cand &cd, size_t s) {
+                for_each([&](const Cand &cd, size_t s) {
                     if (cd.ok) {
                         const float2 pc = G.pm.pc[s];
                         s_pr += cd.pb.w; s_pg += pc.x; s_pb += pc.y;
@@ -856,11 +883,11 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                         wave_sync();
                         const uint32_t hi_mask = ~((1u << (shift + 8)) - 1u) & 0xFFFFFFu;
-                        scan_leaves(G.pm, list, n_iter, slow, lane, Q, [&](const Cand &cd, size_t) {
+                        for_each([&](const Cand &cd, size_t) {
                             if (cd.ok && (cd.key & hi_mask) == prefix) atomicAdd(&L.hist[(cd.key >> shift) & 255u], 1u);
                         });
                     }
-                    n_reads += slow ? G.pm.n_leaves : qnl;
+                    n_reads += n_iter;
                     // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
                     const uint32_t bin_mask = ~((1u << shift) - 1u) & 0xFFFFFFu;
                     s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
@@ -868,7 +895,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     wave_sync();
                     uint32_t tie_taken = 0;                // only used when in_bin > 64 (identical keys)
                     float tmax = 0.0f;
-                    scan_leaves(G.pm, list, n_iter, slow, lane, Q, [&](const Cand &cd, size_t s) {
+                    for_each([&](const Cand &cd, size_t s) {
                         const uint32_t kb = cd.key & bin_mask;
                         bool take = cd.ok && kb < prefix;
                         const bool inb = cd.ok && kb == prefix;
@@ -1080,10 +1107,10 @@ void rtk_launch_trace(hipStream_t st, const DevScene &S, int model, const float 
 void rtk_launch_gather(hipStream_t st, const DevPhotonMap &pm, const float4 *qa, const float4 *qb,
                        const float4 *qc, const uint32_t *count_ptr, uint32_t count_cap, int k,
                        float radius, float *sample_rgb, float *out_irr, float *out_dir, int mode,
-                       unsigned long long *stats, int blocks)
+                       unsigned long long *stats, int blocks, uint16_t *spill, uint32_t *next_batch)
 {
     GatherArgs G; G.pm = pm; G.qa = qa; G.qb = qb; G.qc = qc; G.count_ptr = count_ptr; G.count_cap = count_cap;
-    G.k = k; G.radius = radius; G.sample_rgb = sample_rgb; G.out_irr = out_irr; G.out_dir = out_dir; G.mode = mode; G.stats = stats;
+    G.k = k; G.radius = radius; G.sample_rgb = sample_rgb; G.out_irr = out_irr; G.out_dir = out_dir; G.mode = mode; G.stats = stats; G.spill = spill; G.next_batch = next_batch;
     hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(64 * RT_GATHER_WAVES), 0, st, G);
 }
 
