@@ -702,7 +702,11 @@ static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const 
     if (cam->width <= 0 || cam->height <= 0 || (long long)cam->width * cam->height > (1LL << 28)) return fail(RT_ERR_ARG, "render: bad image size %dx%d", cam->width, cam->height);
     if (cam->dof != 0) return fail(RT_ERR_LIMIT, "render: depth of field (camera.dof != 0) is not implemented on the device yet");
     if (p->min_sample < 1 || p->max_sample < p->min_sample || p->max_sample > 4096) return fail(RT_ERR_ARG, "render: need 1 <= min_sample <= max_sample <= 4096");
-    if (p->shade_model != RT_SHADE_FIN) return fail(RT_ERR_LIMIT, "render: only RT_SHADE_FIN shading is implemented on the device yet");
+    if (p->shade_model != RT_SHADE_FIN && p->shade_model != RT_SHADE_P13) return fail(RT_ERR_ARG, "render: unknown shade model %d", p->shade_model);
+    if (p->shade_model == RT_SHADE_P13)
+        for (const rt_blinn &m : s->data.materials)
+            if (m.reflection_glossiness != 0 || m.refraction_glossiness != 0)
+                return fail(RT_ERR_LIMIT, "render: glossy reflection/refraction (P13 shading) is not implemented on the device yet");
     if (p->knn_k < 1 || p->knn_k > 65536 || !(p->knn_radius > 0)) return fail(RT_ERR_ARG, "render: bad photon gather parameters");
     if (!(p->gamma > 0)) return fail(RT_ERR_ARG, "render: gamma must be positive");
     if (t->tile_w <= 0 || t->tile_h <= 0 || t->stride <= 0 || t->first < 0) return fail(RT_ERR_ARG, "render: bad tile range");

@@ -183,8 +183,8 @@ __device__ __forceinline__ bool tri_hit_p13(const DevTri &T, V3 rp, V3 rd, float
 
 // TriObj::IntersectRay -> TraceBVHNode (FIN/include/objects.h:127-133, 271-302) as an iterative,
 // near-first traversal with a per-lane stack in LDS.  ANY: stop at the first accepted triangle.
-template <bool ANY>
-__device__ bool mesh_hit(const DevMesh &M, int model, V3 o, V3 d, float &z, V3 &hp, V3 &hN, int &front,
+template <bool ANY, int MODEL>
+__device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN, int &front,
                          uint32_t *stack, Counters &cnt)
 {
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -201,7 +201,7 @@ __device__ bool mesh_hit(const DevMesh &M, int model, V3 o, V3 d, float &z, V3 &
             for (uint32_t i = 0; i < count; i++) {
                 const DevTri T = M.tris[first + i];
                 cnt.tris++;
-                const bool h = (model == RT_SHADE_P13) ? tri_hit_p13(T, o, d, z, hp, bc, front)
+                const bool h = (MODEL == RT_SHADE_P13) ? tri_hit_p13(T, o, d, z, hp, bc, front)
                                                        : tri_hit_fin(T, o, d, z, hp, bc, front);
                 if (h) { any = true; best_slot = first + i; }
             }
@@ -227,7 +227,7 @@ __device__ bool mesh_hit(const DevMesh &M, int model, V3 o, V3 d, float &z, V3 &
     // cyTriMesh::GetNormal = vn[fn0]*bc.x + vn[fn1]*bc.y + vn[fn2]*bc.z (cyTriMesh.h:167,191)
     const float *n9 = M.nrm + 9 * (size_t)M.tri_face[best_slot];
     const V3 Ni = ld3(n9) * bc.x + ld3(n9 + 3) * bc.y + ld3(n9 + 6) * bc.z;
-    hN = (model == RT_SHADE_P13) ? normalize(Ni) : Ni;     // FIN leaves it un-normalised (:262)
+    hN = (MODEL == RT_SHADE_P13) ? normalize(Ni) : Ni;     // FIN leaves it un-normalised (:262)
     return true;
 }
 
@@ -237,8 +237,8 @@ __device__ bool mesh_hit(const DevMesh &M, int model, V3 o, V3 d, float &z, V3 &
 // ancestor in turn (scene.h:502-508; direction NOT renormalised, so t is shared by all spaces),
 // and the closest hit is brought back through FromNodeCoords of each ancestor (scene.h:509-513).
 // ------------------------------------------------------------------------------------------------
-template <bool ANY>
-__device__ bool trace(const DevScene &S, int model, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt)
+template <bool ANY, int MODEL>
+__device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt)
 {
     float z = zinit;
     int best = -1, bfront = 1;
@@ -258,8 +258,8 @@ __device__ bool trace(const DevScene &S, int model, V3 o, V3 d, float zinit, Hit
         int fr = 1;
         bool hit = false;
         if (ob.type == RT_OBJ_SPHERE) hit = sphere_hit(lp, ldir, z, hp, hN, fr);
-        else if (ob.type == RT_OBJ_PLANE) hit = plane_hit(model, lp, ldir, z, hp, hN, fr);
-        else if (ob.type == RT_OBJ_MESH) hit = mesh_hit<ANY>(S.meshes[ob.mesh], model, lp, ldir, z, hp, hN, fr, stack, cnt);
+        else if (ob.type == RT_OBJ_PLANE) hit = plane_hit(MODEL, lp, ldir, z, hp, hN, fr);
+        else if (ob.type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes[ob.mesh], lp, ldir, z, hp, hN, fr, stack, cnt);
         if (hit) {
             if (ANY) return true;
             best = oi; bp = hp; bN = hN; bfront = fr;
@@ -318,6 +318,7 @@ __device__ __forceinline__ V3 light_direction(const rt_light &l, V3 p)
 // is exactly 0 or 1 and the refinement loop never runs, so ONE any-hit shadow query (GenLight::
 // Shadow, FIN/main.cpp:499-513: occluded iff 1e-14 < z < t_max) decides it.  size > 0 is rejected
 // by the host API for now (stochastic soft shadows: SURVEY 8(f3)).
+template <int MODEL>
 __device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &l, V3 p, uint32_t *stack, Counters &cnt)
 {
     const V3 I = ld3(l.intensity);
@@ -325,16 +326,16 @@ __device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &
     Hit dummy;
     if (l.type == RT_LIGHT_DIRECT) {
         cnt.shadow++;
-        const bool occ = trace<true>(S, P.shade_model, p, -ld3(l.direction), BIGFLOAT, dummy, stack, cnt);
+        const bool occ = trace<true, MODEL>(S, p, -ld3(l.direction), BIGFLOAT, dummy, stack, cnt);
         return I * (occ ? 0.0f : 1.0f);
     }
     const V3 position = ld3(l.position);
     cnt.shadow++;
-    const bool occ = trace<true>(S, P.shade_model, p, position - p, 1.0f, dummy, stack, cnt);
+    const bool occ = trace<true, MODEL>(S, p, position - p, 1.0f, dummy, stack, cnt);
     const int ns = P.shadow_samples > 0 ? P.shadow_samples : 4;
     float coefsum = 0.0f;
     for (int i = 0; i < ns; i++) coefsum += occ ? 0.0f : 1.0f;     // the ns identical samples
-    if (P.shade_model == RT_SHADE_P13)                              // intensity*coef/SAMPLES, then /dist^2
+    if (MODEL == RT_SHADE_P13)                                      // intensity*coef/SAMPLES, then /dist^2
         return ((I * coefsum) / (float)ns) / len2(p - position);
     const float shadow = coefsum / (float)ns;
     return (I * shadow) / len2(p - position);                       // lights.h:130
@@ -373,101 +374,191 @@ __device__ __forceinline__ void push_photon_query(const ShadeCtx &C, bool pred, 
     }
 }
 
-// One node of the ray tree: Trace + MtlBlinn::Shade (FIN/main.cpp:294-297, 516-708) with the
-// recursion unrolled into queue pushes.  Shade is linear in its children (color += K*child), so a
-// ray carries the product `thr` of the K factors above it and adds thr*local colour to its sample;
-// the child's own K = rK*Attenuation(parent absorption, child z) when the child hit is a back face
-// (:620,:632) is folded in here, where the child hit is known.
+// What one Shade() call produces besides its local colour: up to two child rays with their weights
+// and (FIN only) a photon-map query.
+struct ShadeOut {
+    V3 color;                        // local colour (emission + direct light), before the ray weight
+    bool want_refl, want_refr, want_photon;
+    V3 rdir, tdir;                   // child directions (reflection is normalised by the caller side)
+    V3 rK, tK;                       // child weights relative to this ray
+    V3 child_absorb;                 // what the children need to finish their own weight on arrival
+    V3 kd, N;                        // photon query: diffuse colour and shading normal
+};
+
+// MtlBlinn::Shade, FIN/main.cpp:516-708
+__device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, ShadeOut &o,
+                          uint32_t *stack, Counters &cnt)
+{
+    const rt_blinn &m = S.materials[S.node_material[h.node]];
+    V3 color = ld3(m.emission);                                         // :517
+    const V3 p = h.p;
+    const V3 N = normalize(h.N);                                        // :521-522
+    const V3 direction = normalize(-ray_d);                             // :523-524
+    const V3 kd = ld3(m.diffuse);
+    const V3 ks = ld3(m.specular);
+    const float gloss = m.glossiness;
+    const V3 reflection = ld3(m.reflection), refraction = ld3(m.refraction);
+    const float ior = m.ior;
+    const float coef = S.n_lights == 0 ? 1.0f : 1.0f / S.n_lights;      // :545
+    for (int li = 0; li < S.n_lights; li++) {
+        const rt_light &light = S.lights[li];
+        // the reference still calls Illuminate (its shadow rays) for a back-face hit but uses the
+        // result only for front hits (:551-553): nothing to add, nothing traced
+        if (!h.front) continue;
+        const V3 Il = illuminate<RT_SHADE_FIN>(S, P, light, p, stack, cnt);
+        if (light.type != RT_LIGHT_AMBIENT) {
+            const V3 intensity = Il * coef;                             // :551
+            V3 L = light_direction(light, p) * (float)(-1);             // :556
+            L = normalize(L);
+            const V3 H = normalize(L + direction);
+            const float cosNL = RMAX(0.f, dot(N, L));
+            const float cosNH = RMAX(0.f, dot(N, H));
+            const V3 diffuse = (kd * intensity) * cosNL;                // :563
+            const V3 specular = ((ks * intensity) * powf(cosNH, gloss)) * cosNL;   // :564 (std::pow(float,float))
+            color = color + (diffuse + specular);                       // :566
+        } else {
+            color = color + kd * Il;                                    // :568-569
+        }
+    }
+    // reflection / refraction set-up, :577-610
+    float ein = 1, eout = ior;
+    if (!h.front) { ein = ior; eout = 1; }
+    const float eta = ein / eout;
+    const float cosI = dot(N, direction);
+    const V3 Y = cosI > 0.f ? N : -N;
+    const V3 Z = cross(direction, Y);
+    const V3 X = normalize(cross(Y, Z));
+    // sqrtf(1 - cosI*cosI) is NaN in the reference when |cosI| exceeds 1 by rounding (:592);
+    // clamped at 0 here (documented deviation)
+    const float sinI = sqrtf(fmaxf(0.0f, 1 - cosI * cosI));
+    const float sinO = RMAX(0.f, RMIN(1.f, sinI * eta));
+    const float cosO = sqrtf(1.f - sinO * sinO);
+    o.tdir = normalize((-X) * sinO - Y * cosO);                         // :596, tRay.Normalize() :627
+    o.rdir = normalize((N * 2.f) * cosI - direction);                   // :597, r.Normalize() :615
+    const float C0 = (eta - 1.f) * (eta - 1.f) / ((eta + 1.f) * (eta + 1.f));
+    const float rC = C0 + (1.f - C0) * powf(1.f - fabsf(cosI), 5.f);    // :601
+    const float tC = 1.f - rC;
+    const bool totReflection = (eta * sinI) > 1.001f;                   // materials.h:20
+    o.tK = totReflection ? mk(0.f, 0.f, 0.f) : refraction * tC;
+    o.rK = totReflection ? (reflection + refraction) : (reflection + refraction * rC);
+    const float th = 0.001f;                                            // materials.h:21-22
+    o.want_refl = bounce > 0 && (o.rK.x > th || o.rK.y > th || o.rK.z > th);   // :613
+    o.want_refr = bounce > 0 && (o.tK.x > th || o.tK.y > th || o.tK.z > th);   // :625
+    // :642-693: at bounceCount == BOUNCE the hemisphere loop's result is assigned to a shadowing
+    // variable and contributes exactly 0 -- not traced.  :695-705: every other hit adds
+    // kd * irradiance * max(0, N.(-dir)); queued for k_gather.
+    o.want_photon = (bounce != P.bounce) && S.pm.n_leaves != 0;
+    o.color = color; o.kd = kd; o.N = N;
+    o.child_absorb = ld3(m.absorption);      // children: K *= Attenuation(absorption, z) on a back-face hit (:620,:632)
+}
+
+// MtlBlinn::Shade, P13/main.cpp:485-756 (reflectionGlossiness == refractionGlossiness == 0).
+// all = ambient + direct; all += re_color*reflection; all += refraction*(ra_ratio*absorb*ra_color +
+// re_ratio*re_color): the reflection child weighs reflection + refraction*re_ratio, the refraction
+// child refraction*ra_ratio*exp(-absorption.r * z_child) (z_child = BIGFLOAT on a miss).
+__device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, ShadeOut &o,
+                          uint32_t *stack, Counters &cnt)
+{
+    const rt_blinn &m = S.materials[S.node_material[h.node]];
+    V3 N = h.N;
+    const V3 Pp = h.p;
+    const V3 Kd = ld3(m.diffuse), Ks = ld3(m.specular);
+    const float alpha = m.glossiness;
+    V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
+    for (int i = 0; i < S.n_lights; i++) {
+        const rt_light &l = S.lights[i];
+        const V3 Il = illuminate<RT_SHADE_P13>(S, P, l, Pp, stack, cnt);
+        if (l.type == RT_LIGHT_AMBIENT) ambient = ambient + Il * Kd;                     // :510
+        else {
+            const V3 L = normalize(light_direction(l, Pp) * (float)-1);
+            const V3 V = normalize(-ray_d);
+            const V3 H = normalize(L + V);
+            const V3 kse = Ks * powf(dot(N, H), alpha) + Kd;                              // :547
+            const float theta = dot(N, L);
+            diffuse = diffuse + (Il * (theta > 0.0f ? theta : 0.0f)) * kse;               // :551
+        }
+    }
+    o.color = ambient + diffuse;                                                          // :622
+    V3 V = -normalize(ray_d);                                                             // :632
+    const float costheta = fminf(fmaxf(dot(N, V), -1.0f), 1.0f);                          // clamp :648
+    o.rdir = normalize(N * (2 * costheta) - V);                                           // :649, :652
+    // refraction block :671-751
+    V = normalize(V);
+    const float costheta1 = fabsf(dot(V, N));
+    const float sintheta1 = sqrtf(RMAX(0.0f, 1 - (costheta1 * costheta1)));
+    float n1 = 1.0f, n2 = 1.0f;
+    if (h.front) n2 = m.ior; else { n1 = m.ior; N = -N; }
+    const float ratio_n = n1 / n2;
+    const float sintheta2 = ratio_n * sintheta1;
+    float re_ratio = 0.0f, ra_ratio = 0.0f;
+    o.tdir = mk(0, 0, 1);
+    bool refr_ok = false;
+    if (sintheta2 <= 1.0f) {
+        const float costheta2 = sqrtf(RMAX(0.0f, 1 - (sintheta2 * sintheta2)));
+        V3 Sv = cross(N, cross(N, V));
+        N = normalize(N);
+        Sv = normalize(Sv);
+        o.tdir = (-N) * costheta2 + Sv * sintheta2;                                       // not normalised (:718-720)
+        float R0 = (n1 - n2) / (n1 + n2);
+        R0 = R0 * R0;
+        const double tmp = 1.0 - costheta1;
+        re_ratio = (float)(R0 + (1.0 - R0) * pow(tmp, 5.0));                              // :733 (double)
+        ra_ratio = (float)(1.0 - re_ratio);
+        refr_ok = true;
+    } else re_ratio = 1.0f;
+    const V3 reflection = ld3(m.reflection), refraction = ld3(m.refraction);
+    o.rK = reflection + refraction * re_ratio;
+    o.tK = refraction * ra_ratio;
+    o.want_refl = bounce > 0;
+    o.want_refr = bounce > 0 && refr_ok;
+    o.want_photon = false;
+    o.kd = Kd; o.N = h.N;
+    o.child_absorb = mk(m.absorption[0], 0, 0);          // refraction child: *= exp(-absorption.r * z) (:728)
+}
+
+// One node of the ray tree: Trace + MtlBlinn::Shade with the recursion unrolled into queue pushes.
+// Shade is linear in its children (color += K*child), so a ray carries the product `thr` of the K
+// factors above it and adds thr*local colour to its sample; the part of a child's K that depends on
+// the child's own hit (FIN: Attenuation(parent absorption, z) on a back-face hit, FIN/main.cpp:620,
+// 632; P13: exp(-absorption.r*z) on the refraction child, P13/main.cpp:728) is applied on arrival.
+template <int MODEL>
 __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uint32_t *stack, Counters &cnt)
 {
     const DevScene &S = C.S;
     const rt_params &P = C.P;
+    constexpr bool p13 = MODEL == RT_SHADE_P13;
     Hit h;
     bool hit = false;
-    if (active) hit = trace<false>(S, P.shade_model, in.o, in.d, BIGFLOAT, h, stack, cnt);
+    if (active) hit = trace<false, MODEL>(S, in.o, in.d, BIGFLOAT, h, stack, cnt);
     V3 thr = in.thr;
-    bool want_refl = false, want_refr = false, want_photon = false;
-    V3 rK = mk(0, 0, 0), tK = mk(0, 0, 0), rDir = mk(0, 0, 0), tDir = mk(0, 0, 0), kd = mk(0, 0, 0), N = mk(0, 0, 0), absorption = mk(0, 0, 0);
+    ShadeOut o;
+    o.want_refl = o.want_refr = o.want_photon = false;
+    o.rdir = o.tdir = mk(0, 0, 1); o.rK = o.tK = o.child_absorb = o.kd = o.N = mk(0, 0, 0);
+    if (active && !in.primary) {
+        if (p13) { if (in.kind == KIND_REFRACT) thr = thr * expf(-in.absorb.x * (hit ? h.z : BIGFLOAT)); }
+        else if (hit && !h.front) thr = thr * attenuation(in.absorb, h.z);
+    }
     if (active && !hit) {
         if (in.primary) C.W.sample_hit[in.slot] = 0;
-        else if (in.kind == KIND_REFRACT) add_sample(C, in.slot, thr * ld3(S.env), false);   // :635, SampleEnvironment without a texture
+        // a refraction ray that leaves the scene sees the environment (FIN/main.cpp:635); in P13 so
+        // does a reflection ray (P13/main.cpp:660-662)
+        else if (in.kind == KIND_REFRACT || p13) add_sample(C, in.slot, thr * ld3(S.env), false);
     }
     if (active && hit) {
         if (in.primary) { C.W.sample_hit[in.slot] = 1; C.W.sample_z[in.slot] = h.z; }
-        else if (!h.front) thr = thr * attenuation(in.absorb, h.z);
-        const rt_blinn &m = S.materials[S.node_material[h.node]];
-        V3 color = ld3(m.emission);                                         // :517
-        const V3 p = h.p;
-        N = normalize(h.N);                                                 // :521-522
-        const V3 direction = normalize(-in.d);                              // :523-524
-        kd = ld3(m.diffuse);
-        const V3 ks = ld3(m.specular);
-        const float gloss = m.glossiness;
-        const V3 reflection = ld3(m.reflection), refraction = ld3(m.refraction);
-        const float ior = m.ior;
-        absorption = ld3(m.absorption);
-        const float coef = S.n_lights == 0 ? 1.0f : 1.0f / S.n_lights;      // :545
-        for (int li = 0; li < S.n_lights; li++) {
-            const rt_light &light = S.lights[li];
-            if (!h.front) {
-                // the reference still calls Illuminate (its shadow rays) but uses the result only
-                // for front hits (:551-553); nothing to add for a back-face hit
-                continue;
-            }
-            const V3 Il = illuminate(S, P, light, p, stack, cnt);
-            if (light.type != RT_LIGHT_AMBIENT) {
-                const V3 intensity = Il * coef;                             // :551
-                V3 L = light_direction(light, p) * (float)(-1);             // :556
-                L = normalize(L);
-                const V3 H = normalize(L + direction);
-                const float cosNL = RMAX(0.f, dot(N, L));
-                const float cosNH = RMAX(0.f, dot(N, H));
-                const V3 diffuse = (kd * intensity) * cosNL;                // :563
-                const V3 specular = ((ks * intensity) * powf(cosNH, gloss)) * cosNL;   // :564 (std::pow(float,float))
-                color = color + (diffuse + specular);                       // :566
-            } else {
-                color = color + kd * Il;                                    // :568-569
-            }
-        }
-        // reflection / refraction set-up, :577-610
-        float ein = 1, eout = ior;
-        if (!h.front) { ein = ior; eout = 1; }
-        const float eta = ein / eout;
-        const float cosI = dot(N, direction);
-        const V3 Y = cosI > 0.f ? N : -N;
-        const V3 Z = cross(direction, Y);
-        const V3 X = normalize(cross(Y, Z));
-        // sqrtf(1 - cosI*cosI) is NaN in the reference when |cosI| exceeds 1 by rounding (:592);
-        // clamped at 0 here (documented deviation)
-        const float sinI = sqrtf(fmaxf(0.0f, 1 - cosI * cosI));
-        const float sinO = RMAX(0.f, RMIN(1.f, sinI * eta));
-        const float cosO = sqrtf(1.f - sinO * sinO);
-        tDir = (-X) * sinO - Y * cosO;                                      // :596
-        rDir = (N * 2.f) * cosI - direction;                                // :597
-        const float C0 = (eta - 1.f) * (eta - 1.f) / ((eta + 1.f) * (eta + 1.f));
-        const float rC = C0 + (1.f - C0) * powf(1.f - fabsf(cosI), 5.f);    // :601
-        const float tC = 1.f - rC;
-        const bool totReflection = (eta * sinI) > 1.001f;                   // materials.h:20
-        tK = totReflection ? mk(0.f, 0.f, 0.f) : refraction * tC;
-        rK = totReflection ? (reflection + refraction) : (reflection + refraction * rC);
-        const float th = 0.001f;                                            // materials.h:21-22
-        want_refl = in.bounce > 0 && (rK.x > th || rK.y > th || rK.z > th); // :613
-        want_refr = in.bounce > 0 && (tK.x > th || tK.y > th || tK.z > th); // :625
-        // :642-693: at bounceCount == BOUNCE the hemisphere loop's result is assigned to a shadowing
-        // variable and contributes exactly 0 -- not traced.  :695-705: every other hit adds
-        // kd * irradiance * max(0, N.(-dir)); queued for k_gather with weight thr*kd.
-        const V3 w = thr * kd;
-        want_photon = (in.bounce != P.bounce) && S.pm.n_leaves != 0 && (w.x != 0.f || w.y != 0.f || w.z != 0.f);
-        add_sample(C, in.slot, thr * color, in.primary);
-        // a child whose accumulated weight is exactly zero cannot change the pixel
-        const V3 wr = thr * rK, wt = thr * tK;
-        want_refl = want_refl && (wr.x != 0.f || wr.y != 0.f || wr.z != 0.f);
-        want_refr = want_refr && (wt.x != 0.f || wt.y != 0.f || wt.z != 0.f);
+        if (p13) shade_p13(S, P, h, in.d, in.bounce, o, stack, cnt);
+        else shade_fin(S, P, h, in.d, in.bounce, o, stack, cnt);
+        add_sample(C, in.slot, thr * o.color, in.primary);
+        // a child (or query) whose accumulated weight is exactly zero cannot change the pixel
+        const V3 wr = thr * o.rK, wt = thr * o.tK, wp = thr * o.kd;
+        o.want_refl = o.want_refl && (wr.x != 0.f || wr.y != 0.f || wr.z != 0.f);
+        o.want_refr = o.want_refr && (wt.x != 0.f || wt.y != 0.f || wt.z != 0.f);
+        o.want_photon = o.want_photon && (wp.x != 0.f || wp.y != 0.f || wp.z != 0.f);
     }
     // pushes are wave-collective: every lane of the wave reaches them
-    push_ray(C, want_refl, h.p, normalize(rDir), thr * rK, absorption, in.slot, in.bounce - 1, KIND_REFLECT);
-    push_ray(C, want_refr, h.p, normalize(tDir), thr * tK, absorption, in.slot, in.bounce - 1, KIND_REFRACT);
-    push_photon_query(C, want_photon, h.p, N, thr * kd, in.slot);
+    push_ray(C, o.want_refl, h.p, o.rdir, thr * o.rK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFLECT);
+    push_ray(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT);
+    push_photon_query(C, o.want_photon, h.p, o.N, thr * o.kd, in.slot);
 }
 
 __device__ __forceinline__ void flush_counters(unsigned long long *stats, const Counters &c, uint32_t nprim, uint32_t nrefl, uint32_t nrefr)
@@ -526,6 +617,7 @@ struct PrimaryArgs {
     const float *rays;           // mode 2
 };
 
+template <int MODEL>
 __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
@@ -565,12 +657,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
             }
         }
         if (active) nprim++;
-        shade_path(C, in, active, stack, cnt);
+        shade_path<MODEL>(C, in, active, stack, cnt);
     }
     flush_counters(C.W.stats, cnt, nprim, 0, 0);
 }
 
 // K2-K4 for one level of the ray tree: reads queue `qin` (count in counts[level]).
+template <int MODEL>
 __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin, int level)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
@@ -594,13 +687,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin
             in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu;
             if (in.kind == KIND_REFRACT) nrefr++; else nrefl++;
         }
-        shade_path(C, in, active, stack, cnt);
+        shade_path<MODEL>(C, in, active, stack, cnt);
     }
     flush_counters(C.W.stats, cnt, 0, nrefl, nrefr);
 }
 
 // K2 alone: n closest-hit queries (rt_trace_rays)
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, int model, const float *rays, long long n,
+template <int MODEL>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, const float *rays, long long n,
                                                     uint8_t *hit, float *z, float *p, float *N, int32_t *node, uint8_t *front)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
@@ -609,7 +703,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, int model, const
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         Hit h;
         h.z = BIGFLOAT; h.p = mk(0, 0, 0); h.N = mk(0, 0, 0); h.node = -1; h.front = 1;
-        const bool ok = trace<false>(S, model, ld3(rays + 6 * i), ld3(rays + 6 * i + 3), BIGFLOAT, h, stack, cnt);
+        const bool ok = trace<false, MODEL>(S, ld3(rays + 6 * i), ld3(rays + 6 * i + 3), BIGFLOAT, h, stack, cnt);
         hit[i] = ok ? 1 : 0;
         z[i] = ok ? h.z : BIGFLOAT;
         p[3 * i] = h.p.x; p[3 * i + 1] = h.p.y; p[3 * i + 2] = h.p.z;
@@ -1086,7 +1180,8 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
     PrimaryArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.j0 = j0; A.ns = ns;
     A.max_sample = max_sample; A.mode = mode; A.rays = rays;
     const int grid = grid_for((unsigned long long)npix * ns, RT_BLOCK, max_blocks);
-    hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
+    if (P.shade_model == RT_SHADE_P13) hipLaunchKernelGGL(k_primary<RT_SHADE_P13>, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
+    else hipLaunchKernelGGL(k_primary<RT_SHADE_FIN>, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
 }
 
 void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
@@ -1094,14 +1189,16 @@ void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, cons
                        int level, int max_blocks)
 {
     ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
-    hipLaunchKernelGGL(k_bounce, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
+    if (P.shade_model == RT_SHADE_P13) hipLaunchKernelGGL(k_bounce<RT_SHADE_P13>, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
+    else hipLaunchKernelGGL(k_bounce<RT_SHADE_FIN>, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
 }
 
 void rtk_launch_trace(hipStream_t st, const DevScene &S, int model, const float *rays, long long n,
                       uint8_t *hit, float *z, float *p, float *N, int32_t *node, uint8_t *front)
 {
     const int grid = grid_for((unsigned long long)n, RT_BLOCK, 4096);
-    hipLaunchKernelGGL(k_trace, dim3(grid), dim3(RT_BLOCK), 0, st, S, model, rays, n, hit, z, p, N, node, front);
+    if (model == RT_SHADE_P13) hipLaunchKernelGGL(k_trace<RT_SHADE_P13>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
+    else hipLaunchKernelGGL(k_trace<RT_SHADE_FIN>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
 }
 
 void rtk_launch_gather(hipStream_t st, const DevPhotonMap &pm, const float4 *qa, const float4 *qb,

@@ -174,6 +174,41 @@ def test_shade_rays_cornell(cornell):
         s.set_photons(None)
 
 
+def test_shade_rays_p13_model(cornell):
+    """P13/main.cpp:485-756 semantics: ungated reflection+refraction tree (BOUNCE 6), Schlick in
+    double, exp(-absorption.r * z) on the refraction child, environment on every miss"""
+    s, cam, e = cornell
+    s.set_environment((0.2, 0.3, 0.4), (0, 0, 0))
+    try:
+        osc = scenes.oracle_scene(s.export(), env=(0.2, 0.3, 0.4))
+        p = capi.default_params(shade_model=capi.SHADE_P13, bounce=6)
+        rng = np.random.default_rng(14)
+        tg = np.concatenate([rng.normal([8, -6, 4], 2.5, (900, 3)), rng.normal([-8, -6, 4], 2.5, (900, 3)),
+                             rng.normal([2, 5, 4], 4.0, (700, 3))])
+        o = np.array([0, -60, 12], np.float32)
+        d = tg - o
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([scenes.camera_rays(cam, 1500, seed=15),
+                               np.concatenate([np.tile(o, (len(d), 1)), d], 1).astype(np.float32)])
+        ohit, orgb, oz = orc.shade_rays(osc, scenes.oracle_params(p), rays)
+        hit, rgb, z = s.shade_rays(p, rays)
+        assert (hit == ohit).all() and z.tobytes() == oz.tobytes()
+        assert _close(rgb, orgb, rel=5e-5, abs_=2e-6).mean() > 0.999
+        assert np.abs(rgb - orgb).max() < 1e-3
+    finally:
+        s.set_environment((0, 0, 0), (0, 0, 0))
+
+
+def test_render_p13_frame(cornell):
+    s, cam0, e = cornell
+    s2, cam = scenes.load_cornell(96, 72)
+    p = capi.default_params(shade_model=capi.SHADE_P13, bounce=6, min_sample=4, max_sample=16)
+    rgb, z, cnt, st, _ = s2.render(cam, p)
+    orgb, oz, ocnt = orc.render(scenes.oracle_scene(e), scenes.oracle_camera(cam), scenes.oracle_params(p))
+    _frame_gate(rgb, orgb, z, oz, cnt, ocnt)
+    assert st.rays_reflect > 0 and st.rays_refract > 0 and st.photon_queries == 0
+
+
 def _frame_gate(rgb, orgb, z, oz, cnt, ocnt):
     diff = np.abs(rgb.astype(int) - orgb.astype(int)).max(axis=2)
     assert (diff <= 1).mean() >= 0.995, (diff > 1).sum()
