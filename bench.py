@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--photons", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--synthetic-photons", action="store_true", help="wall-sprinkled photons instead of the GPU photon pass")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -88,17 +89,31 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available() or capi.device_count() < 1:
         sys.exit("bench.py needs an MI355X (gfx950); the render path has no CPU fallback")
+    # rehearsal on a one-GPU box: RT_BENCH_REHEARSAL=1 puts every rank on device 0 and gathers over
+    # gloo (RCCL refuses two ranks on one device); never used for reported numbers
+    rehearsal = os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     # ---- synthetic inputs, resident in HBM before anything is timed -------------------------
     s, cam = scenes.load_cornell(a.width, a.height)
-    balanced = photons.synth_cornell_photon_map(a.photons, seed=20171203)
+    if a.synthetic_photons:
+        balanced = photons.synth_cornell_photon_map(a.photons, seed=20171203)
+    else:
+        # generatePhotonMap on the GPU (counter RNG, seed 20171203), balanced on the host like the
+        # reference does; identical on every rank
+        raw, attempts = s.photon_pass(a.photons, 8, seed=20171203, device=local)
+        balanced = capi.photon_balance(raw)
     s.set_photons(balanced)
     p = capi.default_params(min_sample=a.spp, max_sample=a.spp, threshold=-1.0)
-    R = ShardedRenderer(s, cam, p, rank, world, local)
+    R = ShardedRenderer(s, cam, p, rank, world, local, host_gather=rehearsal)
 
     def barrier():
         torch.cuda.synchronize()
@@ -122,7 +137,8 @@ def main():
     tot = {k: float(sum(x[k] for x in stats)) for k in keys}
     ms = {k: float(sum(x[k] for x in stats)) for k in ("ms_trace", "ms_gather", "ms_resolve", "ms_total")}
     launches_g = float(sum(x["launches_gather"] for x in stats))
-    vec = torch.tensor([dt] + [tot[k] for k in keys] + [ms["ms_gather"], ms["ms_trace"], launches_g], dtype=torch.float64, device="cuda")
+    vec = torch.tensor([dt] + [tot[k] for k in keys] + [ms["ms_gather"], ms["ms_trace"], launches_g], dtype=torch.float64,
+                       device="cpu" if rehearsal else "cuda")
     if world > 1:
         mx = vec.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -158,9 +174,11 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Cornell box, FIN shading, {a.width}x{a.height}, {a.spp} spp fixed, "
-                                   f"{a.photons}-photon map (synthetic), k=400 r=1, bounce 4",
+                                   f"{len(balanced) - 1}-photon map ({'sprinkled on the walls' if a.synthetic_photons else 'GPU photon pass, Philox seed 20171203, 8 bounces'}), "
+                                   f"k=400 r=1, bounce 4",
                        "tiles": "32x8 interleaved, tile t -> rank t mod N", "exchange": "one all_gather of 8 B/pixel per frame"},
             "frame_ms": round(dt / a.steps * 1e3, 2),
+            **({"rehearsal": "all ranks on device 0, gloo gather -- not a scaling measurement"} if rehearsal else {}),
             "rays_per_frame": {k: int(tot[k] / a.steps) for k in keys[:4]},
             "photon_queries_per_frame": int(tot["photon_queries"] / a.steps),
             "gather_per_frame": {k: int(tot[k] / a.steps) for k in ("photons_visited", "gather_rounds", "gather_slow", "gather_leaf_reads")},
@@ -168,6 +186,13 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(s.export(), balanced, cam, p, a.cpu_seconds)
+        if world > 1:
+            # the gathered frame must equal what the tiles say: spot-check against rank 0's own tiles
+            frgb, fz, fcnt = frame
+            own = R.rgb.cpu() if rehearsal else R.rgb
+            t = 0                                    # tile 0 belongs to rank 0
+            assert bool((frgb[:8, :32].cpu() == own[:8, :32].cpu()).all()), "gathered frame disagrees with rank 0's tile"
+            out["gathered_frame_nonzero_fraction"] = round(float((fz.float() != 0).float().mean()), 4)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

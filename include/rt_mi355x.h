@@ -227,6 +227,17 @@ rt_status rt_bvh_build(const float *v, int32_t nv, const uint32_t *f, int32_t nf
  * `in` is permuted in place exactly like the reference permutes its vector. */
 rt_status rt_photon_balance(rt_photon *in, uint32_t n, rt_photon *out);
 
+/* Photon pass on the GPU: generatePhotonMap up to and including ScalePhotonPowers
+ * (FIN/main.cpp:350-396; PhotonTracing :439-459; PointLight::RandomPhoton :489-497;
+ * MtlBlinn::RandomPhotonBounce FIN/include/materials.h:99-256).  rand() is replaced by a
+ * counter-based generator (Philox-4x32-10, key = seed, counter = emission attempt, draw), so the
+ * result depends only on (scene, seed).  Emission attempts are consumed in order until at least
+ * max_photons are stored (like the reference, the last attempt may overshoot by up to 7).
+ * out[0] is unused, out[1..*n_out] are the photons in the reference's 24-byte .dat format, powers
+ * already scaled by 4*pi/n; balance them with rt_photon_balance before rt_scene_set_photons. */
+rt_status rt_photon_pass(rt_scene *s, int device, uint32_t max_photons, int photon_bounce, uint32_t seed,
+                         rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out);
+
 /* ---- rendering: replaces BeginRender/StopRender + RenderPixel + RenderImage progress
  *      (FIN/main.cpp:202-344,984-1012; FIN/include/scene.h:586-589) ---------------------- */
 /* Asynchronous: returns after the job's worker thread has started.  Output buffers are

@@ -258,6 +258,15 @@ def estimate_irradiance(balanced, k, radius, pos, normal):
     return irr, d
 
 
+def photon_pass(scene, max_photons, max_bounce=8, seed=20171203):
+    out = np.zeros(int(max_photons) + 9, PHOTON)
+    att = C.c_uint64()
+    lib().orc_photon_pass.restype = C.c_uint32
+    n = lib().orc_photon_pass(C.byref(scene.c), C.c_uint32(int(seed)), C.c_uint32(int(max_photons)), int(max_bounce),
+                              _p(out), C.byref(att))
+    return out[: n + 1].copy(), att.value
+
+
 def bvh_build(v, f, max_per_leaf=4):
     v = _c(v, np.float32).reshape(-1, 3)
     f = _c(f, np.uint32).reshape(-1, 3)

@@ -1170,3 +1170,136 @@ void orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *P,
     }
     free(colorlist);
 }
+
+/* ---- photon pass ----------------------------------------------------------------------------- */
+/* The reference draws from libc rand(); this build replaces it by a counter-based generator
+ * (Philox-4x32-10, key = (seed, 'RTMI'), counter = (attempt lo, attempt hi, block, 0)), the same
+ * one the HIP photon kernel uses, so that both produce the same photons. */
+typedef struct { uint32_t key0, key1, c0, c1, blk, o[4]; int used; } philox_t;
+static void philox_refill(philox_t *g)
+{
+    uint32_t x0 = g->c0, x1 = g->c1, x2 = g->blk, x3 = 0, k0 = g->key0, k1 = g->key1;
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+        const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1, y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    g->o[0] = x0; g->o[1] = x1; g->o[2] = x2; g->o[3] = x3;
+    g->blk++; g->used = 0;
+}
+static float philox_next(philox_t *g)     /* stands in for rand() / (float) RAND_MAX */
+{
+    if (g->used >= 4) philox_refill(g);
+    return (float)(g->o[g->used++] >> 8) * (1.0f / 16777216.0f);
+}
+static float gray3(v3 c) { return (c.x + c.y + c.z) / 3.0f; }      /* Color::Gray, cyColor.h */
+
+/* MtlBlinn::RandomPhotonBounce, FIN/include/materials.h:99-256 (glossiness 0 branches).
+ * sqrtf(1-cosI^2) is clamped at 0 like in the Shade restatement. */
+static int random_photon_bounce(const rt_blinn *m, const orc_hit *h, float ray[6], v3 *c, philox_t *rng)
+{
+    const v3 V = vneg(v3p(ray + 3));
+    const v3 N = v3p(h->N);
+    const float NV = vdot(N, V);
+    const v3 Y = NV > 0.f ? N : vneg(N);
+    float ein = 1, eout = m->ior;
+    if (!h->front) { ein = m->ior; eout = 1; }
+    float eta = ein / eout;
+    const v3 Z = vcross(V, Y);
+    v3 X = vnorm(vcross(Y, Z));
+    float cosI = NV;
+    float sinI = sqrtf(fmaxf(0.0f, 1 - cosI * cosI));
+    float sinO = RMAX(0.f, RMIN(1.f, sinI * eta));
+    float cosO = sqrtf(1.f - sinO * sinO);
+    v3 tDir = vsub(vscale(vneg(X), sinO), vscale(Y, cosO));
+    v3 rDir = vsub(vscale(vscale(N, 2.f), NV), V);
+    const float C0 = (eta - 1.f) * (eta - 1.f) / ((eta + 1.f) * (eta + 1.f));
+    float rC = C0 + (1.f - C0) * powf(1.f - fabsf(cosI), 5.f);
+    const float tC = 1.f - rC;
+    const int tot = (eta * sinI) > 1.001f;
+    const v3 tK = v3p(m->refraction), rK = v3p(m->reflection);
+    const v3 sRefr = tot ? V3(0, 0, 0) : vscale(tK, tC);
+    const v3 sRefl = tot ? vadd(rK, tK) : vadd(rK, vscale(tK, rC));
+    const v3 sDiff = v3p(m->diffuse), sSpec = v3p(m->specular);
+    float random = philox_next(rng);
+    float diffuseProb = gray3(sDiff), refractionProb = gray3(sRefr), reflectionProb = gray3(sRefl), absorptionProb = gray3(v3p(m->absorption));
+    float total = diffuseProb + reflectionProb + refractionProb + absorptionProb;
+    diffuseProb /= total; refractionProb /= total; reflectionProb /= total;
+    const float rcp = 1.f / total;
+    const float select = random * total;
+    const float luma = 0.00001f;
+    int selected; float scale = 1.f;
+    if (select <= refractionProb && refractionProb > luma) { selected = 0; scale = refractionProb * rcp; }
+    else if (select > refractionProb && select <= refractionProb + reflectionProb && reflectionProb > luma) { selected = 1; scale = reflectionProb * rcp; }
+    else if (select > refractionProb + reflectionProb && select < refractionProb + reflectionProb + diffuseProb && diffuseProb > luma) { selected = 2; scale = diffuseProb * rcp; }
+    else selected = 3;
+    v3 dir, BxDF;
+    if (selected == 0) { dir = tDir; BxDF = sRefr; }
+    else if (selected == 1) { dir = rDir; BxDF = sRefl; }
+    else if (selected == 2) {
+        if (!h->front) return 0;
+        v3 Nt = vdot(N, V3(1, 0, 0)) < 0.4f ? vcross(N, V3(1, 0, 0)) : vcross(N, V3(0, 0, 1));   /* createCoordinateSystem :50-59 */
+        Nt = vnorm(Nt);
+        const v3 Nb = vcross(N, Nt);
+        float theta = (float)((double)philox_next(rng) * M_PI_2);
+        float phi = (float)((double)philox_next(rng) * (2.0 * M_PI));
+        dir = vadd(vadd(vscale(vscale(Nt, cosf(phi)), sinf(theta)), vscale(vscale(Nb, sinf(phi)), sinf(theta))), vscale(N, cosf(theta)));
+        const v3 L = vnorm(dir);
+        const v3 H = vnorm(vadd(V, L));
+        const float cosNH = RMAX(0.f, vdot(N, H));
+        BxDF = vadd(sDiff, vscale(sSpec, powf(cosNH, m->glossiness)));
+    } else return 0;
+    st3(ray, v3p(h->p)); st3(ray + 3, vnorm(dir));
+    *c = vdivs(vmul(*c, BxDF), 1.f * scale);
+    if (!h->front) *c = vmul(*c, attenuation(v3p(m->absorption), h->z));
+    return 1;
+}
+
+/* generatePhotonMap (FIN/main.cpp:350-396) + PhotonTracing (:439-459) + RandomPhoton (:489-497);
+ * out is 1-based; returns the number of photons (>= max_photons, overshoot <= 7). */
+uint32_t orc_photon_pass(const orc_scene *s, uint32_t seed, uint32_t max_photons, int max_bounce,
+                         rt_photon *out, uint64_t *attempts_out)
+{
+    int npl = 0;
+    for (int l = 0; l < s->n_lights; l++) if (s->lights[l].type == RT_LIGHT_POINT) npl++;
+    uint32_t n = 0;
+    uint64_t attempt = 0;
+    memset(&out[0], 0, sizeof(rt_photon));
+    for (; npl > 0 && n < max_photons; attempt++) {
+        philox_t rng;
+        rng.key0 = seed; rng.key1 = 0x52544D49u; rng.c0 = (uint32_t)attempt; rng.c1 = (uint32_t)(attempt >> 32); rng.blk = 0; rng.used = 4;
+        int pick = (int)(philox_next(&rng) * (float)npl);
+        if (pick >= npl) pick = npl - 1;
+        const rt_light *L = 0;
+        for (int l = 0; l < s->n_lights; l++) if (s->lights[l].type == RT_LIGHT_POINT) { if (pick == 0) { L = &s->lights[l]; break; } pick--; }
+        v3 c = v3p(L->intensity);
+        const v3 position = v3p(L->position);
+        const float x = 2 * philox_next(&rng) - 1, y = 2 * philox_next(&rng) - 1, z = 2 * philox_next(&rng) - 1;
+        float ray[6];
+        st3(ray, position);
+        st3(ray + 3, vnorm(vsub(vadd(V3(x, y, z), position), position)));     /* Direction(p+position) */
+        orc_hit h;
+        if (!orc_trace(s, RT_SHADE_FIN, ray, &h)) continue;
+        const rt_blinn *m = hit_material(s, &h);
+        if (!(gray3(v3p(m->diffuse)) > 0)) continue;                          /* IsPhotonSurface */
+        int bounce = max_bounce;
+        uint32_t stored = 0;
+        while (bounce > 0 && random_photon_bounce(m, &h, ray, &c, &rng)) {
+            orc_hit nh;
+            if (!orc_trace(s, RT_SHADE_FIN, ray, &nh)) break;
+            m = hit_material(s, &nh);
+            if (gray3(v3p(m->diffuse)) > 0 && stored < 8) {
+                float pw[3] = { c.x, c.y, c.z };
+                orc_photon_pack(nh.p, ray + 3, pw, &out[++n]);
+                stored++;
+            }
+            bounce--;
+            h = nh;
+        }
+    }
+    const float scale = (float)(1.0 * 4 * M_PI / n);
+    for (uint32_t i = 1; i <= n; i++) out[i].power *= scale;
+    if (attempts_out) *attempts_out = attempt;
+    return n;
+}

@@ -88,6 +88,11 @@ void  orc_estimate_irradiance(const rt_photon *photons, uint32_t n, int k, float
                               const float pos[3], const float normal[3],
                               float irr[3], float dir[3]);
 
+/* generatePhotonMap with the build's counter RNG (Philox); out is 1-based with room for
+ * max_photons + 9 records; returns the photon count */
+uint32_t orc_photon_pass(const orc_scene *s, uint32_t seed, uint32_t max_photons, int max_bounce,
+                         rt_photon *out, uint64_t *attempts_out);
+
 /* cyBVH build (MeanSplit), returns node count incl. unused node 0 */
 int   orc_bvh_build(const float *v, const uint32_t *f, int32_t nf, int32_t max_per_leaf,
                     rt_bvh_node *nodes_out, uint32_t *elements_out);

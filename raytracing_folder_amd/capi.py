@@ -69,7 +69,7 @@ SYMBOLS = [
     "rt_scene_set_materials", "rt_scene_set_lights", "rt_scene_set_environment",
     "rt_scene_set_photons", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
     "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
-    "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_render_begin",
+    "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photon_pass", "rt_render_begin",
     "rt_render_tiles_device", "rt_render_progress", "rt_render_stop", "rt_render_wait",
     "rt_job_stats", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
 ]
@@ -256,6 +256,14 @@ class Scene:
         hit, rgb, z = np.zeros(n, np.uint8), np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
         _check(lib().rt_shade_rays(self._h, C.byref(params), int(device), _p(rays), C.c_int64(n), _p(hit), _p(rgb), _p(z)))
         return hit, rgb, z
+
+    def photon_pass(self, max_photons, photon_bounce=8, seed=20171203, device=0):
+        """generatePhotonMap on the GPU: returns (unbalanced 1-based photon array, attempts)."""
+        out = np.zeros(int(max_photons) + 9, PHOTON)
+        n, att = C.c_uint32(), C.c_uint64()
+        _check(lib().rt_photon_pass(self._h, int(device), C.c_uint32(int(max_photons)), int(photon_bounce),
+                                    C.c_uint32(int(seed)), _p(out), C.c_uint32(len(out)), C.byref(n), C.byref(att)))
+        return out[: n.value + 1].copy(), att.value
 
     def render(self, cam, params, tiles=None, device=0):
         """Blocking render through the asynchronous job API (rt_render_begin + rt_render_wait)."""

@@ -32,6 +32,8 @@ void rtk_launch_resolve(hipStream_t, const DevWork &, const DevCamera &, const D
 
 #define GATHER_BLOCKS (256 * 4)
 
+void rtk_launch_photon_trace(hipStream_t, const DevScene &, unsigned long long, uint32_t, uint32_t, int, float *, uint32_t *);
+
 // ---- errors ---------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 static rt_status fail(rt_status st, const char *fmt, ...)
@@ -1036,5 +1038,66 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
     HIP_TRY(hipMemcpy(hs, W.stats, sizeof hs, hipMemcpyDeviceToHost));
     if (hs[ST_QUEUE_OVERFLOW]) return fail(RT_ERR_LIMIT, "rt_shade_rays: queue overflow");
     for (int64_t i = 0; i < n; i++) if (!hit[i]) z[i] = 1.0e30f;
+    return RT_OK;
+}
+
+// ---- photon pass ----------------------------------------------------------------------------------------
+// Photon::SetDirection / SetPower via AddPhoton (FIN/include/cyPhotonMap.h:139-156,184-192)
+static void pack_photon(const float *rec, rt_photon &o)
+{
+    memset(&o, 0, sizeof o);
+    memcpy(o.position, rec, 12);
+    o.dir_x = (int16_t)(rec[3] * 0x7FFF);
+    o.dir_y = (int16_t)(rec[4] * 0x7FFF);
+    o.plane_and_dirz = rec[5] > 0 ? 0 : 0x8;
+    float power = rec[6];
+    if (power < rec[7]) power = rec[7];
+    if (power < rec[8]) power = rec[8];
+    o.power = power;
+    for (int c = 0; c < 3; c++) {
+        const float s = (rec[6 + c] / power) * 255;
+        const int v = (s == s) ? (int)s : 0;
+        o.color[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+extern "C" rt_status rt_photon_pass(rt_scene *s, int device, uint32_t max_photons, int photon_bounce, uint32_t seed,
+                                    rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out)
+{
+    if (!s || !out || !n_out) return fail(RT_ERR_ARG, "rt_photon_pass: NULL argument");
+    if (max_photons == 0 || photon_bounce < 1 || photon_bounce > 8) return fail(RT_ERR_ARG, "rt_photon_pass: need max_photons > 0 and 1 <= photon_bounce <= 8");
+    if (out_cap < max_photons + 8 + 1) return fail(RT_ERR_ARG, "rt_photon_pass: out must hold max_photons + 9 records (index 0 unused, up to 7 photons of overshoot)");
+    DeviceState *D = nullptr;
+    rt_status st = prepare_device(s, device, &D);
+    if (st) return st;
+    bool have_source = false;
+    for (const rt_light &l : s->data.lights) if (l.type == RT_LIGHT_POINT) have_source = true;
+    if (!have_source) return fail(RT_ERR_STATE, "rt_photon_pass: the scene has no photon source (point light)");
+    const uint32_t batch = 1u << 18;
+    if ((st = D->t_out[0].ensure((size_t)batch * 8 * 9 * 4))) return st;
+    if ((st = D->t_out[1].ensure((size_t)batch * 4))) return st;
+    std::vector<float> recs((size_t)batch * 8 * 9);
+    std::vector<uint32_t> counts(batch);
+    uint32_t n = 0;
+    uint64_t attempts = 0;
+    memset(&out[0], 0, sizeof(rt_photon));
+    int empty_batches = 0;
+    while (n < max_photons) {
+        rtk_launch_photon_trace(D->stream, D->scene, attempts, batch, seed, photon_bounce, (float *)D->t_out[0].p, (uint32_t *)D->t_out[1].p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(D->stream));
+        HIP_TRY(hipMemcpy(recs.data(), D->t_out[0].p, recs.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(counts.data(), D->t_out[1].p, counts.size() * 4, hipMemcpyDeviceToHost));
+        const uint32_t before = n;
+        uint32_t a = 0;
+        for (; a < batch && n < max_photons; a++)          // the reference checks the count between attempts (:362)
+            for (uint32_t j = 0; j < counts[a]; j++) pack_photon(&recs[((size_t)a * 8 + j) * 9], out[++n]);
+        attempts += a;
+        if (n == before && ++empty_batches >= 4) return fail(RT_ERR_STATE, "rt_photon_pass: no photon is ever stored in this scene");
+    }
+    const float scale = (float)(1.0 * 4 * M_PI / n);       // ScalePhotonPowers(1.0*4*M_PI/NumPhotons), :396
+    for (uint32_t i = 1; i <= n; i++) out[i].power *= scale;
+    *n_out = n;
+    if (attempts_out) *attempts_out = attempts;
     return RT_OK;
 }

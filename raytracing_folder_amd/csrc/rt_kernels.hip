@@ -714,6 +714,166 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, const float *ray
 }
 
 // ------------------------------------------------------------------------------------------------
+// Photon pass: generatePhotonMap / PhotonTracing (FIN/main.cpp:350-459),
+// PointLight::RandomPhoton (:489-497) and MtlBlinn::RandomPhotonBounce (FIN/include/materials.h:
+// 99-256), one thread per emission attempt.  The reference draws from libc rand(); here every draw
+// is Philox-4x32-10 keyed by the seed and counted by (attempt index, draw index), so the photon set
+// is a pure function of (scene, seed) whatever the scheduling -- and the CPU oracle, using the same
+// generator, reproduces it photon for photon (up to libm rounding).
+// ------------------------------------------------------------------------------------------------
+struct Philox {
+    uint32_t key0, key1, c0, c1, blk; uint32_t o0, o1, o2, o3; int used;
+    __host__ __device__ void refill()
+    {
+        uint32_t x0 = c0, x1 = c1, x2 = blk, x3 = 0, k0 = key0, k1 = key1;
+        for (int r = 0; r < 10; r++) {
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * x0, p1 = (unsigned long long)0xCD9E8D57u * x2;
+            const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1, y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        o0 = x0; o1 = x1; o2 = x2; o3 = x3;
+        blk++; used = 0;
+    }
+    // uniform in [0,1): stands in for rand() / (float) RAND_MAX
+    __host__ __device__ float next()
+    {
+        if (used >= 4) refill();
+        const uint32_t v = used == 0 ? o0 : (used == 1 ? o1 : (used == 2 ? o2 : o3));
+        used++;
+        return (float)(v >> 8) * (1.0f / 16777216.0f);
+    }
+};
+
+struct PhotonArgs {
+    unsigned long long first_attempt; uint32_t n_attempts;
+    uint32_t seed; int max_bounce;
+    float *out;            // [n_attempts][RT_PHOTON_SLOTS][9]: pos, dir, power
+    uint32_t *count;       // [n_attempts]
+};
+
+__device__ __forceinline__ float gray(V3 c) { return (c.x + c.y + c.z) / 3.0f; }
+
+// MtlBlinn::RandomPhotonBounce, FIN/include/materials.h:99-256 (glossiness 0 branches)
+__device__ bool random_photon_bounce(const rt_blinn &m, const Hit &h, V3 &rp, V3 &rd, V3 &c, Philox &rng)
+{
+    const V3 V = -rd;
+    const V3 N = h.N;
+    const float NV = dot(N, V);
+    const V3 Y = NV > 0.f ? N : -N;
+    float ein = 1, eout = m.ior;
+    if (!h.front) { ein = m.ior; eout = 1; }
+    const float eta = ein / eout;
+    const V3 Z = cross(V, Y);
+    const V3 X = normalize(cross(Y, Z));
+    const float cosI = NV;
+    const float sinI = sqrtf(fmaxf(0.0f, 1 - cosI * cosI));
+    const float sinO = RMAX(0.f, RMIN(1.f, sinI * eta));
+    const float cosO = sqrtf(1.f - sinO * sinO);
+    const V3 tDir = (-X) * sinO - Y * cosO;
+    const V3 rDir = (N * 2.f) * NV - V;
+    const float C0 = (eta - 1.f) * (eta - 1.f) / ((eta + 1.f) * (eta + 1.f));
+    const float rC = C0 + (1.f - C0) * powf(1.f - fabsf(cosI), 5.f);
+    const float tC = 1.f - rC;
+    const bool tot = (eta * sinI) > 1.001f;
+    const V3 tK = ld3(m.refraction), rK = ld3(m.reflection);
+    const V3 sRefr = tot ? mk(0, 0, 0) : tK * tC;
+    const V3 sRefl = tot ? (rK + tK) : (rK + tK * rC);
+    const V3 sDiff = ld3(m.diffuse), sSpec = ld3(m.specular);
+    const float random = rng.next();                                    // :150
+    float diffuseProb = gray(sDiff), refractionProb = gray(sRefr), reflectionProb = gray(sRefl), absorptionProb = gray(ld3(m.absorption));
+    const float total = diffuseProb + reflectionProb + refractionProb + absorptionProb;
+    diffuseProb /= total; refractionProb /= total; reflectionProb /= total;
+    const float rcp = 1.f / total;
+    const float select = random * total;                                // :163 (compared with the NORMALISED probabilities)
+    const float luma = 0.00001f;
+    int selected; float scale = 1.f;
+    if (select <= refractionProb && refractionProb > luma) { selected = 0; scale = refractionProb * rcp; }
+    else if (select > refractionProb && select <= refractionProb + reflectionProb && reflectionProb > luma) { selected = 1; scale = reflectionProb * rcp; }
+    else if (select > refractionProb + reflectionProb && select < refractionProb + reflectionProb + diffuseProb && diffuseProb > luma) { selected = 2; scale = diffuseProb * rcp; }
+    else selected = 3;
+    V3 dir, BxDF;
+    if (selected == 0) { dir = tDir; BxDF = sRefr; }
+    else if (selected == 1) { dir = rDir; BxDF = sRefl; }
+    else if (selected == 2) {
+        if (!h.front) return false;
+        // createCoordinateSystem, materials.h:50-59
+        V3 Nt = dot(N, mk(1, 0, 0)) < 0.4f ? cross(N, mk(1, 0, 0)) : cross(N, mk(0, 0, 1));
+        Nt = normalize(Nt);
+        const V3 Nb = cross(N, Nt);
+        const float theta = (float)((double)rng.next() * M_PI_2);       // :227
+        const float phi = (float)((double)rng.next() * (2.0 * M_PI));   // :228
+        dir = (Nt * cosf(phi)) * sinf(theta) + (Nb * sinf(phi)) * sinf(theta) + N * cosf(theta);
+        const V3 L = normalize(dir);
+        const V3 H = normalize(V + L);
+        const float cosNH = RMAX(0.f, dot(N, H));
+        BxDF = sDiff + sSpec * powf(cosNH, m.glossiness);
+    } else return false;
+    rp = h.p; rd = normalize(dir);
+    c = (c * BxDF) / (1.f * scale);                                     // c * BxDF / (PDF * scale)
+    if (!h.front) c = c * attenuation(ld3(m.absorption), h.z);
+    return true;
+}
+
+#define RT_PHOTON_SLOTS 8
+__global__ __launch_bounds__(RT_BLOCK) void k_photon_trace(DevScene S, PhotonArgs A)
+{
+    __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
+    uint32_t *stack = s_stack + threadIdx.x;
+    Counters cnt = {0, 0, 0, 0};
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n_attempts) return;
+    const unsigned long long attempt = A.first_attempt + i;
+    Philox rng;
+    rng.key0 = A.seed; rng.key1 = 0x52544D49u; rng.c0 = (uint32_t)attempt; rng.c1 = (uint32_t)(attempt >> 32); rng.blk = 0; rng.used = 4;
+    // choose one photon source uniformly (the reference hard-codes two lights, :367-370)
+    int npl = 0;
+    for (int l = 0; l < S.n_lights; l++) if (S.lights[l].type == RT_LIGHT_POINT) npl++;
+    uint32_t stored = 0;
+    float *out = A.out + (size_t)i * RT_PHOTON_SLOTS * 9;
+    if (npl > 0) {
+        int pick = (int)(rng.next() * (float)npl);
+        if (pick >= npl) pick = npl - 1;
+        int li = 0;
+        for (int l = 0; l < S.n_lights; l++) if (S.lights[l].type == RT_LIGHT_POINT) { if (pick == 0) { li = l; break; } pick--; }
+        const rt_light &L = S.lights[li];
+        V3 c = ld3(L.intensity);
+        const V3 position = ld3(L.position);
+        // PointLight::RandomPhoton, :489-497
+        const float x = 2 * rng.next() - 1, y = 2 * rng.next() - 1, z = 2 * rng.next() - 1;
+        V3 rp = position;
+        V3 rd = normalize((mk(x, y, z) + position) - position);
+        Hit h;
+        if (trace<false, RT_SHADE_FIN>(S, rp, rd, BIGFLOAT, h, stack, cnt)) {
+            const rt_blinn *m = &S.materials[S.node_material[h.node]];
+            if (gray(ld3(m->diffuse)) > 0) {                             // IsPhotonSurface, materials.h:97
+                int bounce = A.max_bounce;
+                while (bounce > 0 && random_photon_bounce(*m, h, rp, rd, c, rng)) {      // PhotonTracing :439-459
+                    Hit nh;
+                    if (!trace<false, RT_SHADE_FIN>(S, rp, rd, BIGFLOAT, nh, stack, cnt)) break;
+                    m = &S.materials[S.node_material[nh.node]];
+                    if (gray(ld3(m->diffuse)) > 0 && stored < RT_PHOTON_SLOTS) {
+                        float *o = out + 9 * stored;
+                        o[0] = nh.p.x; o[1] = nh.p.y; o[2] = nh.p.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z; o[6] = c.x; o[7] = c.y; o[8] = c.z;
+                        stored++;
+                    }
+                    bounce--;
+                    h = nh;
+                }
+            }
+        }
+    }
+    A.count[i] = stored;
+}
+
+void rtk_launch_photon_trace(hipStream_t st, const DevScene &S, unsigned long long first_attempt, uint32_t n_attempts,
+                             uint32_t seed, int max_bounce, float *out, uint32_t *count)
+{
+    PhotonArgs A; A.first_attempt = first_attempt; A.n_attempts = n_attempts; A.seed = seed; A.max_bounce = max_bounce; A.out = out; A.count = count;
+    hipLaunchKernelGGL(k_photon_trace, dim3((n_attempts + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K5: PhotonMap::EstimateIrradiance<k>(irr, dir, radius, pos, &N, 1, CONSTANT)
 // (FIN/include/cyPhotonMap.h:288-336, LocatePhotons :365-440).
 //

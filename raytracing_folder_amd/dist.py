@@ -79,8 +79,9 @@ def gather_frame(rgb, z, cnt, rank, world, tile_w=32, tile_h=8):
 class ShardedRenderer:
     """One process per GPU: renders this rank's tiles into device tensors and gathers the frame."""
 
-    def __init__(self, scene, cam, params, rank, world, device_index, tile_w=32, tile_h=8):
+    def __init__(self, scene, cam, params, rank, world, device_index, tile_w=32, tile_h=8, host_gather=False):
         self.scene, self.cam, self.params = scene, cam, params
+        self.host_gather = host_gather          # gather over CPU tensors (gloo rehearsal on one GPU)
         self.rank, self.world, self.device_index = rank, world, device_index
         self.tile_w, self.tile_h = tile_w, tile_h
         dev = torch.device("cuda", device_index)
@@ -98,5 +99,8 @@ class ShardedRenderer:
 
     def step(self):
         st = self.render_own_tiles()
-        frame = gather_frame(self.rgb, self.z, self.cnt, self.rank, self.world, self.tile_w, self.tile_h)
+        if self.host_gather:
+            frame = gather_frame(self.rgb.cpu(), self.z.cpu(), self.cnt.cpu(), self.rank, self.world, self.tile_w, self.tile_h)
+        else:
+            frame = gather_frame(self.rgb, self.z, self.cnt, self.rank, self.world, self.tile_w, self.tile_h)
         return st, frame
