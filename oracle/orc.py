@@ -212,6 +212,7 @@ def shade_rays(scene, params, rays):
     z = np.full(n, 1.0e30, np.float32)
     h = np.zeros(1, HIT)
     for i in range(n):
+        lib().orc_set_rng(C.c_uint32(params.seed), C.c_uint32(i), C.c_uint32(1))      # sample id = ray index
         if lib().orc_trace(C.byref(scene.c), params.shade_model, _p(rays[i]), _p(h)):
             hit[i] = 1
             z[i] = h["z"][0]

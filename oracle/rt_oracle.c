@@ -27,6 +27,36 @@ static orc_counters g_cnt;
 void orc_counters_reset(void) { memset(&g_cnt, 0, sizeof g_cnt); }
 void orc_counters_get(orc_counters *out) { *out = g_cnt; }
 
+/* ---- counter RNG for the stochastic effects (replaces libc rand(); same generator and same
+ * (sample, node, purpose, index) addressing as the HIP kernels, see rt_kernels.hip) ------------ */
+static void philox4x32(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t out[4])
+{
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+        const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1, y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
+}
+#define RNG_LENS 1u
+#define RNG_PICK 2u
+#define RNG_SHADOW 3u
+#define RNG_GLOSSR 4u
+#define RNG_GLOSST 5u
+#define RNG_GI 6u
+static struct { uint32_t seed, sample, node; } g_rng = { 0, 0, 1 };
+void orc_set_rng(uint32_t seed, uint32_t sample, uint32_t node) { g_rng.seed = seed; g_rng.sample = sample; g_rng.node = node; }
+static void rng2_at(uint32_t seed, uint32_t sample, uint32_t node, uint32_t purpose, uint32_t index, float *u0, float *u1)
+{
+    uint32_t o[4];
+    philox4x32(seed, 0x52544D49u, sample, node, (purpose << 24) | (index & 0xFFFFFFu), 0x5eed5eedu, o);
+    *u0 = (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+    *u1 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+}
+static void rng2(uint32_t purpose, uint32_t index, float *u0, float *u1) { rng2_at(g_rng.seed, g_rng.sample, g_rng.node, purpose, index, u0, u1); }
+static uint32_t child_node(uint32_t node, uint32_t kind) { return node * 0x9E3779B1u + kind * 0x85EBCA6Bu + 0x27D4EB2Fu; }
+
 /* ---- cyPoint3f subset (FIN/include/cyPoint.h:259-350) ---------------------------------- */
 typedef struct { float x, y, z; } v3;
 static v3 V3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -412,14 +442,17 @@ void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
     v3 position = v3p(l->position);
     float size = l->size;
     int ns = P->shadow_samples > 0 ? P->shadow_samples : 4;
+    const uint32_t li = (uint32_t)(l - s->lights);
     float shadow = 0.0f;
+    float u0, u1;
     if (model == RT_SHADE_P13) {
         float shadow_coef = 0.0f;
         for (int i = 0; i < ns; i++) {
+            rng2(RNG_SHADOW, li * 64 + (uint32_t)i, &u0, &u1);
             float r = orc_halton(i, 2);
             r = sqrtf(r) * size;
-            float theta = (float)(M_PI * 2.0 * rand() / (float)RAND_MAX);
-            float gam = (float)(M_PI * rand() / (float)RAND_MAX);
+            float theta = (float)(M_PI * 2.0 * (double)u0);            /* M_PI*2.0*rand()/(float)RAND_MAX */
+            float gam = (float)(M_PI * (double)u1);
             float dx = r * sinf(gam) * cosf(theta);
             float dy = r * sinf(gam) * sinf(theta);
             float dz = r * cosf(gam);
@@ -441,12 +474,11 @@ void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
     v2 = vnorm(v2);
     v1 = vnorm(v1);
     for (int i = 0; i < ns; i++) {
-        float random = rand() / (float)RAND_MAX;
-        float rRadius = sqrtf(random) * size;
-        random = rand() / (float)RAND_MAX;
-        float rAngle = (float)(random * (2.0 * M_PI));
-        float xv = (float)(rRadius * cos(rAngle));
-        float yv = (float)(rRadius * sin(rAngle));
+        rng2(RNG_SHADOW, li * 64 + (uint32_t)i, &u0, &u1);
+        float rRadius = sqrtf(u0) * size;
+        float rAngle = (float)((double)u1 * (2.0 * M_PI));
+        float xv = rRadius * cosf(rAngle);                             /* cos(float) -> float overload */
+        float yv = rRadius * sinf(rAngle);
         v3 xv1 = vscale(v1, xv), yv2 = vscale(v2, yv);
         /* (position + xv1.Length() + yv2.Length()) - p : scalars added to all 3 coords */
         float lx = vlen(xv1), ly = vlen(yv2);
@@ -460,12 +492,11 @@ void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
         const int nmax = 16;                               /* MAX_SHADOW_SAMPLES */
         shadow = 0.0f;
         for (int i = 0; i < nmax; i++) {
-            float random = rand() / (float)RAND_MAX;
-            float rRadius = sqrtf(random) * size;
-            random = rand() / (float)RAND_MAX;
-            float rAngle = (float)(random * (2.0 * M_PI));
-            float xv = (float)(rRadius * cos(rAngle));
-            float yv = (float)(rRadius * sin(rAngle));
+            rng2(RNG_SHADOW, li * 64 + 32 + (uint32_t)i, &u0, &u1);
+            float rRadius = sqrtf(u0) * size;
+            float rAngle = (float)((double)u1 * (2.0 * M_PI));
+            float xv = rRadius * cosf(rAngle);
+            float yv = rRadius * sinf(rAngle);
             v3 xv1 = vscale(v1, -xv), yv2 = vscale(v2, -yv);
             float lx = vlen(xv1), ly = vlen(yv2);
             v3 sd = vsub(V3(position.x + lx + ly, position.y + lx + ly, position.z + lx + ly), p);
@@ -569,7 +600,10 @@ static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6]
         if (orc_trace(s, P->shade_model, r, &hh)) {
             v3 K = vmul(rK, hh.front ? V3(1.f, 1.f, 1.f) : attenuation(absorption, hh.z));
             float c[3];
+            const uint32_t me = g_rng.node;
+            g_rng.node = child_node(me, 1u);
             shade_fin(s, P, r, &hh, bounceCount - 1, c);
+            g_rng.node = me;
             color = vadd(color, vmul(K, v3p(c)));
         }
     }
@@ -581,7 +615,10 @@ static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6]
         if (orc_trace(s, P->shade_model, r, &hh)) {
             v3 K = vmul(tK, hh.front ? V3(1.f, 1.f, 1.f) : attenuation(absorption, hh.z));
             float c[3];
+            const uint32_t me = g_rng.node;
+            g_rng.node = child_node(me, 2u);
             shade_fin(s, P, r, &hh, bounceCount - 1, c);
+            g_rng.node = me;
             color = vadd(color, vmul(K, v3p(c)));
         } else {
             color = vadd(color, vmul(tK, v3p(s->env)));                    /* SampleEnvironment, no texture */
@@ -637,7 +674,20 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
     }
     v3 all = vadd(ambient_color, diffuse_color);                                      /* :622 (idr, cau = 0) */
     v3 V = vneg(vnorm(v3p(ray + 3)));                                                 /* :632 */
+    const uint32_t me = g_rng.node;
     if (bounceCount > 0) {                                                            /* :633-663 */
+        v3 newN = N;
+        if (m->reflection_glossiness) {                                               /* :635-647 */
+            v3 newx = vcross(newN, V3(1, 0, 0));
+            v3 newy = vcross(newN, newx);
+            float u0, u1;
+            rng2(RNG_GLOSSR, 0, &u0, &u1);
+            float r = sqrtf(u0) * m->reflection_glossiness;
+            float theta = (float)(M_PI * 2.0 * (double)u1);
+            float dx = r * cosf(theta), dy = r * sinf(theta);
+            newN = vnorm(vadd(newN, vadd(vscale(newx, dx), vscale(newy, dy))));
+        }
+        N = newN;
         float costheta = clampf(vdot(N, V), -1.0f, 1.0f);
         v3 R = vsub(vscale(N, 2 * costheta), V);
         float r[6];
@@ -646,13 +696,25 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
         g_cnt.rays_reflect++;
         if (orc_trace(s, P->shade_model, r, &hh)) {
             float c[3];
+            g_rng.node = child_node(me, 1u);
             shade_p13(s, P, r, &hh, bounceCount - 1, c);
+            g_rng.node = me;
             re_color = v3p(c);
         } else re_color = v3p(s->env);
     }
     all = vadd(all, vmul(re_color, v3p(m->reflection)));                              /* :665 */
     if (bounceCount > 0) {                                                            /* :671-751 */
         N = v3p(hInfo->N);
+        if (m->refraction_glossiness) {                                               /* :673-686 */
+            v3 newx = vcross(N, V3(1, 0, 0));
+            v3 newy = vcross(N, newx);
+            float u0, u1;
+            rng2(RNG_GLOSST, 0, &u0, &u1);
+            float r = sqrtf(u0) * m->refraction_glossiness;
+            float theta = (float)(M_PI * 2.0 * (double)u1);
+            float dx = r * cosf(theta), dy = r * sinf(theta);
+            N = vnorm(vadd(N, vadd(vscale(newx, dx), vscale(newy, dy))));
+        }
         float R0 = 0.0f, re_ratio = 0.0f, ra_ratio = 0.0f;
         V = vnorm(V);
         float costheta1 = fabsf(vdot(V, N));
@@ -676,7 +738,9 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
             g_cnt.rays_refract++;
             if (orc_trace(s, P->shade_model, r, &hh)) {
                 float c[3];
+                g_rng.node = child_node(me, 2u);
                 shade_p13(s, P, r, &hh, bounceCount - 1, c);
+                g_rng.node = me;
                 ra_color = v3p(c);
             } else ra_color = v3p(s->env);
             absorb = expf(-m->absorption[0] * hh.z);                                  /* :728 */
@@ -1049,8 +1113,9 @@ static void camera_setup(const rt_camera *cam, cam_setup *cs)
     cs->m[6] = z_new.x; cs->m[7] = z_new.y; cs->m[8] = z_new.z;
 }
 
-/* generateSample (FIN/main.cpp:147-162) + ray build (:288-292), dof == 0 */
-static void primary_ray(const rt_camera *cam, const cam_setup *cs, int x, int y, int j, float ray[6])
+/* generateSample (FIN/main.cpp:147-162) + ray build (:288-292); with camera.dof != 0 the per-pixel
+ * lens table (:246-262) and the per-sample pick (:284) draw from the counter RNG */
+static void primary_ray_ms(const rt_camera *cam, const cam_setup *cs, int x, int y, int j, int max_sample, uint32_t seed, float ray[6])
 {
     v3 tmp = vadd(V3(x * cs->u, y * cs->v, 0), cs->b);                 /* :235-236 */
     float sx = orc_halton(j, 2) * cs->u;
@@ -1058,11 +1123,29 @@ static void primary_ray(const rt_camera *cam, const cam_setup *cs, int x, int y,
     sx += tmp.x; sy += tmp.y;
     v3 sample = V3(sx, sy, tmp.z);
     v3 d_campos = V3(0, 0, 0);
+    if (cam->dof != 0) {
+        const uint32_t pixel_id = (uint32_t)y * (uint32_t)cam->width + (uint32_t)x;
+        const uint32_t sample_id = pixel_id * (uint32_t)max_sample + (uint32_t)j;
+        float u0, u1;
+        rng2_at(seed, sample_id, 0, RNG_PICK, 0, &u0, &u1);
+        int pick = (int)(u0 * 64.0f);
+        if (pick > 63) pick = 63;
+        rng2_at(seed, pixel_id, 0, RNG_LENS, (uint32_t)(pick + 1), &u0, &u1);
+        float r = orc_halton(pick + 1, 2);
+        r = sqrtf(r) * cam->dof;
+        float theta = (float)(M_PI * 2.0 * (double)u0);
+        d_campos = mmul(cs->m, V3(r * cosf(theta), r * sinf(theta), 0));
+    }
     v3 o = vadd(v3p(cam->pos), d_campos);
     v3 dir = mmul(cs->m, sample);
     dir = vsub(dir, d_campos);
     dir = vnorm(dir);
     st3(ray, o); st3(ray + 3, dir);
+}
+
+static void primary_ray(const rt_camera *cam, const cam_setup *cs, int x, int y, int j, float ray[6])
+{
+    primary_ray_ms(cam, cs, x, y, j, 1, 0, ray);          /* dof == 0 callers */
 }
 
 void orc_primary_ray(const rt_camera *cam, int x, int y, int j, float ray[6])
@@ -1100,7 +1183,8 @@ int orc_pixel_samples(const orc_scene *s, const rt_camera *cam, const rt_params 
     int nh = 0;
     for (int j = j0; j < j1; j++) {
         float ray[6];
-        primary_ray(cam, &cs, x, y, j, ray);
+        primary_ray_ms(cam, &cs, x, y, j, P->max_sample, P->seed, ray);
+        orc_set_rng(P->seed, ((uint32_t)y * (uint32_t)cam->width + (uint32_t)x) * (uint32_t)P->max_sample + (uint32_t)j, 1);
         orc_hit h;
         g_cnt.rays_primary++;
         hitmask[j - j0] = 0;
@@ -1134,7 +1218,8 @@ void orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *P,
         while (s_start == 0 || (variant_over_threshold(colorlist, ncol, P->threshold) && s_start != P->max_sample)) {
             for (int k = s_start; k < s_end; k++) {
                 float ray[6];
-                primary_ray(cam, &cs, x, y, k, ray);
+                primary_ray_ms(cam, &cs, x, y, k, P->max_sample, P->seed, ray);
+                orc_set_rng(P->seed, ((uint32_t)y * (uint32_t)cam->width + (uint32_t)x) * (uint32_t)P->max_sample + (uint32_t)k, 1);
                 orc_hit h;
                 g_cnt.rays_primary++;
                 if (orc_trace(s, P->shade_model, ray, &h)) {

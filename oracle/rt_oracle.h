@@ -59,6 +59,8 @@ typedef struct orc_counters {
 void  orc_counters_reset(void);
 void  orc_counters_get(orc_counters *out);
 
+/* context of the counter RNG: which sample / ray-tree node the next Shade call belongs to */
+void  orc_set_rng(uint32_t seed, uint32_t sample, uint32_t node);
 float orc_halton(int index, int base);
 void  orc_color24(const float rgb[3], uint8_t out[3]);
 

@@ -695,25 +695,21 @@ static void camera_setup(const rt_camera &cam, DevCamera &dc)
     dc.m[3] = up.x; dc.m[4] = up.y; dc.m[5] = up.z;
     dc.m[6] = z_new.x; dc.m[7] = z_new.y; dc.m[8] = z_new.z;
     dc.b[0] = b.x; dc.b[1] = b.y; dc.b[2] = b.z;
-    dc.u = u; dc.v = v; dc.width = cam.width; dc.height = cam.height;
+    dc.u = u; dc.v = v; dc.dof = cam.dof; dc.width = cam.width; dc.height = cam.height;
 }
 
 static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *t)
 {
     if (!cam || !p || !t) return fail(RT_ERR_ARG, "render: camera, params and tile range are required");
     if (cam->width <= 0 || cam->height <= 0 || (long long)cam->width * cam->height > (1LL << 28)) return fail(RT_ERR_ARG, "render: bad image size %dx%d", cam->width, cam->height);
-    if (cam->dof != 0) return fail(RT_ERR_LIMIT, "render: depth of field (camera.dof != 0) is not implemented on the device yet");
+    if ((unsigned long long)cam->width * cam->height * (unsigned long long)p->max_sample >= (1ull << 32))
+        return fail(RT_ERR_LIMIT, "render: width*height*max_sample must stay below 2^32 (sample ids are 32-bit)");
     if (p->min_sample < 1 || p->max_sample < p->min_sample || p->max_sample > 4096) return fail(RT_ERR_ARG, "render: need 1 <= min_sample <= max_sample <= 4096");
     if (p->shade_model != RT_SHADE_FIN && p->shade_model != RT_SHADE_P13) return fail(RT_ERR_ARG, "render: unknown shade model %d", p->shade_model);
-    if (p->shade_model == RT_SHADE_P13)
-        for (const rt_blinn &m : s->data.materials)
-            if (m.reflection_glossiness != 0 || m.refraction_glossiness != 0)
-                return fail(RT_ERR_LIMIT, "render: glossy reflection/refraction (P13 shading) is not implemented on the device yet");
     if (p->knn_k < 1 || p->knn_k > 65536 || !(p->knn_radius > 0)) return fail(RT_ERR_ARG, "render: bad photon gather parameters");
     if (!(p->gamma > 0)) return fail(RT_ERR_ARG, "render: gamma must be positive");
     if (t->tile_w <= 0 || t->tile_h <= 0 || t->stride <= 0 || t->first < 0) return fail(RT_ERR_ARG, "render: bad tile range");
-    for (const rt_light &l : s->data.lights)
-        if (l.type == RT_LIGHT_POINT && l.size != 0) return fail(RT_ERR_LIMIT, "render: area lights (size != 0) are not implemented on the device yet");
+    if (p->shadow_samples > 32) return fail(RT_ERR_LIMIT, "render: at most 32 shadow samples per light");
     return RT_OK;
 }
 
@@ -1028,7 +1024,7 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
         if ((st = D->t_in.upload(rays + 6 * off, (size_t)m * 24))) return st;
         HIP_TRY(hipMemsetAsync(W.sample_hit, 0, m, D->stream));
         HIP_TRY(hipMemsetAsync(W.sample_rgb, 0, (size_t)m * 12, D->stream));
-        if ((st = run_pipeline(D, D->stream, W, pv, nullptr, dc, dt, 0, m, 0, 1, 1, 2, (const float *)D->t_in.p))) return st;
+        if ((st = run_pipeline(D, D->stream, W, pv, nullptr, dc, dt, (uint32_t)off, m, 0, 1, 1, 2, (const float *)D->t_in.p))) return st;
         HIP_TRY(hipStreamSynchronize(D->stream));
         HIP_TRY(hipMemcpy(hit + off, W.sample_hit, m, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(rgb + 3 * off, W.sample_rgb, (size_t)m * 12, hipMemcpyDeviceToHost));

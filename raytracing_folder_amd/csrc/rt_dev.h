@@ -92,6 +92,7 @@ struct DevCamera {
     float m[9];          // Matrix3(x_new, up, z_new), column-major
     float b[3];          // pixel (0,0) sample origin incl. the half-pixel shift
     float u, v;          // pixel pitch
+    float dof;           // lens radius (0 = pinhole)
     int32_t width, height;
 };
 

@@ -53,6 +53,16 @@ __device__ __forceinline__ V3 mtmul(const float *d, V3 v)      // TransposeMult,
 
 struct Counters { uint32_t inst, nodes, tris, shadow; };
 
+// Halton, FIN/include/scene.h:131-140
+__device__ __forceinline__ float halton(int index, int base)
+{
+    float r = 0;
+    float f = 1.0f / (float)base;
+    for (int i = index; i > 0; i /= base) { r += f * (i % base); f /= (float)base; }
+    return r;
+}
+
+
 struct Hit { float z; V3 p, N; int node; int front; };
 
 // ------------------------------------------------------------------------------------------------
@@ -277,6 +287,42 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
 }
 
 // ------------------------------------------------------------------------------------------------
+// Counter-based random numbers for the stochastic effects.  The reference calls
+// libc rand() from all its threads at once, so its sequences are not even reproducible; here every
+// draw is Philox-4x32-10 keyed by the seed and counted by WHAT it is for:
+//   (sample id = (y*W+x)*max_sample+j, ray-tree node, purpose, index)
+// so a pixel's value does not depend on tiling, chunking, scheduling or the number of GPUs, and the
+// CPU oracle draws the very same numbers.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t out[4])
+{
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * x0, p1 = (unsigned long long)0xCD9E8D57u * x2;
+        const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0, y1 = (uint32_t)p1, y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1, y3 = (uint32_t)p0;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
+}
+#define RNG_LENS   1u     // DoF lens table entry (sample id = pixel id)
+#define RNG_PICK   2u     // which lens entry a sample uses
+#define RNG_SHADOW 3u     // area-light sample (index = light*64 + i, refinement batch at +32)
+#define RNG_GLOSSR 4u     // glossy reflection jitter
+#define RNG_GLOSST 5u     // glossy refraction jitter
+#define RNG_GI     6u     // hemisphere sample
+struct RngCtx { uint32_t seed, sample, node; };
+// two uniforms in [0,1): each stands in for one rand() / (float) RAND_MAX
+__device__ __forceinline__ void rng2(const RngCtx &c, uint32_t purpose, uint32_t index, float &u0, float &u1)
+{
+    uint32_t o[4];
+    philox4x32(c.seed, 0x52544D49u, c.sample, c.node, (purpose << 24) | (index & 0xFFFFFFu), 0x5eed5eedu, o);
+    u0 = (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+    u1 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+}
+// id of a child node in the ray tree (1 = primary ray): only has to be reproducible
+__host__ __device__ inline uint32_t child_node(uint32_t node, uint32_t kind) { return node * 0x9E3779B1u + kind * 0x85EBCA6Bu + 0x27D4EB2Fu; }
+
+// ------------------------------------------------------------------------------------------------
 // queues: wave-aggregated append (one atomic per wave, __ballot + popcount for the lane offset)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_push(bool pred, uint32_t *counter)
@@ -295,7 +341,7 @@ __device__ __forceinline__ uint32_t wave_push(bool pred, uint32_t *counter)
 #define KIND_REFLECT 0u
 #define KIND_REFRACT 1u
 
-struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; bool primary; };
+struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; bool primary; uint32_t node, sample; };
 
 struct ShadeCtx {
     DevScene S; DevWork W; rt_params P;
@@ -313,13 +359,17 @@ __device__ __forceinline__ V3 light_direction(const rt_light &l, V3 p)
     return mk(0, 0, 0);
 }
 
-// Light::Illuminate (FIN/include/lights.h:34,50,67-131; P13/include/lights.h:65-91) for light
-// size 0: the MIN_SHADOW_SAMPLES sample rays coincide (every disc offset has length 0), their mean
-// is exactly 0 or 1 and the refinement loop never runs, so ONE any-hit shadow query (GenLight::
-// Shadow, FIN/main.cpp:499-513: occluded iff 1e-14 < z < t_max) decides it.  size > 0 is rejected
-// by the host API for now (stochastic soft shadows: SURVEY 8(f3)).
+// Light::Illuminate.  Ambient: intensity (lights.h:34).  Direct: Shadow(Ray(p,-direction))*intensity
+// (:50).  Point, FIN (FIN/include/lights.h:67-131): MIN_SHADOW_SAMPLES rays towards position + s*(1,1,1)
+// with s = |xv|+|yv| (the reference adds the two LENGTHS to every coordinate, :103), xv,yv a random
+// point of the disc of radius `size`; if their mean is neither 0 nor 1, MAX_SHADOW_SAMPLES (16) more
+// replace them; result intensity*shadow/dist^2.  Point, P13 (P13/include/lights.h:65-91): 4 rays
+// towards position + (dx,dy,dz), radius sqrt(Halton(i,2))*size, two random angles.
+// Each shadow ray is an any-hit query (GenLight::Shadow, FIN/main.cpp:499-513: occluded iff
+// 1e-14 < z < t_max).  With size == 0 all samples coincide and ONE query decides them.
 template <int MODEL>
-__device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &l, V3 p, uint32_t *stack, Counters &cnt)
+__device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &l, int li, V3 p, const RngCtx &rc,
+                         uint32_t *stack, Counters &cnt)
 {
     const V3 I = ld3(l.intensity);
     if (l.type == RT_LIGHT_AMBIENT) return I;
@@ -330,15 +380,66 @@ __device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &
         return I * (occ ? 0.0f : 1.0f);
     }
     const V3 position = ld3(l.position);
-    cnt.shadow++;
-    const bool occ = trace<true, MODEL>(S, p, position - p, 1.0f, dummy, stack, cnt);
     const int ns = P.shadow_samples > 0 ? P.shadow_samples : 4;
-    float coefsum = 0.0f;
-    for (int i = 0; i < ns; i++) coefsum += occ ? 0.0f : 1.0f;     // the ns identical samples
-    if (MODEL == RT_SHADE_P13)                                      // intensity*coef/SAMPLES, then /dist^2
-        return ((I * coefsum) / (float)ns) / len2(p - position);
-    const float shadow = coefsum / (float)ns;
-    return (I * shadow) / len2(p - position);                       // lights.h:130
+    if (l.size == 0) {
+        cnt.shadow++;
+        const bool occ = trace<true, MODEL>(S, p, position - p, 1.0f, dummy, stack, cnt);
+        float coefsum = 0.0f;
+        for (int i = 0; i < ns; i++) coefsum += occ ? 0.0f : 1.0f;     // the ns identical samples
+        if (MODEL == RT_SHADE_P13) return ((I * coefsum) / (float)ns) / len2(p - position);
+        const float shadow = coefsum / (float)ns;
+        return (I * shadow) / len2(p - position);                       // lights.h:130
+    }
+    if (MODEL == RT_SHADE_P13) {
+        float coef = 0.0f;
+        for (int i = 0; i < ns; i++) {
+            float u0, u1;
+            rng2(rc, RNG_SHADOW, (uint32_t)(li * 64 + i), u0, u1);
+            float r = halton(i, 2);
+            r = sqrtf(r) * l.size;
+            const float theta = (float)(M_PI * 2.0 * (double)u0);
+            const float gam = (float)(M_PI * (double)u1);
+            const float dx = r * sinf(gam) * cosf(theta), dy = r * sinf(gam) * sinf(theta), dz = r * cosf(gam);
+            const V3 lp = mk(dx, dy, dz) + position;
+            cnt.shadow++;
+            coef += trace<true, MODEL>(S, p, lp - p, 1.0f, dummy, stack, cnt) ? 0.0f : 1.0f;
+        }
+        return ((I * coef) / (float)ns) / len2(p - position);
+    }
+    const V3 dir = position - p;
+    V3 v1 = dot(dir, mk(1, 0, 0)) > 0.8f ? cross(mk(0, 1, 0), dir) : cross(mk(1, 0, 0), dir);
+    V3 v2 = cross(v1, dir);
+    v2 = normalize(v2);
+    v1 = normalize(v1);
+    float shadow = 0.0f;
+    for (int i = 0; i < ns; i++) {
+        float u0, u1;
+        rng2(rc, RNG_SHADOW, (uint32_t)(li * 64 + i), u0, u1);
+        const float rRadius = sqrtf(u0) * l.size;
+        const float rAngle = (float)((double)u1 * (2.0 * M_PI));
+        const float xv = rRadius * cosf(rAngle), yv = rRadius * sinf(rAngle);
+        const float lx = sqrtf(len2(v1 * xv)), ly = sqrtf(len2(v2 * yv));
+        const V3 tgt = mk(position.x + lx + ly, position.y + lx + ly, position.z + lx + ly);
+        cnt.shadow++;
+        shadow += trace<true, MODEL>(S, p, tgt - p, 1.0f, dummy, stack, cnt) ? 0.0f : 1.0f;
+    }
+    shadow /= (float)ns;
+    if (shadow != 0.0f && shadow != 1.0f) {
+        shadow = 0.0f;
+        for (int i = 0; i < 16; i++) {                                  // MAX_SHADOW_SAMPLES
+            float u0, u1;
+            rng2(rc, RNG_SHADOW, (uint32_t)(li * 64 + 32 + i), u0, u1);
+            const float rRadius = sqrtf(u0) * l.size;
+            const float rAngle = (float)((double)u1 * (2.0 * M_PI));
+            const float xv = rRadius * cosf(rAngle), yv = rRadius * sinf(rAngle);
+            const float lx = sqrtf(len2(v1 * (-xv))), ly = sqrtf(len2(v2 * (-yv)));
+            const V3 tgt = mk(position.x + lx + ly, position.y + lx + ly, position.z + lx + ly);
+            cnt.shadow++;
+            shadow += trace<true, MODEL>(S, p, tgt - p, 1.0f, dummy, stack, cnt) ? 0.0f : 1.0f;
+        }
+        shadow /= 16.0f;
+    }
+    return (I * shadow) / len2(p - position);
 }
 
 __device__ __forceinline__ void add_sample(const ShadeCtx &C, uint32_t slot, V3 c, bool primary)
@@ -349,7 +450,7 @@ __device__ __forceinline__ void add_sample(const ShadeCtx &C, uint32_t slot, V3 
 }
 
 __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 d, V3 thr, V3 absorb,
-                                         uint32_t slot, int bounce, uint32_t kind)
+                                         uint32_t slot, int bounce, uint32_t kind, uint32_t node, uint32_t sample)
 {
     const uint32_t idx = wave_push(pred, C.qout_count);
     if (pred) {
@@ -357,7 +458,7 @@ __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 
             C.qout.a[idx] = make_float4(o.x, o.y, o.z, d.x);
             C.qout.b[idx] = make_float4(d.y, d.z, thr.x, thr.y);
             C.qout.c[idx] = make_float4(thr.z, absorb.x, absorb.y, absorb.z);
-            C.qout.d[idx] = make_uint4(slot, (uint32_t)bounce | (kind << 8), 0u, 0u);
+            C.qout.d[idx] = make_uint4(slot, (uint32_t)bounce | (kind << 8), node, sample);
         } else atomicAdd(&C.W.stats[ST_QUEUE_OVERFLOW], 1ull);
     }
 }
@@ -386,8 +487,8 @@ struct ShadeOut {
 };
 
 // MtlBlinn::Shade, FIN/main.cpp:516-708
-__device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, ShadeOut &o,
-                          uint32_t *stack, Counters &cnt)
+__device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
+                          ShadeOut &o, uint32_t *stack, Counters &cnt)
 {
     const rt_blinn &m = S.materials[S.node_material[h.node]];
     V3 color = ld3(m.emission);                                         // :517
@@ -405,7 +506,7 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
         // the reference still calls Illuminate (its shadow rays) for a back-face hit but uses the
         // result only for front hits (:551-553): nothing to add, nothing traced
         if (!h.front) continue;
-        const V3 Il = illuminate<RT_SHADE_FIN>(S, P, light, p, stack, cnt);
+        const V3 Il = illuminate<RT_SHADE_FIN>(S, P, light, li, p, rc, stack, cnt);
         if (light.type != RT_LIGHT_AMBIENT) {
             const V3 intensity = Il * coef;                             // :551
             V3 L = light_direction(light, p) * (float)(-1);             // :556
@@ -456,8 +557,8 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
 // all = ambient + direct; all += re_color*reflection; all += refraction*(ra_ratio*absorb*ra_color +
 // re_ratio*re_color): the reflection child weighs reflection + refraction*re_ratio, the refraction
 // child refraction*ra_ratio*exp(-absorption.r * z_child) (z_child = BIGFLOAT on a miss).
-__device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, ShadeOut &o,
-                          uint32_t *stack, Counters &cnt)
+__device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
+                          ShadeOut &o, uint32_t *stack, Counters &cnt)
 {
     const rt_blinn &m = S.materials[S.node_material[h.node]];
     V3 N = h.N;
@@ -467,7 +568,7 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
     V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
     for (int i = 0; i < S.n_lights; i++) {
         const rt_light &l = S.lights[i];
-        const V3 Il = illuminate<RT_SHADE_P13>(S, P, l, Pp, stack, cnt);
+        const V3 Il = illuminate<RT_SHADE_P13>(S, P, l, i, Pp, rc, stack, cnt);
         if (l.type == RT_LIGHT_AMBIENT) ambient = ambient + Il * Kd;                     // :510
         else {
             const V3 L = normalize(light_direction(l, Pp) * (float)-1);
@@ -480,9 +581,30 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
     }
     o.color = ambient + diffuse;                                                          // :622
     V3 V = -normalize(ray_d);                                                             // :632
-    const float costheta = fminf(fmaxf(dot(N, V), -1.0f), 1.0f);                          // clamp :648
-    o.rdir = normalize(N * (2 * costheta) - V);                                           // :649, :652
-    // refraction block :671-751
+    // glossy reflection: the normal is jittered inside a disc of radius reflectionGlossiness (:635-647)
+    V3 Nr = N;
+    if (m.reflection_glossiness != 0) {
+        const V3 newx = cross(Nr, mk(1, 0, 0));
+        const V3 newy = cross(Nr, newx);
+        float u0, u1;
+        rng2(rc, RNG_GLOSSR, 0u, u0, u1);
+        const float r = sqrtf(u0) * m.reflection_glossiness;
+        const float theta = (float)(M_PI * 2.0 * (double)u1);
+        Nr = normalize(Nr + (newx * (r * cosf(theta)) + newy * (r * sinf(theta))));
+    }
+    const float costheta = fminf(fmaxf(dot(Nr, V), -1.0f), 1.0f);                         // clamp :648
+    o.rdir = normalize(Nr * (2 * costheta) - V);                                          // :649, :652
+    // refraction block :671-751 (starts again from the unjittered normal, :672)
+    N = h.N;
+    if (m.refraction_glossiness != 0) {                                                   // :673-686
+        const V3 newx = cross(N, mk(1, 0, 0));
+        const V3 newy = cross(N, newx);
+        float u0, u1;
+        rng2(rc, RNG_GLOSST, 0u, u0, u1);
+        const float r = sqrtf(u0) * m.refraction_glossiness;
+        const float theta = (float)(M_PI * 2.0 * (double)u1);
+        N = normalize(N + (newx * (r * cosf(theta)) + newy * (r * sinf(theta))));
+    }
     V = normalize(V);
     const float costheta1 = fabsf(dot(V, N));
     const float sintheta1 = sqrtf(RMAX(0.0f, 1 - (costheta1 * costheta1)));
@@ -546,8 +668,9 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
     }
     if (active && hit) {
         if (in.primary) { C.W.sample_hit[in.slot] = 1; C.W.sample_z[in.slot] = h.z; }
-        if (p13) shade_p13(S, P, h, in.d, in.bounce, o, stack, cnt);
-        else shade_fin(S, P, h, in.d, in.bounce, o, stack, cnt);
+        RngCtx rc; rc.seed = P.seed; rc.sample = in.sample; rc.node = in.node;
+        if (p13) shade_p13(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
+        else shade_fin(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
         add_sample(C, in.slot, thr * o.color, in.primary);
         // a child (or query) whose accumulated weight is exactly zero cannot change the pixel
         const V3 wr = thr * o.rK, wt = thr * o.tK, wp = thr * o.kd;
@@ -556,8 +679,10 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
         o.want_photon = o.want_photon && (wp.x != 0.f || wp.y != 0.f || wp.z != 0.f);
     }
     // pushes are wave-collective: every lane of the wave reaches them
-    push_ray(C, o.want_refl, h.p, o.rdir, thr * o.rK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFLECT);
-    push_ray(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT);
+    push_ray(C, o.want_refl, h.p, o.rdir, thr * o.rK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFLECT,
+             child_node(in.node, 1u), in.sample);
+    push_ray(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
+             child_node(in.node, 2u), in.sample);
     push_photon_query(C, o.want_photon, h.p, o.N, thr * o.kd, in.slot);
 }
 
@@ -579,15 +704,6 @@ __device__ __forceinline__ void flush_counters(unsigned long long *stats, const 
         if (v[5]) atomicAdd(&stats[ST_RAYS_REFLECT], (unsigned long long)v[5]);
         if (v[6]) atomicAdd(&stats[ST_RAYS_REFRACT], (unsigned long long)v[6]);
     }
-}
-
-// Halton, FIN/include/scene.h:131-140
-__device__ __forceinline__ float halton(int index, int base)
-{
-    float r = 0;
-    float f = 1.0f / (float)base;
-    for (int i = index; i > 0; i /= base) { r += f * (i % base); f /= (float)base; }
-    return r;
 }
 
 // chunk-local pixel q -> image pixel, walking this call's tiles (tile-major, row-major inside)
@@ -633,7 +749,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
         bool active = gid < total;
         PathIn in;
         in.thr = mk(1.f, 1.f, 1.f); in.absorb = mk(0, 0, 0); in.bounce = C.P.bounce; in.kind = KIND_REFLECT; in.primary = true;
-        in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.slot = 0;
+        in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.slot = 0; in.node = 1; in.sample = 0;
         if (active) {
             const uint32_t pi = (uint32_t)(gid / (unsigned long long)A.ns);
             const int j = A.j0 + (int)(gid % (unsigned long long)A.ns);
@@ -642,6 +758,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
             if (A.mode == 2) {
                 const float *r = A.rays + 6 * (size_t)ql;
                 in.o = ld3(r); in.d = ld3(r + 3);
+                in.sample = A.q0 + ql;                     // caller's ray index
             } else {
                 int x, y;
                 if (!pixel_of(A.tiles, A.cam, A.q0 + ql, x, y)) active = false;
@@ -651,8 +768,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
                     float sy = A.cam.v * halton(j, 3);                                 // :154
                     sx += tmp.x; sy += tmp.y;
                     const V3 sample = mk(sx, sy, tmp.z);
-                    in.o = ld3(A.cam.pos);                                             // camera.pos + 0
-                    in.d = normalize(mmul(A.cam.m, sample));                           // :289-292
+                    const uint32_t pixel_id = (uint32_t)y * (uint32_t)A.cam.width + (uint32_t)x;
+                    in.sample = pixel_id * (uint32_t)A.max_sample + (uint32_t)j;
+                    V3 d_campos = mk(0, 0, 0);
+                    if (A.cam.dof != 0) {
+                        // :246-262: a table of CAM_SAMPLE lens points per pixel (radius sqrt(Halton(i,2))*dof,
+                        // random angle), of which every sample picks one at random (:284)
+                        RngCtx pc; pc.seed = C.P.seed; pc.sample = in.sample; pc.node = 0;
+                        float u0, u1;
+                        rng2(pc, RNG_PICK, 0u, u0, u1);
+                        int pick = (int)(u0 * 64.0f);
+                        pick = pick > 63 ? 63 : pick;
+                        RngCtx lc; lc.seed = C.P.seed; lc.sample = pixel_id; lc.node = 0;
+                        rng2(lc, RNG_LENS, (uint32_t)(pick + 1), u0, u1);
+                        float r = halton(pick + 1, 2);
+                        r = sqrtf(r) * A.cam.dof;
+                        const float theta = (float)(M_PI * 2.0 * (double)u0);
+                        d_campos = mmul(A.cam.m, mk(r * cosf(theta), r * sinf(theta), 0));
+                    }
+                    in.o = ld3(A.cam.pos) + d_campos;                                  // :288
+                    in.d = normalize(mmul(A.cam.m, sample) - d_campos);                // :289-292
                 }
             }
         }
@@ -678,13 +813,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin
         const bool active = gid < total;
         PathIn in;
         in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
-        in.slot = 0; in.bounce = 0; in.kind = 0;
+        in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0;
         if (active) {
             const float4 a = qin.a[gid], b = qin.b[gid], c = qin.c[gid];
             const uint4 dd = qin.d[gid];
             in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
             in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
-            in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu;
+            in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.node = dd.z; in.sample = dd.w;
             if (in.kind == KIND_REFRACT) nrefr++; else nrefl++;
         }
         shade_path<MODEL>(C, in, active, stack, cnt);

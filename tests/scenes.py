@@ -56,3 +56,14 @@ def camera_rays(cam, n, seed=0):
     oc = oracle_camera(cam)
     xs, ys, js = rng.integers(0, cam.width, n), rng.integers(0, cam.height, n), rng.integers(0, 8, n)
     return np.stack([orc.primary_ray(oc, x, y, j) for x, y, j in zip(xs, ys, js)])
+
+
+def rebuild(export, materials=None, lights=None):
+    """A new product scene from exported arrays, with materials / lights optionally replaced."""
+    s = capi.Scene()
+    s.set_nodes(export["nodes"])
+    for i, m in enumerate(export["meshes"]):
+        s.set_mesh(i, m["v"], m["f"], m["vn"], m["fn"], m["nodes"], m["elements"])
+    s.set_materials(export["materials"] if materials is None else materials)
+    s.set_lights(export["lights"] if lights is None else lights)
+    return s

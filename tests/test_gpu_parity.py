@@ -246,6 +246,65 @@ def test_render_p13_frame(cornell):
     assert st.rays_reflect > 0 and st.rays_refract > 0 and st.photon_queries == 0
 
 
+def _aimed_rays(cam, seed, n_cam=1500):
+    rng = np.random.default_rng(seed)
+    tg = np.concatenate([rng.normal([8, -6, 4], 2.5, (700, 3)), rng.normal([-8, -6, 4], 2.5, (700, 3)),
+                         rng.normal([2, 5, 4], 4.0, (600, 3))])
+    o = np.array([0, -60, 12], np.float32)
+    d = tg - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([scenes.camera_rays(cam, n_cam, seed=seed + 1),
+                           np.concatenate([np.tile(o, (len(d), 1)), d], 1).astype(np.float32)])
+
+
+@pytest.mark.parametrize("model", [capi.SHADE_FIN, capi.SHADE_P13])
+def test_soft_shadows_and_glossy_with_counter_rng(cornell, model):
+    """area light (size 3) + glossy mirror/glass: every random draw is Philox(seed; sample, ray-tree
+    node, purpose, index) on both sides, so GPU and oracle agree ray by ray (statistical parity with
+    the reference, whose rand() stream is not reproducible)"""
+    s0, cam, e = cornell
+    lights = e["lights"].copy()
+    lights["size"] = 3.0
+    mats = e["materials"].copy()
+    if model == capi.SHADE_P13:
+        mats["reflection_glossiness"][4] = 0.08
+        mats["refraction_glossiness"][5] = 0.05
+    s = scenes.rebuild(e, mats, lights)
+    e2 = s.export()
+    osc = scenes.oracle_scene(e2)
+    p = capi.default_params(shade_model=model, bounce=6 if model == capi.SHADE_P13 else 4, seed=4242)
+    rays = _aimed_rays(cam, 21)
+    ohit, orgb, oz = orc.shade_rays(osc, scenes.oracle_params(p), rays)
+    hit, rgb, z = s.shade_rays(p, rays)
+    assert (hit == ohit).all() and z.tobytes() == oz.tobytes()
+    ok = _close(rgb, orgb, rel=5e-5, abs_=2e-6).all(axis=1)
+    assert ok.mean() > 0.99, (~ok).sum()              # an ulp of cosf/sinf may flip one shadow sample
+    # penumbra: the same rays with a point light differ on a visible fraction of the hits
+    hit0, rgb0, _ = s0.shade_rays(capi.default_params(shade_model=model, bounce=p.bounce), rays)
+    changed = (np.abs(rgb0 - rgb).max(axis=1) > 1e-3)[hit.astype(bool)]
+    assert 0.02 < changed.mean() < 0.9
+    # a different seed gives different penumbra samples
+    p2 = capi.default_params(shade_model=model, bounce=p.bounce, seed=4243)
+    _, rgb2, _ = s.shade_rays(p2, rays)
+    assert (np.abs(rgb2 - rgb).max(axis=1) > 1e-4).mean() > 0.01
+
+
+def test_depth_of_field_frame(cornell):
+    """camera.dof: per-pixel lens table + per-sample pick (FIN/main.cpp:246-262, 283-291)"""
+    s0, cam0, e = cornell
+    s, cam = scenes.load_cornell(96, 72)
+    cam.dof = 0.6
+    cam.focaldist = 48.0
+    p = capi.default_params(min_sample=8, max_sample=8, threshold=-1.0, seed=99)
+    rgb, z, cnt, st, _ = s.render(cam, p)
+    orgb, oz, ocnt = orc.render(scenes.oracle_scene(e), scenes.oracle_camera(cam), scenes.oracle_params(p))
+    diff = np.abs(rgb.astype(int) - orgb.astype(int)).max(axis=2)
+    assert (diff <= 1).mean() >= 0.99 and (z == oz).mean() > 0.99
+    cam.dof = 0.0
+    rgb_pin, _, _, _, _ = s.render(cam, p)
+    assert (np.abs(rgb_pin.astype(int) - rgb.astype(int)).max(axis=2) > 2).mean() > 0.05    # blur is visible
+
+
 def _frame_gate(rgb, orgb, z, oz, cnt, ocnt):
     diff = np.abs(rgb.astype(int) - orgb.astype(int)).max(axis=2)
     assert (diff <= 1).mean() >= 0.995, (diff > 1).sum()
