@@ -115,6 +115,7 @@ typedef struct rt_photon {
 /* shading semantics: which snapshot's MtlBlinn::Shade / primitives to follow */
 #define RT_SHADE_FIN 0   /* FIN/main.cpp:516-708 (+ FIN primitives, two-sided triangles)      */
 #define RT_SHADE_P13 1   /* P13/main.cpp:485-756 (+ P13 primitives, back-face-culled tris)    */
+#define RT_SHADE_P12 2   /* RayTracingProj12 main.cpp:341-588: P13's tree + live path-traced GI  */
 
 /* The reference's compile-time #defines (FIN/main.cpp:19-32, FIN/include/lights.h:16-18,
  * FIN/include/materials.h:20-25, FIN/main.cpp:699) as one runtime block.

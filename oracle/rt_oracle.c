@@ -173,7 +173,7 @@ int orc_plane_intersect(int model, const float ray[6], orc_hit *hit)
             st3(hit->p, Hitp);
             st3(hit->N, N);
             float nd = vdot(N, d);
-            if (model == RT_SHADE_P13) hit->front = (nd < 0.0f) ? 0 : 1;
+            if (model != RT_SHADE_FIN) hit->front = (nd < 0.0f) ? 0 : 1;
             else                       hit->front = (nd <= 0.0f) ? 1 : 0;
             return 1;
         }
@@ -318,7 +318,7 @@ static int trace_bvh_node(int model, const orc_mesh *m, const float ray[6], orc_
         uint32_t count = ((n->data >> 28) & 7u) + 1;       /* ElementCount, cyBVH.h:194 */
         uint32_t off = n->data & 0x0FFFFFFFu;              /* ElementOffset, cyBVH.h:193 */
         for (uint32_t i = 0; i < count; i++) {
-            int h = (model == RT_SHADE_P13) ? tri_intersect_p13(m, ray, hit, m->elements[off + i])
+            int h = (model != RT_SHADE_FIN) ? tri_intersect_p13(m, ray, hit, m->elements[off + i])
                                             : tri_intersect_fin(m, ray, hit, m->elements[off + i]);
             if (h) hitted = 1;
         }
@@ -445,7 +445,7 @@ void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
     const uint32_t li = (uint32_t)(l - s->lights);
     float shadow = 0.0f;
     float u0, u1;
-    if (model == RT_SHADE_P13) {
+    if (model != RT_SHADE_FIN) {
         float shadow_coef = 0.0f;
         for (int i = 0; i < ns; i++) {
             rng2(RNG_SHADOW, li * 64 + (uint32_t)i, &u0, &u1);
@@ -521,7 +521,7 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
 
 void orc_shade(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3])
 {
-    if (P->shade_model == RT_SHADE_P13) shade_p13(s, P, ray, h, bounce, out);
+    if (P->shade_model == RT_SHADE_P13 || P->shade_model == RT_SHADE_P12) shade_p13(s, P, ray, h, bounce, out);
     else shade_fin(s, P, ray, h, bounce, out);
 }
 
@@ -650,6 +650,7 @@ static float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi 
 static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *hInfo, int bounceCount, float out[3])
 {
     const rt_blinn *m = hit_material(s, hInfo);
+    const int p12 = P->shade_model == RT_SHADE_P12;
     v3 ra_color = V3(0, 0, 0), re_color = V3(0, 0, 0), re_ra_color;
     v3 ambient_color = V3(0, 0, 0), diffuse_color = V3(0, 0, 0);
     v3 N = v3p(hInfo->N), Pp = v3p(hInfo->p);
@@ -664,7 +665,8 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
         } else {
             orc_illuminate(s, P, l, hInfo->p, hInfo->N, Il);
             v3 I_i = v3p(Il);
-            v3 L = vnorm(vscale(light_direction(l, Pp), (float)-1));
+            v3 L = vscale(light_direction(l, Pp), (float)-1);
+            if (!p12) L = vnorm(L);                                                   /* P13 adds L.Normalize() (:540) */
             v3 V = vnorm(vneg(v3p(ray + 3)));
             v3 H = vnorm(vadd(L, V));
             v3 kse = vadd(vscale(Ks, powf(vdot(N, H), alpha)), Kd);                   /* :547 */
@@ -672,9 +674,48 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
             diffuse_color = vadd(diffuse_color, vmul(vscale(I_i, (theta > 0.0 ? theta : 0.0f)), kse));   /* :551 */
         }
     }
-    v3 all = vadd(ambient_color, diffuse_color);                                      /* :622 (idr, cau = 0) */
-    v3 V = vneg(vnorm(v3p(ray + 3)));                                                 /* :632 */
     const uint32_t me = g_rng.node;
+    v3 all = vadd(ambient_color, diffuse_color);                                      /* :622 (idr, cau = 0) */
+    if (p12) {
+        /* RayTracingProj12 main.cpp:393-448: cosine-weighted hemisphere rays, HEMISPHERE_SAMPLE at
+         * the primary hit and 1 below it; all = ambient + ((diffuse/pi) + idr)*Kd */
+        v3 idr = V3(0, 0, 0);
+        if (bounceCount > 0) {
+            v3 newz = v3p(hInfo->N);
+            v3 newx = vdot(newz, V3(1, 0, 0)) < 0.4 ? vcross(newz, V3(1, 0, 0)) : vcross(newz, V3(0, 0, 1));
+            newx = vnorm(newx);
+            v3 newy = vcross(newz, newx);
+            int Nof = (bounceCount == P->bounce) ? P->hemisphere_sample : 1;
+            for (int i = 0; i < Nof; i++) {
+                float u0, u1;
+                rng2(RNG_GI, (uint32_t)i, &u0, &u1);
+                float phi = (float)(2 * M_PI * u0);
+                float cosphi = cosf(phi);
+                float ysquare = u1;
+                float sintheta = sqrtf(ysquare);
+                float costheta = sqrtf(1 - ysquare);
+                v3 hd = vadd(vadd(vscale(newx, sintheta * cosphi), vscale(newy, sintheta * sinf(phi))), vscale(newz, costheta));
+                hd = vnorm(hd);
+                float dotN_wi = vdot(hd, newz);
+                float r[6];
+                st3(r, Pp); st3(r + 3, vnorm(hd));
+                orc_hit hh;
+                v3 ic;
+                g_cnt.rays_refract++;                      /* counted with the secondary rays */
+                if (orc_trace(s, P->shade_model, r, &hh)) {
+                    float c[3];
+                    g_rng.node = child_node(me, 3u + (uint32_t)i);
+                    shade_p13(s, P, r, &hh, bounceCount - 1, c);
+                    g_rng.node = me;
+                    ic = v3p(c);
+                } else ic = v3p(s->env);
+                ic = vscale(ic, dotN_wi);
+                idr = vadd(idr, vdivs(vscale(ic, 1.0f), (float)Nof));
+            }
+        }
+        all = vadd(ambient_color, vmul(vadd(vdivs(diffuse_color, (float)M_PI), idr), Kd));
+    }
+    v3 V = vneg(vnorm(v3p(ray + 3)));                                                 /* :632 */
     if (bounceCount > 0) {                                                            /* :633-663 */
         v3 newN = N;
         if (m->reflection_glossiness) {                                               /* :635-647 */

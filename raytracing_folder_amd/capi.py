@@ -29,7 +29,7 @@ assert (NODE.itemsize, BVHNODE.itemsize, BLINN.itemsize, LIGHT.itemsize, PHOTON.
 
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3
 LIGHT_AMBIENT, LIGHT_DIRECT, LIGHT_POINT = 0, 1, 2
-SHADE_FIN, SHADE_P13 = 0, 1
+SHADE_FIN, SHADE_P13, SHADE_P12 = 0, 1, 2
 
 
 class Camera(C.Structure):

@@ -635,13 +635,16 @@ static size_t chunk_samples_limit()
     return (size_t)v;
 }
 
-static rt_status ensure_workspace(DeviceState *D, size_t samples, int bounce, size_t list_pixels)
+static rt_status ensure_workspace(DeviceState *D, size_t samples, int bounce, size_t list_pixels, int fan = 2)
 {
     rt_status st;
     if (bounce < 0) bounce = 0;
     if (bounce > 12) return fail(RT_ERR_LIMIT, "bounce limit %d > 12", bounce);
-    unsigned long long rq_cap = (unsigned long long)samples << bounce;            // worst case: every hit spawns 2 rays
-    unsigned long long pq_cap = ((unsigned long long)samples << (bounce + 1));    // hits on levels 1..bounce
+    // worst case: every hit spawns `fan` rays, level after level (overflow is detected and reported)
+    double grow = 1.0;
+    for (int b = 0; b < bounce; b++) grow *= fan;
+    unsigned long long rq_cap = (unsigned long long)std::min(4.0e9, (double)samples * grow);
+    unsigned long long pq_cap = (unsigned long long)std::min(4.0e9, (double)samples * grow * 2.0);    // hits on levels 1..bounce
     const unsigned long long lim = 1ull << 28;
     if (rq_cap > lim) rq_cap = lim;
     if (pq_cap > lim) pq_cap = lim;
@@ -705,7 +708,10 @@ static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const 
     if ((unsigned long long)cam->width * cam->height * (unsigned long long)p->max_sample >= (1ull << 32))
         return fail(RT_ERR_LIMIT, "render: width*height*max_sample must stay below 2^32 (sample ids are 32-bit)");
     if (p->min_sample < 1 || p->max_sample < p->min_sample || p->max_sample > 4096) return fail(RT_ERR_ARG, "render: need 1 <= min_sample <= max_sample <= 4096");
-    if (p->shade_model != RT_SHADE_FIN && p->shade_model != RT_SHADE_P13) return fail(RT_ERR_ARG, "render: unknown shade model %d", p->shade_model);
+    if (p->shade_model != RT_SHADE_FIN && p->shade_model != RT_SHADE_P13 && p->shade_model != RT_SHADE_P12)
+        return fail(RT_ERR_ARG, "render: unknown shade model %d", p->shade_model);
+    if (p->shade_model == RT_SHADE_P12 && (p->hemisphere_sample < 1 || p->hemisphere_sample > 256))
+        return fail(RT_ERR_ARG, "render: hemisphere_sample must be 1..256 for RT_SHADE_P12");
     if (p->knn_k < 1 || p->knn_k > 65536 || !(p->knn_radius > 0)) return fail(RT_ERR_ARG, "render: bad photon gather parameters");
     if (!(p->gamma > 0)) return fail(RT_ERR_ARG, "render: gamma must be positive");
     if (t->tile_w <= 0 || t->tile_h <= 0 || t->stride <= 0 || t->first < 0) return fail(RT_ERR_ARG, "render: bad tile range");
@@ -772,7 +778,11 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
     uint64_t ppc = std::max<uint64_t>(1, limit / (uint64_t)p->max_sample);
     ppc = std::max<uint64_t>(tile_px, ppc / tile_px * tile_px);
     ppc = std::min<uint64_t>(ppc, std::max<uint64_t>(total_px, 1));
-    if ((st = ensure_workspace(D, (size_t)ppc * p->max_sample, p->bounce, (size_t)ppc))) return st;
+    // P12: a diffuse hit spawns hemisphere rays on top of the reflection/refraction pair; in practice one
+    // of the three classes dominates per material, so the queues are sized for a fan-out of 2 and an
+    // overflow is reported as an error rather than silently dropped
+    if ((st = ensure_workspace(D, (size_t)ppc * p->max_sample, p->bounce, (size_t)ppc,
+                               p->shade_model == RT_SHADE_P12 && p->hemisphere_sample > 1 ? 1 + p->hemisphere_sample : 2))) return st;
     const DevWork W = make_work(D);
     const bool want_stats = stats_out != nullptr || job != nullptr;
     Timing tm;
@@ -945,7 +955,7 @@ extern "C" rt_status rt_trace_rays(rt_scene *s, int shade_model, int device, con
 {
     if (!s || n < 0) return fail(RT_ERR_ARG, "rt_trace_rays: NULL scene or negative count");
     if (n > 0 && (!rays || !hit || !z || !p || !N || !node || !front)) return fail(RT_ERR_ARG, "rt_trace_rays: NULL argument");
-    if (shade_model != RT_SHADE_FIN && shade_model != RT_SHADE_P13) return fail(RT_ERR_ARG, "rt_trace_rays: unknown shade model");
+    if (shade_model != RT_SHADE_FIN && shade_model != RT_SHADE_P13 && shade_model != RT_SHADE_P12) return fail(RT_ERR_ARG, "rt_trace_rays: unknown shade model");
     DeviceState *D = nullptr;
     rt_status st = prepare_device(s, device, &D);
     if (st) return st;

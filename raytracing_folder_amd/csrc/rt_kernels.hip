@@ -105,7 +105,7 @@ __device__ __forceinline__ bool plane_hit(int model, V3 P, V3 d, float &z, V3 &h
         if (Hitp.x >= -1 && Hitp.x <= 1 && Hitp.y >= -1 && Hitp.y <= 1) {
             z = t; hp = Hitp; hN = mk(0, 0, 1);
             const float nd = dot(mk(0, 0, 1), d);
-            front = (model == RT_SHADE_P13) ? ((nd < 0.0f) ? 0 : 1) : ((nd <= 0.0f) ? 1 : 0);
+            front = (model != RT_SHADE_FIN) ? ((nd < 0.0f) ? 0 : 1) : ((nd <= 0.0f) ? 1 : 0);
             return true;
         }
     }
@@ -211,7 +211,7 @@ __device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN,
             for (uint32_t i = 0; i < count; i++) {
                 const DevTri T = M.tris[first + i];
                 cnt.tris++;
-                const bool h = (MODEL == RT_SHADE_P13) ? tri_hit_p13(T, o, d, z, hp, bc, front)
+                const bool h = (MODEL != RT_SHADE_FIN) ? tri_hit_p13(T, o, d, z, hp, bc, front)
                                                        : tri_hit_fin(T, o, d, z, hp, bc, front);
                 if (h) { any = true; best_slot = first + i; }
             }
@@ -237,7 +237,7 @@ __device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN,
     // cyTriMesh::GetNormal = vn[fn0]*bc.x + vn[fn1]*bc.y + vn[fn2]*bc.z (cyTriMesh.h:167,191)
     const float *n9 = M.nrm + 9 * (size_t)M.tri_face[best_slot];
     const V3 Ni = ld3(n9) * bc.x + ld3(n9 + 3) * bc.y + ld3(n9 + 6) * bc.z;
-    hN = (MODEL == RT_SHADE_P13) ? normalize(Ni) : Ni;     // FIN leaves it un-normalised (:262)
+    hN = (MODEL != RT_SHADE_FIN) ? normalize(Ni) : Ni;     // FIN leaves it un-normalised (:262)
     return true;
 }
 
@@ -340,6 +340,14 @@ __device__ __forceinline__ uint32_t wave_push(bool pred, uint32_t *counter)
 
 #define KIND_REFLECT 0u
 #define KIND_REFRACT 1u
+#define KIND_GI      2u
+
+// wave-wide maximum of a small non-negative int (loop bound for wave-collective pushes)
+__device__ __forceinline__ int __reduce_max_sync_compat(int v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
 
 struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; bool primary; uint32_t node, sample; };
 
@@ -386,11 +394,11 @@ __device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &
         const bool occ = trace<true, MODEL>(S, p, position - p, 1.0f, dummy, stack, cnt);
         float coefsum = 0.0f;
         for (int i = 0; i < ns; i++) coefsum += occ ? 0.0f : 1.0f;     // the ns identical samples
-        if (MODEL == RT_SHADE_P13) return ((I * coefsum) / (float)ns) / len2(p - position);
+        if (MODEL != RT_SHADE_FIN) return ((I * coefsum) / (float)ns) / len2(p - position);
         const float shadow = coefsum / (float)ns;
         return (I * shadow) / len2(p - position);                       // lights.h:130
     }
-    if (MODEL == RT_SHADE_P13) {
+    if (MODEL != RT_SHADE_FIN) {
         float coef = 0.0f;
         for (int i = 0; i < ns; i++) {
             float u0, u1;
@@ -484,6 +492,8 @@ struct ShadeOut {
     V3 rK, tK;                       // child weights relative to this ray
     V3 child_absorb;                 // what the children need to finish their own weight on arrival
     V3 kd, N;                        // photon query: diffuse colour and shading normal
+    int n_gi;                        // P12: hemisphere rays to spawn (weights/dirs are drawn at push time)
+    V3 gi_x, gi_y, gi_z;             // P12: frame of the hemisphere
 };
 
 // MtlBlinn::Shade, FIN/main.cpp:516-708
@@ -557,9 +567,11 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
 // all = ambient + direct; all += re_color*reflection; all += refraction*(ra_ratio*absorb*ra_color +
 // re_ratio*re_color): the reflection child weighs reflection + refraction*re_ratio, the refraction
 // child refraction*ra_ratio*exp(-absorption.r * z_child) (z_child = BIGFLOAT on a miss).
+template <int MODEL>
 __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
                           ShadeOut &o, uint32_t *stack, Counters &cnt)
 {
+    constexpr bool p12 = MODEL == RT_SHADE_P12;
     const rt_blinn &m = S.materials[S.node_material[h.node]];
     V3 N = h.N;
     const V3 Pp = h.p;
@@ -568,10 +580,11 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
     V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
     for (int i = 0; i < S.n_lights; i++) {
         const rt_light &l = S.lights[i];
-        const V3 Il = illuminate<RT_SHADE_P13>(S, P, l, i, Pp, rc, stack, cnt);
+        const V3 Il = illuminate<MODEL>(S, P, l, i, Pp, rc, stack, cnt);
         if (l.type == RT_LIGHT_AMBIENT) ambient = ambient + Il * Kd;                     // :510
         else {
-            const V3 L = normalize(light_direction(l, Pp) * (float)-1);
+            V3 L = light_direction(l, Pp) * (float)-1;
+            if (!p12) L = normalize(L);                                                   // P13 adds L.Normalize() (:540)
             const V3 V = normalize(-ray_d);
             const V3 H = normalize(L + V);
             const V3 kse = Ks * powf(dot(N, H), alpha) + Kd;                              // :547
@@ -580,6 +593,19 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
         }
     }
     o.color = ambient + diffuse;                                                          // :622
+    o.n_gi = 0;
+    if (p12) {
+        // RayTracingProj12 main.cpp:393-448: all = ambient + ((diffuse/pi) + idr)*Kd, idr = mean over the
+        // hemisphere rays of childColour * (dir.N): local part here, rays spawned by the caller
+        o.color = ambient + (diffuse / (float)M_PI) * Kd;
+        if (bounce > 0) {
+            o.n_gi = (bounce == P.bounce) ? P.hemisphere_sample : 1;
+            o.gi_z = h.N;
+            V3 nx = dot(o.gi_z, mk(1, 0, 0)) < 0.4f ? cross(o.gi_z, mk(1, 0, 0)) : cross(o.gi_z, mk(0, 0, 1));
+            o.gi_x = normalize(nx);
+            o.gi_y = cross(o.gi_z, o.gi_x);
+        }
+    }
     V3 V = -normalize(ray_d);                                                             // :632
     // glossy reflection: the normal is jittered inside a disc of radius reflectionGlossiness (:635-647)
     V3 Nr = N;
@@ -648,7 +674,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
 {
     const DevScene &S = C.S;
     const rt_params &P = C.P;
-    constexpr bool p13 = MODEL == RT_SHADE_P13;
+    constexpr bool p13 = MODEL != RT_SHADE_FIN;          // P13 and P12 share primitives, lights and the ray tree
     Hit h;
     bool hit = false;
     if (active) hit = trace<false, MODEL>(S, in.o, in.d, BIGFLOAT, h, stack, cnt);
@@ -656,20 +682,21 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
     ShadeOut o;
     o.want_refl = o.want_refr = o.want_photon = false;
     o.rdir = o.tdir = mk(0, 0, 1); o.rK = o.tK = o.child_absorb = o.kd = o.N = mk(0, 0, 0);
+    o.n_gi = 0; o.gi_x = o.gi_y = o.gi_z = mk(0, 0, 1);
     if (active && !in.primary) {
-        if (p13) { if (in.kind == KIND_REFRACT) thr = thr * expf(-in.absorb.x * (hit ? h.z : BIGFLOAT)); }
+        if (p13) { if (in.kind == KIND_REFRACT) thr = thr * expf(-in.absorb.x * (hit ? h.z : BIGFLOAT)); }   // not for GI rays
         else if (hit && !h.front) thr = thr * attenuation(in.absorb, h.z);
     }
     if (active && !hit) {
         if (in.primary) C.W.sample_hit[in.slot] = 0;
         // a refraction ray that leaves the scene sees the environment (FIN/main.cpp:635); in P13 so
         // does a reflection ray (P13/main.cpp:660-662)
-        else if (in.kind == KIND_REFRACT || p13) add_sample(C, in.slot, thr * ld3(S.env), false);
+        else if (in.kind != KIND_REFLECT || p13) add_sample(C, in.slot, thr * ld3(S.env), false);
     }
     if (active && hit) {
         if (in.primary) { C.W.sample_hit[in.slot] = 1; C.W.sample_z[in.slot] = h.z; }
         RngCtx rc; rc.seed = P.seed; rc.sample = in.sample; rc.node = in.node;
-        if (p13) shade_p13(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
+        if (p13) shade_p13<MODEL>(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
         else shade_fin(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
         add_sample(C, in.slot, thr * o.color, in.primary);
         // a child (or query) whose accumulated weight is exactly zero cannot change the pixel
@@ -684,6 +711,28 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
     push_ray(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
              child_node(in.node, 2u), in.sample);
     push_photon_query(C, o.want_photon, h.p, o.N, thr * o.kd, in.slot);
+    if (MODEL == RT_SHADE_P12) {
+        // hemisphere rays: idr += childColour * (dir.N) / Nofsample, times Kd (main.cpp:420-446)
+        const int n_max = __reduce_max_sync_compat(o.n_gi);
+        for (int i = 0; i < n_max; i++) {
+            bool want = i < o.n_gi;
+            V3 hd = mk(0, 0, 1), w = mk(0, 0, 0);
+            if (want) {
+                RngCtx rc; rc.seed = P.seed; rc.sample = in.sample; rc.node = in.node;
+                float u0, u1;
+                rng2(rc, RNG_GI, (uint32_t)i, u0, u1);
+                const float phi = (float)(2 * M_PI * (double)u0);
+                const float cosphi = cosf(phi);
+                const float sintheta = sqrtf(u1), costheta = sqrtf(1 - u1);
+                hd = normalize(o.gi_x * (sintheta * cosphi) + o.gi_y * (sintheta * sinf(phi)) + o.gi_z * costheta);
+                const float dotN_wi = dot(hd, o.gi_z);
+                w = thr * (o.kd * (dotN_wi / (float)o.n_gi));
+                hd = normalize(hd);                        // Ray_idr.dir.Normalize() (:433)
+                want = (w.x != 0.f || w.y != 0.f || w.z != 0.f);
+            }
+            push_ray(C, want, h.p, hd, w, mk(0, 0, 0), in.slot, in.bounce - 1, KIND_GI, child_node(in.node, 3u + (uint32_t)i), in.sample);
+        }
+    }
 }
 
 __device__ __forceinline__ void flush_counters(unsigned long long *stats, const Counters &c, uint32_t nprim, uint32_t nrefl, uint32_t nrefr)
@@ -820,7 +869,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin
             in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
             in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
             in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.node = dd.z; in.sample = dd.w;
-            if (in.kind == KIND_REFRACT) nrefr++; else nrefl++;
+            if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
         }
         shade_path<MODEL>(C, in, active, stack, cnt);
     }
@@ -1476,6 +1525,7 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
     A.max_sample = max_sample; A.mode = mode; A.rays = rays;
     const int grid = grid_for((unsigned long long)npix * ns, RT_BLOCK, max_blocks);
     if (P.shade_model == RT_SHADE_P13) hipLaunchKernelGGL(k_primary<RT_SHADE_P13>, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
+    else if (P.shade_model == RT_SHADE_P12) hipLaunchKernelGGL(k_primary<RT_SHADE_P12>, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
     else hipLaunchKernelGGL(k_primary<RT_SHADE_FIN>, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
 }
 
@@ -1485,6 +1535,7 @@ void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, cons
 {
     ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
     if (P.shade_model == RT_SHADE_P13) hipLaunchKernelGGL(k_bounce<RT_SHADE_P13>, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
+    else if (P.shade_model == RT_SHADE_P12) hipLaunchKernelGGL(k_bounce<RT_SHADE_P12>, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
     else hipLaunchKernelGGL(k_bounce<RT_SHADE_FIN>, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
 }
 
@@ -1492,7 +1543,7 @@ void rtk_launch_trace(hipStream_t st, const DevScene &S, int model, const float 
                       uint8_t *hit, float *z, float *p, float *N, int32_t *node, uint8_t *front)
 {
     const int grid = grid_for((unsigned long long)n, RT_BLOCK, 4096);
-    if (model == RT_SHADE_P13) hipLaunchKernelGGL(k_trace<RT_SHADE_P13>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
+    if (model != RT_SHADE_FIN) hipLaunchKernelGGL(k_trace<RT_SHADE_P13>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
     else hipLaunchKernelGGL(k_trace<RT_SHADE_FIN>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
 }
 

@@ -289,6 +289,34 @@ def test_soft_shadows_and_glossy_with_counter_rng(cornell, model):
     assert (np.abs(rgb2 - rgb).max(axis=1) > 1e-4).mean() > 0.01
 
 
+def test_p12_live_gi_model(cornell):
+    """RayTracingProj12 semantics (BASELINE config 3): P13's ray tree + cosine-hemisphere GI rays at every
+    hit (HEMISPHERE_SAMPLE at the primary hit, 1 below), all = ambient + (direct/pi + idr)*Kd, BOUNCE 8.
+    Same counter RNG on both sides -> ray-by-ray agreement; long diffuse chains amplify libm ulps."""
+    s, cam, e = cornell
+    osc = scenes.oracle_scene(e)
+    # (the oracle walks the reference's full 3^bounce tree, zero-weight children included: keep it small)
+    p = capi.default_params(shade_model=capi.SHADE_P12, bounce=5, hemisphere_sample=3, seed=1212,
+                            min_sample=4, max_sample=8, threshold=1e-2)
+    rays = _aimed_rays(cam, 31, n_cam=600)[::2]
+    ohit, orgb, oz = orc.shade_rays(osc, scenes.oracle_params(p), rays)
+    hit, rgb, z = s.shade_rays(p, rays)
+    assert (hit == ohit).all() and z.tobytes() == oz.tobytes()
+    ok = _close(rgb, orgb, rel=2e-4, abs_=1e-5).all(axis=1)
+    assert ok.mean() > 0.97, (~ok).sum()
+    assert abs(rgb.mean() / orgb.mean() - 1) < 2e-3
+    # indirect light is really there: brighter than the same rays without GI rays (bounce 0)
+    _, rgb0, _ = s.shade_rays(capi.default_params(shade_model=capi.SHADE_P12, bounce=0), rays)
+    assert rgb.mean() > 1.2 * rgb0.mean()
+    # small adaptive frame
+    s2, cam2 = scenes.load_cornell(48, 36)
+    p.hemisphere_sample = 1
+    frame, z2, cnt, st, _ = s2.render(cam2, p)
+    oframe, oz2, ocnt = orc.render(osc, scenes.oracle_camera(cam2), scenes.oracle_params(p))
+    diff = np.abs(frame.astype(int) - oframe.astype(int)).max(axis=2)
+    assert (diff <= 1).mean() > 0.97 and (diff <= 4).mean() > 0.995 and (z2 == oz2).mean() > 0.999
+
+
 def test_depth_of_field_frame(cornell):
     """camera.dof: per-pixel lens table + per-sample pick (FIN/main.cpp:246-262, 283-291)"""
     s0, cam0, e = cornell
