@@ -23,6 +23,9 @@
 #ifndef RT_GATHER_UNROLL
 #define RT_GATHER_UNROLL 1
 #endif
+#ifndef RT_GATHER_CACHE
+#define RT_GATHER_CACHE 16     // leaves whose per-lane distances are kept in registers between the passes
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // float3 algebra in the reference's evaluation order (cyPoint.h:259-350, cyMatrix.h:542-546)
@@ -1148,10 +1151,10 @@ __device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuer
 // lanes, same leaf) so it may use ballots.  RT_GATHER_UNROLL leaves are fetched per step (more
 // loads in flight per lane vs. registers/occupancy; measured on MI355X: 1 beats 4).
 template <class F>
-__device__ __forceinline__ void scan_leaves(const DevPhotonMap &pm, const uint16_t *list, uint32_t n_iter,
+__device__ __forceinline__ void scan_leaves(const DevPhotonMap &pm, const uint16_t *list, uint32_t it0, uint32_t n_iter,
                                             int lane, const GatherQuery &Q, F &&f)
 {
-    uint32_t it = 0;
+    uint32_t it = it0;
 #if RT_GATHER_UNROLL >= 2
     for (; it + 2 <= n_iter; it += 2) {
         const size_t s0 = (size_t)list[it] * RT_LEAF_PHOTONS + lane, s1 = (size_t)list[it + 1] * RT_LEAF_PHOTONS + lane;
@@ -1258,17 +1261,21 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 }
                 n_rounds++; n_slow += slow ? 1u : 0u; n_reads += n_iter;
                 // run one pass over the query's leaves, from the LDS list or from the spill list
-                auto for_each = [&](auto &&f) {
-                    if (slow) scan_leaves(G.pm, spill, n_iter, lane, Q, f);
-                    else scan_leaves(G.pm, L.leaves[q], n_iter, lane, Q, f);
+                auto for_each = [&](uint32_t from, auto &&f) {
+                    if (slow) scan_leaves(G.pm, spill, from, n_iter, lane, Q, f);
+                    else scan_leaves(G.pm, L.leaves[q], from, n_iter, lane, Q, f);
                 };
+                // the squared distances of the first RT_GATHER_CACHE leaves stay in registers (the loops
+                // over them are fully unrolled) so that pass 2 neither reloads nor re-tests those photons
+                float d2c[RT_GATHER_CACHE];
+                const uint32_t n_cached = slow ? 0u : min(n_iter, (uint32_t)RT_GATHER_CACHE);
 
                 float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // sums over ALL candidates
                 uint32_t my_cnt = 0;
                 for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                 wave_sync();
                 // pass 1
-                for_each([&](const Cand &cd, size_t s) {
+                auto pass1 = [&](const Cand &cd, size_t s) {
                     if (cd.ok) {
                         const float2 pc = G.pm.pc[s];
                         s_pr += cd.pb.w; s_pg += pc.x; s_pb += pc.y;
@@ -1277,7 +1284,18 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         atomicAdd(&L.hist[cd.key >> 16], 1u);
                     }
                     visited += 1;
-                });
+                };
+#pragma unroll
+                for (int it = 0; it < RT_GATHER_CACHE; it++) {
+                    d2c[it] = 3.0e38f;
+                    if ((uint32_t)it < n_cached) {
+                        const size_t s0 = (size_t)L.leaves[q][it] * RT_LEAF_PHOTONS + lane;
+                        const Cand cd = make_cand(G.pm.pa[s0], G.pm.pb[s0], Q, true);
+                        pass1(cd, s0);
+                        if (cd.ok) d2c[it] = cd.d2;
+                    }
+                }
+                for_each(n_cached, pass1);
                 const uint32_t M = wave_sum_u(my_cnt);
                 if (!final_round && M <= K) {
                     // not enough inside the trial radius: grow it (count ~ r^2 on a surface) and retry
@@ -1321,7 +1339,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                         wave_sync();
                         const uint32_t hi_mask = ~((1u << (shift + 8)) - 1u) & 0xFFFFFFu;
-                        for_each([&](const Cand &cd, size_t) {
+                        for_each(0u, [&](const Cand &cd, size_t) {
                             if (cd.ok && (cd.key & hi_mask) == prefix) atomicAdd(&L.hist[(cd.key >> shift) & 255u], 1u);
                         });
                     }
@@ -1333,10 +1351,10 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     wave_sync();
                     uint32_t tie_taken = 0;                // only used when in_bin > 64 (identical keys)
                     float tmax = 0.0f;
-                    for_each([&](const Cand &cd, size_t s) {
-                        const uint32_t kb = cd.key & bin_mask;
-                        bool take = cd.ok && kb < prefix;
-                        const bool inb = cd.ok && kb == prefix;
+                    auto pass2 = [&](bool ok, float d2, uint32_t key, size_t s) {
+                        const uint32_t kb = key & bin_mask;
+                        bool take = ok && kb < prefix;
+                        const bool inb = ok && kb == prefix;
                         const unsigned long long mb = __ballot(inb);
                         if (in_bin <= 64u) {
                             if (mb) {
@@ -1346,21 +1364,34 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                                 base = __shfl(base, leader);
                                 if (inb) {
                                     const uint32_t at = base + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                                    if (at < 64u) { L.sel_d[at] = cd.d2; L.sel_i[at] = (uint32_t)s; }
+                                    if (at < 64u) { L.sel_d[at] = d2; L.sel_i[at] = (uint32_t)s; }
                                 }
                             }
                         } else {
                             // more than 64 photons share all 24 key bits: take the first `need` in scan order
                             const uint32_t rank = tie_taken + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                            if (inb && rank < need) { take = true; tmax = fmaxf(tmax, cd.d2); }
+                            if (inb && rank < need) { take = true; tmax = fmaxf(tmax, d2); }
                             tie_taken += (uint32_t)__popcll(mb);
                         }
                         if (take) {
+                            const float4 pa = G.pm.pa[s];
+                            const float4 pb = G.pm.pb[s];
                             const float2 pc = G.pm.pc[s];
-                            s_pr += cd.pb.w; s_pg += pc.x; s_pb += pc.y;
-                            s_dx += cd.pa.w * cd.pb.z; s_dy += cd.pb.x * cd.pb.z; s_dz += cd.pb.y * cd.pb.z;
+                            s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
+                            s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
                         }
-                    });
+                    };
+#pragma unroll
+                    for (int it = 0; it < RT_GATHER_CACHE; it++) {
+                        if ((uint32_t)it < n_cached) {
+                            const float d2 = d2c[it];
+                            const bool ok = d2 < 1.0e38f;
+                            uint32_t key = (uint32_t)(d2 * Q.kscale);
+                            key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
+                            pass2(ok, d2, key, (size_t)L.leaves[q][it] * RT_LEAF_PHOTONS + lane);
+                        }
+                    }
+                    for_each(n_cached, [&](const Cand &cd, size_t s) { pass2(cd.ok, cd.d2, cd.key, s); });
                     wave_sync();
                     if (in_bin <= 64u) {
                         // exact selection: rank by (d2, list position); take ranks < need

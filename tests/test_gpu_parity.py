@@ -85,6 +85,32 @@ def test_trace_nested_synthetic_scene(gold):
         _assert_hits_equal(s.trace_rays(rays, model), hit, hits)
 
 
+def test_trace_100k_triangle_mesh_bit_exact():
+    """stand-in for the absent christmas_balls.obj (BASELINE config 5): 128 tessellated spheres,
+    102 402 triangles, BVH depth 24 -- closest hits must still equal the oracle's exhaustive walk"""
+    from tests import meshgen
+    v, f = meshgen.balls_scene()
+    nodes, el = capi.bvh_build(v, f, 4)
+    vn = np.zeros_like(v)
+    tri_n = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    for k in range(3):
+        np.add.at(vn, f[:, k], tri_n)
+    vn = (vn / np.linalg.norm(vn, axis=1, keepdims=True)).astype(np.float32)
+    s = capi.Scene()
+    s.set_nodes(np.concatenate([scenes.identity_node(), scenes.identity_node(0, capi.OBJ_MESH, 0, 0, scale=1.0)]))
+    s.set_mesh(0, v, f, vn, f, nodes, el)
+    s.set_materials(np.zeros(1, capi.BLINN))
+    osc = scenes.oracle_scene(s.export())
+    rng = np.random.default_rng(8)
+    o = np.stack([rng.uniform(-25, 25, 3000), rng.uniform(-60, -35, 3000), rng.uniform(2, 30, 3000)], 1)
+    tgt = np.stack([rng.uniform(-15, 15, 3000), rng.uniform(-26, 19, 3000), rng.uniform(0, 8, 3000)], 1)
+    rays = np.concatenate([o, tgt - o], 1).astype(np.float32)
+    for model in (capi.SHADE_FIN, capi.SHADE_P13):
+        hit, hits = orc.trace(osc, model, rays)
+        assert hit.mean() > 0.9
+        _assert_hits_equal(s.trace_rays(rays, model), hit, hits)
+
+
 def test_trace_empty_and_missing_everything():
     s = capi.Scene()
     s.set_nodes(scenes.identity_node())
