@@ -112,6 +112,27 @@ typedef struct rt_photon {
     int16_t  dir_x, dir_y;
 } rt_photon;
 
+/* Textures (FIN/include/texture.h, FIN/texture.cpp, FIN/include/scene.h:323-434).
+ * RT_TEX_FILE: width x height RGB8 texels at texel_offset (bytes) of the texel array, sampled
+ * bilinearly with tiling (TextureFile::Sample); RT_TEX_CHECKER: TextureChecker (color1/color2). */
+#define RT_TEX_FILE    1
+#define RT_TEX_CHECKER 2
+typedef struct rt_texture {
+    int32_t  type;
+    int32_t  width, height;
+    uint32_t texel_offset;
+    float    color1[3], color2[3];
+} rt_texture;
+/* TextureMap = a texture reference + a Transformation of the uvw coordinate (scene.h:376-398).
+ * texture: index into the texture array; RT_MAP_NONE = the colour has no map;
+ * RT_MAP_EMPTY = a map whose texture failed to load (samples black, as in the reference). */
+#define RT_MAP_NONE  (-1)
+#define RT_MAP_EMPTY (-2)
+typedef struct rt_texmap {
+    int32_t texture;
+    float   tm[9], itm[9], pos[3];
+} rt_texmap;
+
 /* shading semantics: which snapshot's MtlBlinn::Shade / primitives to follow */
 #define RT_SHADE_FIN 0   /* FIN/main.cpp:516-708 (+ FIN primitives, two-sided triangles)      */
 #define RT_SHADE_P13 1   /* P13/main.cpp:485-756 (+ P13 primitives, back-face-culled tris)    */
@@ -193,6 +214,17 @@ rt_status rt_scene_set_materials(rt_scene *s, const rt_blinn *m, int32_t n);
 rt_status rt_scene_set_lights(rt_scene *s, const rt_light *l, int32_t n);
 /* environment / background colour (FIN/include/scene.h:406-434; textures: not yet) */
 rt_status rt_scene_set_environment(rt_scene *s, const float env_rgb[3], const float bg_rgb[3]);
+/* Texture store (replaces the TextureList global, FIN/main.cpp:46) and the maps of the colours the
+ * render path samples: per material its diffuse and specular maps (MtlBlinn::Shade samples only
+ * those two, FIN/main.cpp:531-532), the environment (SampleEnvironment, :635) and the background
+ * (:328).  maps = 2 * n_materials records: [2m] diffuse, [2m+1] specular. */
+rt_status rt_scene_set_textures(rt_scene *s, const rt_texture *tex, int32_t n, const uint8_t *texels, uint64_t n_bytes);
+rt_status rt_scene_set_material_maps(rt_scene *s, const rt_texmap *maps, int32_t n_materials);
+rt_status rt_scene_set_environment_maps(rt_scene *s, const rt_texmap *environment, const rt_texmap *background);
+rt_status rt_scene_get_textures(const rt_scene *s, rt_texture *tex, int32_t cap, uint8_t *texels, uint64_t texel_cap,
+                                int32_t *n_tex, uint64_t *n_bytes);
+rt_status rt_scene_get_maps(const rt_scene *s, rt_texmap *material_maps, int32_t cap, rt_texmap *environment, rt_texmap *background);
+
 /* Balanced photon array exactly as PhotonMap::photons after PrepareForIrradianceEstimation
  * (FIN/include/cyPhotonMap.h:196-218): photons[0] unused, photons[1..n_stored] heap-ordered.
  * n_stored = 0 clears the map (photon term contributes 0). */
@@ -215,6 +247,12 @@ rt_status rt_scene_mesh_counts(const rt_scene *s, int32_t mesh, int32_t *nv, int
                                int32_t *nvn, int32_t *nnodes);
 rt_status rt_scene_get_mesh(const rt_scene *s, int32_t mesh, float *v, uint32_t *f, float *vn,
                             uint32_t *fn, rt_bvh_node *nodes, uint32_t *elements);
+
+/* Image files: what TextureFile::Load gets from lodepng::decode(..., LCT_RGB) / LoadPPM
+ * (FIN/texture.cpp:33-91) and RenderImage::SavePNG from lodepng::encode (FIN/include/scene.h:645-655).
+ * rt_image_read_rgb with rgb == NULL only reports the size. comps: 1 = grey, 3 = RGB. */
+rt_status rt_image_read_rgb(const char *path, int32_t *w, int32_t *h, uint8_t *rgb, uint64_t cap);
+rt_status rt_image_write_png(const char *path, const uint8_t *data, int32_t w, int32_t h, int32_t comps);
 
 /* ---- host helpers that mirror reference host code --------------------------------------- */
 /* cyBVH build with MeanSplit (FIN/include/cyBVH.h:122-142,295-328) as TriObj::Load calls it

@@ -245,6 +245,74 @@ def gen_photon(tag, npho, k, radius, nq, seed):
     print(f"photon[{tag}]: n={npho} k={k} r={radius} half={half} queries with light: {nz}/{nq}")
 
 
+def write_png_all_filters(path, img):
+    """PNG written here (not by the product): every scanline filter type in turn, zlib level 9
+    (dynamic Huffman) -- exercises the product's own inflate + unfilter against lodepng's."""
+    import zlib
+    h, w, _ = img.shape
+    raw = bytearray()
+    prev = np.zeros(w * 3, np.int32)
+    for y in range(h):
+        cur = img[y].astype(np.int32).ravel()
+        left = np.concatenate([np.zeros(3, np.int32), cur[:-3]])
+        upleft = np.concatenate([np.zeros(3, np.int32), prev[:-3]])
+        ft = y % 5
+        if ft == 0: out = cur
+        elif ft == 1: out = cur - left
+        elif ft == 2: out = cur - prev
+        elif ft == 3: out = cur - (left + prev) // 2
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            out = cur - pred
+        raw.append(ft)
+        raw += bytes((out % 256).astype(np.uint8))
+        prev = cur
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+    comp = zlib.compress(bytes(raw), 9)
+    png += chunk(b"IDAT", comp[: len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(png)
+
+
+def gen_texture():
+    rng = np.random.default_rng(109)
+    h, w = 37, 52
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 5 + yy * 3) % 256, (xx * yy) % 256, 255 - (xx * 7) % 256], 2).astype(np.uint8)
+    img[10:20, 10:30] = rng.integers(0, 256, (10, 20, 3))          # noise: poorly compressible
+    path = os.path.join(GOLD, "texture_52x37.png")
+    write_png_all_filters(path, img)
+    n = 2048
+    uvw = rng.uniform(-2.5, 3.5, (n, 3)).astype(np.float32)
+    uvw[:64, :2] = rng.choice([0.0, 0.5, 1.0, -1.0, 0.25, 0.999999, 1.000001], (64, 2))
+    ops = [(0, 0.25, 0.5, 1.0, 0), (1, 0, 0, 1, 30), (2, 0.1, -0.2, 0, 0)]
+    payload = struct.pack("<i", len(ops))
+    for op in ops:
+        payload += struct.pack("<i4f", int(op[0]), *[float(x) for x in op[1:]])
+    c12 = np.array([0.1, 0.2, 0.3, 0.9, 0.8, 0.7], np.float32)
+    payload += c12.tobytes() + struct.pack("<i", n) + uvw.tobytes()
+    out = run("fin", "tex", payload, path)
+    wi, hi = struct.unpack_from("<2i", out, 0)
+    assert (wi, hi) == (w, h)
+    off = 8
+    def take(count):
+        nonlocal off
+        a = np.frombuffer(out, "<f4", count, off)
+        off += a.nbytes
+        return a
+    texels = take(w * h * 3).reshape(h, w, 3)
+    assert np.array_equal(np.rint(texels * 255).astype(np.uint8), img)       # lodepng decodes what was written
+    np.savez_compressed(os.path.join(GOLD, "texture.npz"), image=img, uvw=uvw, ops=np.array(ops, np.float64), colors=c12,
+                        file_sample=take(n * 3).reshape(n, 3), checker_sample=take(n * 3).reshape(n, 3),
+                        map_transform=take(n * 3).reshape(n, 3), env_coord=take(n * 3).reshape(n, 3))
+    print("texture: 52x37 PNG,", n, "samples")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     for m in ("fin", "p13"):
@@ -257,6 +325,7 @@ def main():
     gen_mesh("p13")
     gen_node()
     gen_misc()
+    gen_texture()
     gen_photon("k400", 12000, 400, 1.0, 384, 106)
     gen_photon("k50", 3001, 50, 1.5, 256, 107)
     gen_photon("k8", 64, 8, 4.0, 64, 108)

@@ -23,9 +23,13 @@ LIGHT = np.dtype([("type", "<i4"), ("intensity", "<f4", 3), ("position", "<f4", 
                   ("direction", "<f4", 3), ("size", "<f4")])
 PHOTON = np.dtype([("position", "<f4", 3), ("power", "<f4"), ("color", "u1", 3),
                    ("plane_and_dirz", "u1"), ("dir_x", "<i2"), ("dir_y", "<i2")])
-HIT = np.dtype([("z", "<f4"), ("p", "<f4", 3), ("N", "<f4", 3), ("node", "<i4"), ("front", "<i4")])
+HIT = np.dtype([("z", "<f4"), ("p", "<f4", 3), ("N", "<f4", 3), ("node", "<i4"), ("front", "<i4"),
+                ("uvw", "<f4", 3)])
+TEXTURE = np.dtype([("type", "<i4"), ("width", "<i4"), ("height", "<i4"), ("texel_offset", "<u4"),
+                    ("color1", "<f4", 3), ("color2", "<f4", 3)])
+TEXMAP = np.dtype([("texture", "<i4"), ("tm", "<f4", 9), ("itm", "<f4", 9), ("pos", "<f4", 3)])
 assert (NODE.itemsize, BVHNODE.itemsize, BLINN.itemsize, LIGHT.itemsize, PHOTON.itemsize,
-        HIT.itemsize) == (100, 28, 88, 44, 24, 36)
+        HIT.itemsize, TEXTURE.itemsize, TEXMAP.itemsize) == (100, 28, 88, 44, 24, 48, 40, 88)
 
 
 class Camera(C.Structure):
@@ -61,7 +65,9 @@ class _Scene(C.Structure):
     _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_int32), ("meshes", C.c_void_p),
                 ("n_meshes", C.c_int32), ("materials", C.c_void_p), ("n_materials", C.c_int32),
                 ("lights", C.c_void_p), ("n_lights", C.c_int32), ("photons", C.c_void_p),
-                ("n_photons", C.c_uint32), ("env", C.c_float * 3), ("bg", C.c_float * 3)]
+                ("n_photons", C.c_uint32), ("env", C.c_float * 3), ("bg", C.c_float * 3),
+                ("textures", C.c_void_p), ("n_textures", C.c_int32), ("texels", C.c_void_p),
+                ("material_maps", C.c_void_p), ("env_map", C.c_void_p), ("bg_map", C.c_void_p)]
 
 
 class Counters(C.Structure):
@@ -115,7 +121,8 @@ class Scene:
     """Holds the numpy arrays alive and exposes an orc_scene."""
 
     def __init__(self, nodes, meshes=(), materials=None, lights=None, photons=None,
-                 env=(0, 0, 0), bg=(0, 0, 0)):
+                 env=(0, 0, 0), bg=(0, 0, 0), textures=None, texels=None, material_maps=None,
+                 env_map=None, bg_map=None):
         self.nodes = _c(nodes, NODE)
         self.meshes = list(meshes)
         self.materials = _c(materials if materials is not None else np.zeros(0, BLINN), BLINN)
@@ -126,6 +133,15 @@ class Scene:
                         len(self.meshes), _p(self.materials), len(self.materials),
                         _p(self.lights), len(self.lights), _p(self.photons),
                         max(0, len(self.photons) - 1), (C.c_float * 3)(*env), (C.c_float * 3)(*bg))
+        self.textures = _c(textures, TEXTURE) if textures is not None else np.zeros(0, TEXTURE)
+        self.texels = _c(texels, np.uint8) if texels is not None else np.zeros(0, np.uint8)
+        self.material_maps = _c(material_maps, TEXMAP) if material_maps is not None else None
+        self.env_map = _c(env_map, TEXMAP).reshape(1) if env_map is not None else None
+        self.bg_map = _c(bg_map, TEXMAP).reshape(1) if bg_map is not None else None
+        self.c.textures, self.c.n_textures, self.c.texels = _p(self.textures), len(self.textures), _p(self.texels)
+        self.c.material_maps = _p(self.material_maps) if self.material_maps is not None else None
+        self.c.env_map = _p(self.env_map) if self.env_map is not None else None
+        self.c.bg_map = _p(self.bg_map) if self.bg_map is not None else None
 
 
 def halton(i, base):
@@ -219,6 +235,33 @@ def shade_rays(scene, params, rays):
             lib().orc_shade(C.byref(scene.c), C.byref(params), _p(rays[i]), _p(h),
                             params.bounce, _p(rgb[i]))
     return hit, rgb, z
+
+
+def texture_sample(texture, texels, uvw):
+    texture = _c(texture, TEXTURE).reshape(1)
+    texels = _c(texels, np.uint8)
+    uvw = _c(uvw, np.float32).reshape(-1, 3)
+    out = np.zeros_like(uvw)
+    for i in range(len(uvw)):
+        lib().orc_texture_sample(_p(texture), _p(texels), _p(uvw[i]), _p(out[i]))
+    return out
+
+
+def texmap_transform(texmap, uvw):
+    texmap = _c(texmap, TEXMAP).reshape(1)
+    uvw = _c(uvw, np.float32).reshape(-1, 3)
+    out = np.zeros_like(uvw)
+    for i in range(len(uvw)):
+        lib().orc_texmap_transform(_p(texmap), _p(uvw[i]), _p(out[i]))
+    return out
+
+
+def environment_coord(dirs):
+    dirs = _c(dirs, np.float32).reshape(-1, 3)
+    out = np.zeros_like(dirs)
+    for i in range(len(dirs)):
+        lib().orc_environment_coord(_p(dirs[i]), _p(out[i]))
+    return out
 
 
 def photon_pack(pos, dirn, power):

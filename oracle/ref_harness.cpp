@@ -31,6 +31,7 @@
 #include "scene.h"
 #include "objects.h"
 #include "cyPhotonMap.h"
+#include "texture.h"
 
 // the reference declares these as globals in main.cpp; objects.h has `extern` declarations only
 Sphere theSphere;
@@ -277,6 +278,57 @@ static int cmd_photon(const char *in, const char *out)
     return 0;
 }
 
+// Texture that returns the coordinate it is asked for: shows what TextureMap / SampleEnvironment compute
+struct ProbeTexture : public Texture { Color Sample(const Point3 &uvw) const { return Color(uvw.x, uvw.y, uvw.z); } };
+
+// tex <in.bin> <out.bin> <image.png|ppm>
+// in: int32 nops; nops x {int32 kind; float a[4]} (TextureMap transform, as cmd_node); float c1[3], c2[3];
+//     int32 n; n x float uvw[3]
+// out: int32 w, h; w*h x float rgb[3] (texels, via Sample at texel origins);
+//      n x float rgb[3] TextureFile::Sample(uvw); n x rgb TextureChecker::Sample(uvw);
+//      n x float[3] TextureMap::TransformTo(uvw); n x float[3] coordinate SampleEnvironment(uvw as dir) looks up
+static int cmd_tex(const char *in, const char *out, const char *image)
+{
+    std::vector<char> b = slurp(in);
+    const char *c = b.data();
+    int32_t nops = *(int32_t *)c; c += 4;
+    ProbeTexture probe;
+    TextureMap *map = new TextureMap(&probe);
+    for (int i = 0; i < nops; i++) {
+        int32_t kind = *(int32_t *)c; c += 4;
+        const float *a = (const float *)c; c += 16;
+        if (kind == 0) map->Scale(a[0], a[1], a[2]);
+        else if (kind == 1) { Point3 s(a[0], a[1], a[2]); s.Normalize(); map->Rotate(s, a[3]); }
+        else map->Translate(Point3(a[0], a[1], a[2]));
+    }
+    const float *cc = (const float *)c; c += 24;
+    int32_t n = *(int32_t *)c; c += 4;
+    const float *uvw = (const float *)c;
+    TextureFile *tf = (TextureFile *)calloc(1, sizeof(TextureFile));   // no vtable exists for it (see header note)
+    new ((void *)&((char *)tf)[0]) ItemBase();                            // name storage only
+    tf->SetName(image);
+    if (!tf->TextureFile::Load()) { fprintf(stderr, "cannot load %s\n", image); return 3; }
+    // width/height are private: recover them by probing the tiling period is overkill -- lodepng again
+    unsigned w = 0, h = 0;
+    { std::vector<unsigned char> d; lodepng::decode(d, w, h, image, LCT_RGB); }
+    Out o(out);
+    int32_t wi = (int32_t)w, hi = (int32_t)h;
+    o.put(wi); o.put(hi);
+    for (unsigned y = 0; y < h; y++) for (unsigned x = 0; x < w; x++) {
+        Color t = tf->TextureFile::Sample(Point3((x + 0.0f) / w, (y + 0.0f) / h, 0));
+        o.put(t.r); o.put(t.g); o.put(t.b);
+    }
+    for (int i = 0; i < n; i++) { Color t = tf->TextureFile::Sample(Point3(uvw[3 * i], uvw[3 * i + 1], uvw[3 * i + 2])); o.put(t.r); o.put(t.g); o.put(t.b); }
+    TextureChecker *tc = (TextureChecker *)calloc(1, sizeof(TextureChecker));
+    tc->SetColor1(Color(cc[0], cc[1], cc[2])); tc->SetColor2(Color(cc[3], cc[4], cc[5]));
+    for (int i = 0; i < n; i++) { Color t = tc->TextureChecker::Sample(Point3(uvw[3 * i], uvw[3 * i + 1], uvw[3 * i + 2])); o.put(t.r); o.put(t.g); o.put(t.b); }
+    for (int i = 0; i < n; i++) { Point3 t = map->TransformTo(Point3(uvw[3 * i], uvw[3 * i + 1], uvw[3 * i + 2])); o.put(t.x); o.put(t.y); o.put(t.z); }
+    TexturedColor env(1, 1, 1);
+    env.SetTexture(new TextureMap(&probe));
+    for (int i = 0; i < n; i++) { Color t = env.SampleEnvironment(Point3(uvw[3 * i], uvw[3 * i + 1], uvw[3 * i + 2])); o.put(t.r); o.put(t.g); o.put(t.b); }
+    return 0;
+}
+
 // time <in.bin> <out.bin>: same input as `photon`; prints seconds spent in the nq queries (k=400)
 static int cmd_time(const char *in, const char *out)
 {
@@ -294,6 +346,7 @@ int main(int argc, char **argv)
     if (cmd == "node") return cmd_node(argv[2], argv[3]);
     if (cmd == "misc") return cmd_misc(argv[2], argv[3]);
     if (cmd == "photon") return cmd_photon(argv[2], argv[3]);
+    if (cmd == "tex") { if (argc < 5) return 1; return cmd_tex(argv[2], argv[3], argv[4]); }
     if (cmd == "time") return cmd_time(argv[2], argv[3]);
     fprintf(stderr, "unknown command %s\n", cmd.c_str());
     return 1;

@@ -121,8 +121,15 @@ void orc_color24(const float rgb[3], uint8_t out[3])
 }
 
 /* ---- primitives -------------------------------------------------------------------------- */
-/* Sphere::IntersectRay, FIN/include/objects.h:24-70 (identical in P13/include/objects.h:23-69).
- * uvw is not produced (no textures on this path yet). */
+/* sphere texture coordinate, FIN/include/objects.h:49-51: atan2/asin on floats promote to double */
+static void sphere_uvw(v3 p, float uvw[3])
+{
+    uvw[0] = (float)(0.5 - atan2(p.x, p.y) / (2 * M_PI));
+    uvw[1] = (float)(0.5 + asin(p.z) / M_PI);
+    uvw[2] = 0;
+}
+
+/* Sphere::IntersectRay, FIN/include/objects.h:24-70 (identical in P13/include/objects.h:23-69). */
 int orc_sphere_intersect(int model, const float ray[6], orc_hit *hit)
 {
     (void)model;
@@ -146,6 +153,7 @@ int orc_sphere_intersect(int model, const float ray[6], orc_hit *hit)
             v3 p = vadd(vscale(rd, hit->z), rp);          /* hitinfo.z*ray.dir+ray.p */
             st3(hit->p, p);
             st3(hit->N, vnorm(p));
+            sphere_uvw(p, hit->uvw);
         } else if (t1 > zero && t2 > zero && t2 < prez) {
             behitted = 1;
             hit->z = min_t;
@@ -153,6 +161,7 @@ int orc_sphere_intersect(int model, const float ray[6], orc_hit *hit)
             v3 p = vadd(vscale(rd, hit->z), rp);
             st3(hit->p, p);
             st3(hit->N, vnorm(p));
+            sphere_uvw(p, hit->uvw);
         }
     }
     return behitted;
@@ -173,6 +182,7 @@ int orc_plane_intersect(int model, const float ray[6], orc_hit *hit)
             st3(hit->p, Hitp);
             st3(hit->N, N);
             float nd = vdot(N, d);
+            hit->uvw[0] = (Hitp.x + 1) / 2; hit->uvw[1] = (Hitp.y + 1) / 2; hit->uvw[2] = 0;      /* :103 */
             if (model != RT_SHADE_FIN) hit->front = (nd < 0.0f) ? 0 : 1;
             else                       hit->front = (nd <= 0.0f) ? 1 : 0;
             return 1;
@@ -388,6 +398,7 @@ static void hit_init(orc_hit *h)
     /* HitInfo::Init, FIN/include/scene.h:163 */
     memset(h, 0, sizeof *h);
     h->z = BIGFLOAT; h->node = -1; h->front = 1;
+    h->uvw[0] = h->uvw[1] = h->uvw[2] = 0.5f;
 }
 
 int orc_trace(const orc_scene *s, int model, const float ray[6], orc_hit *hit)
@@ -510,6 +521,91 @@ void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
     st3(out, vdivs(vscale(I, shadow), vlen2(vsub(p, position))));
 }
 
+/* ---- textures ------------------------------------------------------------------------------- */
+/* Texture::TileClamp, FIN/include/scene.h:356-366 */
+static v3 tile_clamp(v3 uvw)
+{
+    v3 u;
+    u.x = uvw.x - (int)uvw.x; u.y = uvw.y - (int)uvw.y; u.z = uvw.z - (int)uvw.z;
+    if (u.x < 0) u.x += 1;
+    if (u.y < 0) u.y += 1;
+    if (u.z < 0) u.z += 1;
+    return u;
+}
+/* TextureFile::Sample (FIN/texture.cpp:95-121), TextureChecker::Sample (:125-133) */
+void orc_texture_sample(const rt_texture *t, const uint8_t *texels, const float uvw_[3], float rgb[3])
+{
+    v3 u = tile_clamp(v3p(uvw_));
+    if (t->type == RT_TEX_CHECKER) {
+        const float *c = (u.x <= 0.5f) ? (u.y <= 0.5f ? t->color1 : t->color2) : (u.y <= 0.5f ? t->color2 : t->color1);
+        rgb[0] = c[0]; rgb[1] = c[1]; rgb[2] = c[2];
+        return;
+    }
+    int width = t->width, height = t->height;
+    if (width + height == 0) { rgb[0] = rgb[1] = rgb[2] = 0; return; }
+    const uint8_t *data = texels + t->texel_offset;
+    float x = width * u.x;
+    float y = height * u.y;
+    int ix = (int)x;
+    int iy = (int)y;
+    float fx = x - ix;
+    float fy = y - iy;
+    if (ix < 0) ix -= (ix / width - 1) * width;
+    if (ix >= width) ix -= (ix / width) * width;
+    int ixp = ix + 1;
+    if (ixp >= width) ixp -= width;
+    if (iy < 0) iy -= (iy / height - 1) * height;
+    if (iy >= height) iy -= (iy / height) * height;
+    int iyp = iy + 1;
+    if (iyp >= height) iyp -= height;
+#define TEXEL(X, Y) V3(data[3 * ((Y) * width + (X))] / 255.0f, data[3 * ((Y) * width + (X)) + 1] / 255.0f, data[3 * ((Y) * width + (X)) + 2] / 255.0f)
+    v3 r = vadd(vadd(vadd(vscale(TEXEL(ix, iy), (1 - fx) * (1 - fy)), vscale(TEXEL(ixp, iy), fx * (1 - fy))),
+                     vscale(TEXEL(ix, iyp), (1 - fx) * fy)), vscale(TEXEL(ixp, iyp), fx * fy));
+#undef TEXEL
+    st3(rgb, r);
+}
+/* TextureMap: Transformation::TransformTo(uvw) = itm * (uvw - pos), scene.h:236,383 */
+void orc_texmap_transform(const rt_texmap *m, const float uvw[3], float out[3])
+{
+    st3(out, mmul(m->itm, vsub(v3p(uvw), v3p(m->pos))));
+}
+/* the coordinate TexturedColor::SampleEnvironment looks up, scene.h:426-432 */
+void orc_environment_coord(const float dir[3], float uvw[3])
+{
+    float z = asinf(-dir[2]) / (float)M_PI + 0.5f;
+    float x = dir[0] / (fabsf(dir[0]) + fabsf(dir[1]));
+    float y = dir[1] / (fabsf(dir[0]) + fabsf(dir[1]));
+    /* Point3(0.5,0.5,0) + z*(x*Point3(0.5,0.5,0) + y*Point3(-0.5,0.5,0)) */
+    v3 a = vadd(vscale(V3(0.5f, 0.5f, 0), x), vscale(V3(-0.5f, 0.5f, 0), y));
+    st3(uvw, vadd(V3(0.5f, 0.5f, 0.0f), vscale(a, z)));
+}
+/* TexturedColor::Sample(uvw[,duvw]) with duvw == 0 (scene.h:331-334,383-392,422-423) */
+void orc_textured_color(const orc_scene *s, const float color[3], const rt_texmap *map, const float uvw[3], float out[3])
+{
+    if (!map || map->texture == RT_MAP_NONE) { out[0] = color[0]; out[1] = color[1]; out[2] = color[2]; return; }
+    float t[3] = {0, 0, 0};
+    if (map->texture >= 0 && map->texture < s->n_textures) {
+        float u[3];
+        orc_texmap_transform(map, uvw, u);
+        orc_texture_sample(&s->textures[map->texture], s->texels, u, t);
+    }
+    out[0] = color[0] * t[0]; out[1] = color[1] * t[1]; out[2] = color[2] * t[2];
+}
+static v3 environment_color(const orc_scene *s, v3 dir)
+{
+    float uvw[3], c[3];
+    orc_environment_coord((const float *)&dir, uvw);
+    orc_textured_color(s, s->env, s->env_map, uvw, c);
+    return v3p(c);
+}
+static void material_colors(const orc_scene *s, const orc_hit *h, const rt_blinn *m, v3 *kd, v3 *ks)
+{
+    int mi = s->nodes[h->node].material;
+    float c[3];
+    orc_textured_color(s, m->diffuse, s->material_maps ? &s->material_maps[2 * mi] : 0, h->uvw, c); *kd = v3p(c);
+    orc_textured_color(s, m->specular, s->material_maps ? &s->material_maps[2 * mi + 1] : 0, h->uvw, c); *ks = v3p(c);
+}
+
 /* Attenuation, FIN/include/materials.h:60-66 (exp(float) -> expf, see header note) */
 static v3 attenuation(v3 absorption, float l)
 {
@@ -541,7 +637,8 @@ static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6]
     const v3 p = v3p(hInfo->p);
     v3 N = vnorm(v3p(hInfo->N));                                           /* :521-522 */
     v3 direction = vnorm(vneg(v3p(ray + 3)));                              /* :523-524 */
-    v3 kd = v3p(mtl->diffuse), ks = v3p(mtl->specular);
+    v3 kd, ks;
+    material_colors(s, hInfo, mtl, &kd, &ks);                              /* diffuse/specular .Sample(uvw, duvw) :531-532 */
     float gloss = mtl->glossiness;
     v3 reflection = v3p(mtl->reflection), refraction = v3p(mtl->refraction);
     float ior = mtl->ior;
@@ -621,7 +718,7 @@ static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6]
             g_rng.node = me;
             color = vadd(color, vmul(K, v3p(c)));
         } else {
-            color = vadd(color, vmul(tK, v3p(s->env)));                    /* SampleEnvironment, no texture */
+            color = vadd(color, vmul(tK, environment_color(s, vnorm(tDir))));  /* environment.SampleEnvironment(tRay.dir) */
         }
     }
     v3 idr = V3(0, 0, 0);
@@ -654,7 +751,8 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
     v3 ra_color = V3(0, 0, 0), re_color = V3(0, 0, 0), re_ra_color;
     v3 ambient_color = V3(0, 0, 0), diffuse_color = V3(0, 0, 0);
     v3 N = v3p(hInfo->N), Pp = v3p(hInfo->p);
-    v3 Kd = v3p(m->diffuse), Ks = v3p(m->specular);
+    v3 Kd, Ks;
+    material_colors(s, hInfo, m, &Kd, &Ks);
     float alpha = m->glossiness;
     for (int i = 0; i < s->n_lights; i++) {
         const rt_light *l = &s->lights[i];
@@ -708,7 +806,7 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
                     shade_p13(s, P, r, &hh, bounceCount - 1, c);
                     g_rng.node = me;
                     ic = v3p(c);
-                } else ic = v3p(s->env);
+                } else ic = environment_color(s, v3p(r + 3));
                 ic = vscale(ic, dotN_wi);
                 idr = vadd(idr, vdivs(vscale(ic, 1.0f), (float)Nof));
             }
@@ -741,7 +839,7 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
             shade_p13(s, P, r, &hh, bounceCount - 1, c);
             g_rng.node = me;
             re_color = v3p(c);
-        } else re_color = v3p(s->env);
+        } else re_color = environment_color(s, v3p(r + 3));
     }
     all = vadd(all, vmul(re_color, v3p(m->reflection)));                              /* :665 */
     if (bounceCount > 0) {                                                            /* :671-751 */
@@ -783,7 +881,7 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
                 shade_p13(s, P, r, &hh, bounceCount - 1, c);
                 g_rng.node = me;
                 ra_color = v3p(c);
-            } else ra_color = v3p(s->env);
+            } else ra_color = environment_color(s, v3p(r + 3));
             absorb = expf(-m->absorption[0] * hh.z);                                  /* :728 */
             R0 = (n1 - n2) / (n1 + n2);
             R0 = R0 * R0;
@@ -1288,7 +1386,9 @@ void orc_render(const orc_scene *s, const rt_camera *cam, const rt_params *P,
             zbuf[index] = hitz;
         } else {
             float ig = (float)(1.0 / (double)P->gamma);
-            g[0] = powf(s->bg[0], ig); g[1] = powf(s->bg[1], ig); g[2] = powf(s->bg[2], ig);
+            float uvw[3] = { (float)x / cam->width, (float)y / cam->height, 0 }, bgc[3];      /* :326-328 */
+            orc_textured_color(s, s->bg, s->bg_map, uvw, bgc);
+            g[0] = powf(bgc[0], ig); g[1] = powf(bgc[1], ig); g[2] = powf(bgc[2], ig);
             orc_color24(g, &rgb8[3 * (size_t)index]);
             zbuf[index] = BIGFLOAT;
             count[index] = 0;

@@ -43,11 +43,16 @@ typedef struct orc_scene {
     const rt_light *lights;     int32_t n_lights;
     const rt_photon *photons;   uint32_t n_photons;   /* balanced, [0] unused */
     float env[3], bg[3];
+    /* textures (all optional) */
+    const rt_texture *textures; int32_t n_textures; const uint8_t *texels;
+    const rt_texmap *material_maps;                   /* 2 per material (diffuse, specular) or NULL */
+    const rt_texmap *env_map, *bg_map;                /* NULL = none */
 } orc_scene;
 
 typedef struct orc_hit {
     float z; float p[3]; float N[3];
     int32_t node; int32_t front;
+    float uvw[3];
 } orc_hit;
 
 typedef struct orc_counters {
@@ -80,6 +85,13 @@ void  orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
                      const float p[3], const float N[3], float out[3]);
 void  orc_shade(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h,
                 int bounce, float out[3]);
+
+/* textures */
+void  orc_texture_sample(const rt_texture *t, const uint8_t *texels, const float uvw[3], float rgb[3]);
+void  orc_texmap_transform(const rt_texmap *m, const float uvw[3], float out[3]);
+void  orc_environment_coord(const float dir[3], float uvw[3]);
+/* TexturedColor::Sample(uvw): color, or color * map sample */
+void  orc_textured_color(const orc_scene *s, const float color[3], const rt_texmap *map, const float uvw[3], float out[3]);
 
 /* photon map */
 void  orc_photon_pack(const float pos[3], const float dir[3], const float power[3], rt_photon *out);

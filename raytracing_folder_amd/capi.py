@@ -25,7 +25,12 @@ LIGHT = np.dtype([("type", "<i4"), ("intensity", "<f4", 3), ("position", "<f4", 
                   ("direction", "<f4", 3), ("size", "<f4")])
 PHOTON = np.dtype([("position", "<f4", 3), ("power", "<f4"), ("color", "u1", 3),
                    ("plane_and_dirz", "u1"), ("dir_x", "<i2"), ("dir_y", "<i2")])
-assert (NODE.itemsize, BVHNODE.itemsize, BLINN.itemsize, LIGHT.itemsize, PHOTON.itemsize) == (100, 28, 88, 44, 24)
+TEXTURE = np.dtype([("type", "<i4"), ("width", "<i4"), ("height", "<i4"), ("texel_offset", "<u4"),
+                    ("color1", "<f4", 3), ("color2", "<f4", 3)])
+TEXMAP = np.dtype([("texture", "<i4"), ("tm", "<f4", 9), ("itm", "<f4", 9), ("pos", "<f4", 3)])
+assert (NODE.itemsize, BVHNODE.itemsize, BLINN.itemsize, LIGHT.itemsize, PHOTON.itemsize,
+        TEXTURE.itemsize, TEXMAP.itemsize) == (100, 28, 88, 44, 24, 40, 88)
+TEX_FILE, TEX_CHECKER, MAP_NONE, MAP_EMPTY = 1, 2, -1, -2
 
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3
 LIGHT_AMBIENT, LIGHT_DIRECT, LIGHT_POINT = 0, 1, 2
@@ -67,7 +72,8 @@ SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_params_default",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_set_nodes", "rt_scene_set_mesh",
     "rt_scene_set_materials", "rt_scene_set_lights", "rt_scene_set_environment",
-    "rt_scene_set_photons", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
+    "rt_scene_set_photons", "rt_scene_set_textures", "rt_scene_set_material_maps", "rt_scene_set_environment_maps",
+    "rt_scene_get_textures", "rt_scene_get_maps", "rt_image_read_rgb", "rt_image_write_png", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
     "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
     "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photon_pass", "rt_render_begin",
     "rt_render_tiles_device", "rt_render_progress", "rt_render_stop", "rt_render_wait",
@@ -137,6 +143,28 @@ def bvh_build(v, f, max_per_leaf=4):
     return nodes[:n.value].copy(), el
 
 
+def image_read_rgb(path):
+    w, h = C.c_int32(), C.c_int32()
+    _check(lib().rt_image_read_rgb(os.fsencode(path), C.byref(w), C.byref(h), None, C.c_uint64(0)))
+    rgb = np.zeros((h.value, w.value, 3), np.uint8)
+    _check(lib().rt_image_read_rgb(os.fsencode(path), C.byref(w), C.byref(h), _p(rgb), C.c_uint64(rgb.size)))
+    return rgb
+
+
+def image_write_png(path, data):
+    data = np.ascontiguousarray(data, np.uint8)
+    comps = 1 if data.ndim == 2 else data.shape[2]
+    _check(lib().rt_image_write_png(os.fsencode(path), _p(data), data.shape[1], data.shape[0], comps))
+
+
+def identity_map(texture=MAP_NONE):
+    m = np.zeros(1, TEXMAP)
+    m["texture"] = texture
+    m["tm"][0, [0, 4, 8]] = 1
+    m["itm"][0, [0, 4, 8]] = 1
+    return m
+
+
 def photon_balance(photons_1based):
     a = _c(photons_1based, PHOTON).copy()
     out = np.zeros_like(a)
@@ -187,6 +215,20 @@ class Scene:
         e, b = (C.c_float * 3)(*env), (C.c_float * 3)(*bg)
         _check(lib().rt_scene_set_environment(self._h, e, b))
 
+    def set_textures(self, textures, texels):
+        textures, texels = _c(textures, TEXTURE), _c(texels, np.uint8)
+        _check(lib().rt_scene_set_textures(self._h, _p(textures), len(textures), _p(texels), C.c_uint64(texels.size)))
+
+    def set_material_maps(self, maps):
+        maps = _c(maps, TEXMAP)
+        assert len(maps) % 2 == 0
+        _check(lib().rt_scene_set_material_maps(self._h, _p(maps), len(maps) // 2))
+
+    def set_environment_maps(self, environment=None, background=None):
+        e = _c(environment, TEXMAP).reshape(1) if environment is not None else None
+        b = _c(background, TEXMAP).reshape(1) if background is not None else None
+        _check(lib().rt_scene_set_environment_maps(self._h, _p(e) if e is not None else None, _p(b) if b is not None else None))
+
     def set_photons(self, balanced_1based):
         if balanced_1based is None or len(balanced_1based) < 2:
             _check(lib().rt_scene_set_photons(self._h, None, C.c_uint32(0)))
@@ -231,7 +273,15 @@ class Scene:
             _check(lib().rt_scene_get_mesh(self._h, m, _p(d["v"]), _p(d["f"]), _p(d["vn"]), _p(d["fn"]),
                                            _p(d["nodes"]), _p(d["elements"])))
             meshes.append(d)
-        return dict(nodes=nodes, materials=mats, lights=lights, meshes=meshes)
+        ntex, nbytes = C.c_int32(), C.c_uint64()
+        _check(lib().rt_scene_get_textures(self._h, None, 0, None, C.c_uint64(0), C.byref(ntex), C.byref(nbytes)))
+        textures, texels = np.zeros(ntex.value, TEXTURE), np.zeros(nbytes.value, np.uint8)
+        _check(lib().rt_scene_get_textures(self._h, _p(textures), len(textures), _p(texels), C.c_uint64(texels.size), None, None))
+        maps, env_map, bg_map = np.zeros(2 * len(mats), TEXMAP), np.zeros(1, TEXMAP), np.zeros(1, TEXMAP)
+        _check(lib().rt_scene_get_maps(self._h, _p(maps), len(maps), _p(env_map), _p(bg_map)))
+        has_maps = bool(len(maps)) and bool((maps["tm"] != 0).any() or (maps["texture"] != 0).any())
+        return dict(nodes=nodes, materials=mats, lights=lights, meshes=meshes, textures=textures, texels=texels,
+                    material_maps=maps if has_maps else None, env_map=env_map, bg_map=bg_map)
 
     # -- GPU work -------------------------------------------------------------------------------
     def trace_rays(self, rays, shade_model=SHADE_FIN, device=0):

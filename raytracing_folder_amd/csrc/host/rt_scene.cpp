@@ -50,9 +50,29 @@ void AmbientLight::Lower(rt_light &o) const { memset(&o, 0, sizeof o); o.type = 
 void DirectLight::Lower(rt_light &o) const { memset(&o, 0, sizeof o); o.type = RT_LIGHT_DIRECT; put3(o.intensity, intensity); put3(o.direction, direction); }
 void PointLight::Lower(rt_light &o) const { memset(&o, 0, sizeof o); o.type = RT_LIGHT_POINT; put3(o.intensity, intensity); put3(o.position, position); o.size = size; }
 
+bool TextureFile::Load(std::string *err)
+{
+    data.clear(); width = height = 0;
+    return ReadImageRGB(name.c_str(), width, height, data, err);
+}
+bool TextureFile::Lower(rt_texture &o, std::vector<uint8_t> &texels) const
+{
+    memset(&o, 0, sizeof o);
+    o.type = RT_TEX_FILE; o.width = width; o.height = height; o.texel_offset = (uint32_t)texels.size();
+    texels.insert(texels.end(), data.begin(), data.end());
+    while (texels.size() % 4) texels.push_back(0);
+    return true;
+}
+bool TextureChecker::Lower(rt_texture &o, std::vector<uint8_t> &) const
+{
+    memset(&o, 0, sizeof o);
+    o.type = RT_TEX_CHECKER; put3(o.color1, color1); put3(o.color2, color2);
+    return true;
+}
+
 bool MtlBlinn::Lower(rt_blinn &o) const
 {
-    put3(o.diffuse, diffuse); put3(o.specular, specular); put3(o.reflection, reflection);
+    put3(o.diffuse, diffuse.GetColor()); put3(o.specular, specular.GetColor()); put3(o.reflection, reflection);
     put3(o.refraction, refraction); put3(o.emission, emission); put3(o.absorption, absorption);
     o.glossiness = glossiness; o.ior = ior;
     o.reflection_glossiness = reflectionGlossiness; o.refraction_glossiness = refractionGlossiness;
@@ -391,10 +411,15 @@ TriObj *Scene::FindObj(const std::string &n)
     for (auto &o : objList) if (o.first == n) return o.second.get();
     return nullptr;
 }
+Texture *Scene::FindTexture(const std::string &n)
+{
+    for (auto &t : textureList) if (t && t->name == n) return t.get();
+    return nullptr;
+}
 void Scene::Clear()
 {
-    rootNode.Init(); materials.clear(); lights.clear(); objList.clear();
-    environment = Color(); background = Color(); camera.Init();
+    rootNode.Init(); materials.clear(); lights.clear(); objList.clear(); textureList.clear();
+    environment = TexturedColor(); background = TexturedColor(); camera.Init();
 }
 
 // ---- lowering: Node tree -> rt_node[] in TraceNode's visiting order --------------------------------
@@ -462,6 +487,31 @@ bool Lower(const Scene &scene, SceneData &out, std::string *err)
         if (!m->Lower(b)) { if (err) *err = "material '" + m->name + "' has no device lowering"; return false; }
         out.materials.push_back(b);
     }
+    // textures in TextureList order; maps refer to them by index
+    std::vector<const Texture *> texs;
+    for (auto &t : scene.textureList) {
+        rt_texture r;
+        if (!t->Lower(r, out.texels)) { if (err) *err = "texture '" + t->name + "' has no device lowering"; return false; }
+        out.textures.push_back(r);
+        texs.push_back(t.get());
+    }
+    auto lower_map = [&](const TextureMap *m) {
+        rt_texmap r;
+        memset(&r, 0, sizeof r);
+        r.texture = RT_MAP_NONE;
+        if (!m) return r;
+        r.texture = RT_MAP_EMPTY;
+        for (size_t i = 0; i < texs.size(); i++) if (texs[i] == m->GetTexture()) r.texture = (int32_t)i;
+        memcpy(r.tm, m->GetTransform().data, 36); memcpy(r.itm, m->GetInverseTransform().data, 36);
+        r.pos[0] = m->GetPosition().x; r.pos[1] = m->GetPosition().y; r.pos[2] = m->GetPosition().z;
+        return r;
+    };
+    bool any_map = false;
+    for (const Material *m : L.mats) if (m->DiffuseMap() || m->SpecularMap()) any_map = true;
+    if (any_map)
+        for (const Material *m : L.mats) { out.material_maps.push_back(lower_map(m->DiffuseMap())); out.material_maps.push_back(lower_map(m->SpecularMap())); }
+    out.env_map = lower_map(scene.environment.GetTexture());
+    out.bg_map = lower_map(scene.background.GetTexture());
     for (auto &l : scene.lights) { rt_light r; l->Lower(r); out.lights.push_back(r); }
     const Camera &c = scene.camera;
     rt_camera &rc = out.camera;
@@ -470,8 +520,8 @@ bool Lower(const Scene &scene, SceneData &out, std::string *err)
     rc.up[0] = c.up.x; rc.up[1] = c.up.y; rc.up[2] = c.up.z;
     rc.fov = c.fov; rc.focaldist = c.focaldist; rc.dof = c.dof; rc.width = c.imgWidth; rc.height = c.imgHeight;
     out.has_camera = true;
-    out.env[0] = scene.environment.r; out.env[1] = scene.environment.g; out.env[2] = scene.environment.b;
-    out.bg[0] = scene.background.r; out.bg[1] = scene.background.g; out.bg[2] = scene.background.b;
+    put3(out.env, scene.environment.GetColor());
+    put3(out.bg, scene.background.GetColor());
     return true;
 }
 

@@ -92,6 +92,48 @@ public:
     void InitTransform() { pos = Point3(); tm.SetIdentity(); itm.SetIdentity(); }
 };
 
+// ---- textures (FIN/include/scene.h:323-434, FIN/include/texture.h) ---------------------------------
+class Texture {
+public:
+    std::string name;
+    virtual ~Texture() {}
+    virtual bool Lower(rt_texture &out, std::vector<uint8_t> &texels) const = 0;
+};
+class TextureFile : public Texture {          // PNG / PPM, bilinear + tiling on the device
+public:
+    int width = 0, height = 0;
+    std::vector<uint8_t> data;                // RGB8
+    bool Load(std::string *err = nullptr);    // reads `name`
+    bool Lower(rt_texture &out, std::vector<uint8_t> &texels) const override;
+};
+class TextureChecker : public Texture {
+    Color color1{0, 0, 0}, color2{1, 1, 1};
+public:
+    void SetColor1(const Color &c) { color1 = c; }
+    void SetColor2(const Color &c) { color2 = c; }
+    bool Lower(rt_texture &out, std::vector<uint8_t> &texels) const override;
+};
+// a texture reference plus a transformation of the uvw coordinate
+class TextureMap : public Transformation {
+    Texture *texture;
+public:
+    explicit TextureMap(Texture *tex = nullptr) : texture(tex) {}
+    void SetTexture(Texture *tex) { texture = tex; }
+    const Texture *GetTexture() const { return texture; }
+};
+// a colour that may carry a TextureMap; the sampled value is colour * texture
+class TexturedColor {
+    Color color;
+    std::unique_ptr<TextureMap> map;
+public:
+    TexturedColor() {}
+    TexturedColor(float r, float g, float b) : color(r, g, b) {}
+    void SetColor(const Color &c) { color = c; }
+    void SetTexture(TextureMap *m) { map.reset(m); }
+    Color GetColor() const { return color; }
+    const TextureMap *GetTexture() const { return map.get(); }
+};
+
 // ---- Object plug-ins (FIN/include/scene.h:269-275, objects.h) ----------------------------
 class Material;
 class Object {
@@ -159,13 +201,20 @@ public:
     std::string name;
     virtual ~Material() {}
     virtual bool Lower(rt_blinn &out) const = 0;
+    virtual const TextureMap *DiffuseMap() const { return nullptr; }
+    virtual const TextureMap *SpecularMap() const { return nullptr; }
 };
 class MtlBlinn : public Material {
-    Color diffuse{0.5f, 0.5f, 0.5f}, specular{0.7f, 0.7f, 0.7f}, reflection, refraction, emission, absorption;
+    TexturedColor diffuse{0.5f, 0.5f, 0.5f}, specular{0.7f, 0.7f, 0.7f};
+    Color reflection, refraction, emission, absorption;
     float glossiness = 20.0f, ior = 1, reflectionGlossiness = 0, refractionGlossiness = 0;
 public:
-    void SetDiffuse(Color c) { diffuse = c; }
-    void SetSpecular(Color c) { specular = c; }
+    void SetDiffuse(Color c) { diffuse.SetColor(c); }
+    void SetSpecular(Color c) { specular.SetColor(c); }
+    void SetDiffuseTexture(TextureMap *m) { diffuse.SetTexture(m); }
+    void SetSpecularTexture(TextureMap *m) { specular.SetTexture(m); }
+    const TextureMap *DiffuseMap() const override { return diffuse.GetTexture(); }
+    const TextureMap *SpecularMap() const override { return specular.GetTexture(); }
     void SetGlossiness(float g) { glossiness = g; }
     void SetEmission(Color c) { emission = c; }
     void SetReflection(Color c) { reflection = c; }
@@ -174,7 +223,7 @@ public:
     void SetRefractionIndex(float i) { ior = i; }
     void SetReflectionGlossiness(float g) { reflectionGlossiness = g; }
     void SetRefractionGlossiness(float g) { refractionGlossiness = g; }
-    bool IsPhotonSurface() const { return diffuse.Gray() > 0; }
+    bool IsPhotonSurface() const { return diffuse.GetColor().Gray() > 0; }
     bool Lower(rt_blinn &o) const override;
 };
 
@@ -216,7 +265,9 @@ struct Scene {
     std::vector<std::pair<std::string, std::unique_ptr<TriObj>>> objList;   // ObjFileList
     Sphere theSphere;
     Plane thePlane;
-    Color environment, background;
+    TexturedColor environment, background;
+    std::vector<std::unique_ptr<Texture>> textureList;                       // TextureList
+    Texture *FindTexture(const std::string &n);
     Material *FindMaterial(const std::string &n);
     TriObj *FindObj(const std::string &n);
     void Clear();
@@ -241,6 +292,11 @@ struct SceneData {
     rt_camera camera{};
     float env[3] = {0, 0, 0}, bg[3] = {0, 0, 0};
     bool has_camera = false;
+    std::vector<rt_texture> textures;
+    std::vector<uint8_t> texels;
+    std::vector<rt_texmap> material_maps;      // 2 per material (diffuse, specular); empty = none anywhere
+    rt_texmap env_map, bg_map;                 // texture == RT_MAP_NONE when absent
+    SceneData() { memset(&env_map, 0, sizeof env_map); memset(&bg_map, 0, sizeof bg_map); env_map.texture = bg_map.texture = RT_MAP_NONE; }
 };
 bool Lower(const Scene &scene, SceneData &out, std::string *err);
 
@@ -250,6 +306,8 @@ void BuildMeanSplitBVH(const float *v, const uint32_t *f, unsigned nf, unsigned 
 // PhotonMap::PrepareForIrradianceEstimation (FIN/include/cyPhotonMap.h:196-284)
 void BalancePhotons(rt_photon *in, uint32_t n, rt_photon *out);
 
+// PNG (non-interlaced, 8/16 bit) and binary PPM reader -> RGB8, as TextureFile::Load needs
+bool ReadImageRGB(const char *filename, int &w, int &h, std::vector<uint8_t> &rgb, std::string *err);
 // minimal PNG writer (8-bit grey or RGB, stored deflate blocks) for RenderImage::SavePNG
 bool WritePNG(const char *filename, const uint8_t *data, int width, int height, int comps);
 

@@ -168,6 +168,39 @@ struct Loader {
 
     void Error(const std::string &m) { ok = false; if (err && err->empty()) *err = m; }
 
+    // ReadTexture(TiXmlElement*), FIN/xmlload.cpp:500-530: attribute texture="checkerboard" (children
+    // color1/color2) or a PNG/PPM file name shared through the TextureList; the element's own
+    // scale/rotate/translate children transform the map
+    TextureMap *ReadTexture(const XmlElement &e)
+    {
+        const char *texName = e.Attribute("texture");
+        if (!texName) return nullptr;
+        Texture *tex = nullptr;
+        if (IsStr(texName, "checkerboard")) {
+            std::unique_ptr<TextureChecker> c(new TextureChecker);
+            for (auto &ch : e.children) {
+                if (Is(*ch, "color1")) { Color col(0, 0, 0); ReadColor(*ch, col); c->SetColor1(col); }
+                else if (Is(*ch, "color2")) { Color col(0, 0, 0); ReadColor(*ch, col); c->SetColor2(col); }
+            }
+            c->name = texName;
+            tex = c.get();
+            sc.textureList.push_back(std::move(c));
+        } else {
+            tex = sc.FindTexture(texName);
+            if (!tex) {
+                std::unique_ptr<TextureFile> f(new TextureFile);
+                const std::string n = texName;
+                f->name = (!n.empty() && n[0] == '/') ? n : dir + n;
+                std::string e2;
+                if (!f->Load(&e2)) fprintf(stderr, "rt_mi355x: cannot load texture \"%s\": %s\n", f->name.c_str(), e2.c_str());   // map stays, samples black
+                else { f->name = texName; tex = f.get(); sc.textureList.push_back(std::move(f)); }
+            }
+        }
+        TextureMap *map = new TextureMap(tex);
+        LoadTransform(*map, e);
+        return map;
+    }
+
     // LoadTransform, FIN/xmlload.cpp:265-291
     void LoadTransform(Transformation &t, const XmlElement &e)
     {
@@ -229,8 +262,8 @@ struct Loader {
         for (auto &c : e.children) {
             Color col(1, 1, 1);
             float f = 1;
-            if (Is(*c, "diffuse")) { ReadColor(*c, col); m->SetDiffuse(col); }
-            else if (Is(*c, "specular")) { ReadColor(*c, col); m->SetSpecular(col); }
+            if (Is(*c, "diffuse")) { ReadColor(*c, col); m->SetDiffuse(col); m->SetDiffuseTexture(ReadTexture(*c)); }
+            else if (Is(*c, "specular")) { ReadColor(*c, col); m->SetSpecular(col); m->SetSpecularTexture(ReadTexture(*c)); }
             else if (Is(*c, "glossiness")) { ReadFloat(*c, f); m->SetGlossiness(f); }
             else if (Is(*c, "emission")) { ReadColor(*c, col); m->SetEmission(col); }
             else if (Is(*c, "reflection")) {
@@ -283,8 +316,8 @@ struct Loader {
     void LoadSceneElement(const XmlElement &e)
     {
         for (auto &c : e.children) {
-            if (Is(*c, "background")) { Color col(1, 1, 1); ReadColor(*c, col); sc.background = col; }
-            else if (Is(*c, "environment")) { Color col(1, 1, 1); ReadColor(*c, col); sc.environment = col; }
+            if (Is(*c, "background")) { Color col(1, 1, 1); ReadColor(*c, col); sc.background.SetColor(col); sc.background.SetTexture(ReadTexture(*c)); }
+            else if (Is(*c, "environment")) { Color col(1, 1, 1); ReadColor(*c, col); sc.environment.SetColor(col); sc.environment.SetTexture(ReadTexture(*c)); }
             else if (Is(*c, "object")) LoadNode(sc.rootNode, *c);
             else if (Is(*c, "material")) LoadMaterial(*c);
             else if (Is(*c, "light")) LoadLight(*c);

@@ -27,7 +27,7 @@ void rtk_launch_bounce(hipStream_t, const DevScene &, const DevWork &, const rt_
 void rtk_launch_trace(hipStream_t, const DevScene &, int, const float *, long long, uint8_t *, float *, float *, float *, int32_t *, uint8_t *);
 void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const float4 *, const float4 *, const uint32_t *,
                        uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint16_t *, uint32_t *);
-void rtk_launch_resolve(hipStream_t, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
+void rtk_launch_resolve(hipStream_t, const DevScene &, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
                         float, float, int, const float *, uint8_t *, float *, uint8_t *, int);
 
 #define GATHER_BLOCKS (256 * 4)
@@ -107,7 +107,7 @@ struct DevMeshBufs { DevBuf nodes, tris, tri_face, nrm; };
 struct DeviceState {
     int device = -1;
     bool scene_valid = false, photons_valid = false;
-    DevBuf nodes, objects, meshes, materials, lights, node_material;
+    DevBuf nodes, objects, meshes, materials, lights, node_material, textures, texels, material_maps;
     std::vector<DevMeshBufs> mesh_bufs;
     DevBuf pa, pb, pc, tbox, spill, grid;
     DevScene scene{};
@@ -119,7 +119,7 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     void release()
     {
-        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &pa, &pb, &pc, &tbox, &spill, &grid,
+        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &pc, &tbox, &spill, &grid,
                           &sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); }
         for (int i = 0; i < 2; i++) for (int k = 0; k < 4; k++) rq[i][k].release();
@@ -250,6 +250,93 @@ extern "C" rt_status rt_scene_set_environment(rt_scene *s, const float env[3], c
     if (env) memcpy(s->data.env, env, 12);
     if (bg) memcpy(s->data.bg, bg, 12);
     s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_textures(rt_scene *s, const rt_texture *tex, int32_t n, const uint8_t *texels, uint64_t n_bytes)
+{
+    rt_status st = check_idle(s, "rt_scene_set_textures");
+    if (st) return st;
+    if (n < 0 || (n > 0 && !tex) || (n_bytes > 0 && !texels)) return fail(RT_ERR_ARG, "rt_scene_set_textures: bad array");
+    for (int32_t i = 0; i < n; i++) {
+        if (tex[i].type != RT_TEX_FILE && tex[i].type != RT_TEX_CHECKER) return fail(RT_ERR_ARG, "rt_scene_set_textures: texture %d has unknown type", i);
+        if (tex[i].type == RT_TEX_FILE && (tex[i].width < 0 || tex[i].height < 0 || (uint64_t)tex[i].texel_offset + 3ull * tex[i].width * tex[i].height > n_bytes))
+            return fail(RT_ERR_ARG, "rt_scene_set_textures: texture %d exceeds the texel array", i);
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->data.textures.assign(tex, tex + n);
+    s->data.texels.assign(texels, texels + n_bytes);
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_material_maps(rt_scene *s, const rt_texmap *maps, int32_t n_materials)
+{
+    rt_status st = check_idle(s, "rt_scene_set_material_maps");
+    if (st) return st;
+    if (n_materials < 0 || (n_materials > 0 && !maps)) return fail(RT_ERR_ARG, "rt_scene_set_material_maps: bad array");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->data.material_maps.assign(maps, maps + 2 * (size_t)n_materials);
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_environment_maps(rt_scene *s, const rt_texmap *environment, const rt_texmap *background)
+{
+    rt_status st = check_idle(s, "rt_scene_set_environment_maps");
+    if (st) return st;
+    std::lock_guard<std::mutex> lk(s->mu);
+    rt_texmap none;
+    memset(&none, 0, sizeof none);
+    none.texture = RT_MAP_NONE;
+    s->data.env_map = environment ? *environment : none;
+    s->data.bg_map = background ? *background : none;
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_get_textures(const rt_scene *s, rt_texture *tex, int32_t cap, uint8_t *texels, uint64_t texel_cap,
+                                           int32_t *n_tex, uint64_t *n_bytes)
+{
+    if (!s) return fail(RT_ERR_ARG, "rt_scene_get_textures: scene is NULL");
+    if (n_tex) *n_tex = (int32_t)s->data.textures.size();
+    if (n_bytes) *n_bytes = s->data.texels.size();
+    if (tex) { if ((size_t)cap < s->data.textures.size()) return fail(RT_ERR_ARG, "rt_scene_get_textures: capacity"); if (!s->data.textures.empty()) memcpy(tex, s->data.textures.data(), s->data.textures.size() * sizeof(rt_texture)); }
+    if (texels) { if (texel_cap < s->data.texels.size()) return fail(RT_ERR_ARG, "rt_scene_get_textures: texel capacity"); if (!s->data.texels.empty()) memcpy(texels, s->data.texels.data(), s->data.texels.size()); }
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_get_maps(const rt_scene *s, rt_texmap *material_maps, int32_t cap, rt_texmap *environment, rt_texmap *background)
+{
+    if (!s) return fail(RT_ERR_ARG, "rt_scene_get_maps: scene is NULL");
+    if (material_maps) {
+        if ((size_t)cap < s->data.material_maps.size()) return fail(RT_ERR_ARG, "rt_scene_get_maps: capacity %d < %zu", cap, s->data.material_maps.size());
+        if (!s->data.material_maps.empty()) memcpy(material_maps, s->data.material_maps.data(), s->data.material_maps.size() * sizeof(rt_texmap));
+    }
+    if (environment) *environment = s->data.env_map;
+    if (background) *background = s->data.bg_map;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_image_read_rgb(const char *path, int32_t *w, int32_t *h, uint8_t *rgb, uint64_t cap)
+{
+    if (!path || !w || !h) return fail(RT_ERR_ARG, "rt_image_read_rgb: NULL argument");
+    int iw = 0, ih = 0;
+    std::vector<uint8_t> d;
+    std::string err;
+    if (!rt::ReadImageRGB(path, iw, ih, d, &err)) return fail(RT_ERR_IO, "rt_image_read_rgb(%s): %s", path, err.c_str());
+    *w = iw; *h = ih;
+    if (rgb) {
+        if (cap < d.size()) return fail(RT_ERR_ARG, "rt_image_read_rgb: buffer of %llu bytes, need %zu", (unsigned long long)cap, d.size());
+        memcpy(rgb, d.data(), d.size());
+    }
+    return RT_OK;
+}
+
+extern "C" rt_status rt_image_write_png(const char *path, const uint8_t *data, int32_t w, int32_t h, int32_t comps)
+{
+    if (!path || !data || w <= 0 || h <= 0) return fail(RT_ERR_ARG, "rt_image_write_png: bad argument");
+    if (!rt::WritePNG(path, data, w, h, comps)) return fail(RT_ERR_IO, "rt_image_write_png(%s): cannot write (comps must be 1 or 3)", path);
     return RT_OK;
 }
 
@@ -492,6 +579,22 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
     S.n_nodes = nn; S.n_objects = (int)objs.size(); S.n_meshes = (int)sd.meshes.size();
     S.n_materials = (int)sd.materials.size(); S.n_lights = (int)sd.lights.size();
     memcpy(S.env, sd.env, 12); memcpy(S.bg, sd.bg, 12);
+    // textures and maps
+    for (const rt_texture &t : sd.textures)
+        if (t.type == RT_TEX_FILE && (t.width < 0 || t.height < 0 || (uint64_t)t.texel_offset + 3ull * t.width * t.height > sd.texels.size()))
+            return fail(RT_ERR_ARG, "texture texels out of range");
+    if (!sd.material_maps.empty() && sd.material_maps.size() != 2 * sd.materials.size())
+        return fail(RT_ERR_ARG, "material maps: need 2 per material (%zu given for %zu materials)", sd.material_maps.size(), sd.materials.size());
+    auto check_map = [&](const rt_texmap &m) { return m.texture == RT_MAP_NONE || m.texture == RT_MAP_EMPTY || (m.texture >= 0 && (size_t)m.texture < sd.textures.size()); };
+    for (const rt_texmap &m : sd.material_maps) if (!check_map(m)) return fail(RT_ERR_ARG, "material map refers to texture %d", m.texture);
+    if (!check_map(sd.env_map) || !check_map(sd.bg_map)) return fail(RT_ERR_ARG, "environment/background map refers to a missing texture");
+    if ((st = D->textures.upload(sd.textures.data(), sd.textures.size() * sizeof(rt_texture)))) return st;
+    if ((st = D->texels.upload(sd.texels.data(), sd.texels.size()))) return st;
+    if ((st = D->material_maps.upload(sd.material_maps.data(), sd.material_maps.size() * sizeof(rt_texmap)))) return st;
+    S.textures = (const rt_texture *)D->textures.p; S.texels = (const uint8_t *)D->texels.p; S.n_textures = (int)sd.textures.size();
+    S.material_maps = sd.material_maps.empty() ? nullptr : (const rt_texmap *)D->material_maps.p;
+    S.env_map = sd.env_map; S.bg_map = sd.bg_map;
+    S.use_uvw = sd.material_maps.empty() ? 0 : 1;
     D->scene_valid = true;
     return RT_OK;
 }
@@ -804,7 +907,7 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
         auto timed_resolve = [&](int phase) -> rt_status {
             hipEvent_t r0 = nullptr, r1 = nullptr;
             if (want_stats) { HIP_TRY(hipEventCreate(&r0)); HIP_TRY(hipEventCreate(&r1)); HIP_TRY(hipEventRecord(r0, stream)); }
-            rtk_launch_resolve(stream, W, dc, dt, (uint32_t)q0, npix, p->min_sample, p->max_sample, p->threshold, inv_gamma, phase,
+            rtk_launch_resolve(stream, D->scene, W, dc, dt, (uint32_t)q0, npix, p->min_sample, p->max_sample, p->threshold, inv_gamma, phase,
                                D->scene.bg, rgb8_dev, z_dev, count_dev, 2048);
             if (want_stats) { HIP_TRY(hipEventRecord(r1, stream)); resolve_ev.emplace_back(r0, r1); }
             return RT_OK;

@@ -83,6 +83,11 @@ struct DevScene {
     int32_t n_nodes, n_objects, n_meshes, n_materials, n_lights;
     float env[3], bg[3];
     DevPhotonMap pm;
+    // textures: all NULL / RT_MAP_NONE when the scene has none (then no uvw is computed either)
+    const rt_texture *textures; const uint8_t *texels; int32_t n_textures;
+    const rt_texmap *material_maps;          // 2 per material, or NULL
+    rt_texmap env_map, bg_map;
+    int32_t use_uvw;
 };
 
 // camera set-up computed once on the host the way RenderPixel does it per thread

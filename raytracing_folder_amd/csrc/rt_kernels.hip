@@ -66,7 +66,7 @@ __device__ __forceinline__ float halton(int index, int base)
 }
 
 
-struct Hit { float z; V3 p, N; int node; int front; };
+struct Hit { float z; V3 p, N; int node; int front; V3 uvw; };
 
 // ------------------------------------------------------------------------------------------------
 // primitives (object space)
@@ -256,6 +256,10 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
     float z = zinit;
     int best = -1, bfront = 1;
     V3 bp = mk(0, 0, 0), bN = mk(0, 0, 0);
+    // HitInfo::uvw starts at (0.5,0.5,0.5) (scene.h:163); spheres and planes overwrite it whenever they
+    // accept a hit (objects.h:49-51,103), FIN's triangles never do (:226-267) -- so a mesh hit keeps the
+    // coordinate of whatever sphere/plane hit the ray had accepted before it.  Reproduced as is.
+    V3 uvw = mk(0.5f, 0.5f, 0.5f);
     for (int oi = 0; oi < S.n_objects; oi++) {
         const DevObject &ob = S.objects[oi];
         V3 lp = o, ldir = d;
@@ -276,10 +280,16 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
         if (hit) {
             if (ANY) return true;
             best = oi; bp = hp; bN = hN; bfront = fr;
+            if (S.use_uvw) {
+                if (ob.type == RT_OBJ_SPHERE)               // objects.h:49-51, atan2/asin in double
+                    uvw = mk((float)(0.5 - atan2((double)hp.x, (double)hp.y) / (2 * M_PI)), (float)(0.5 + asin((double)hp.z) / M_PI), 0);
+                else if (ob.type == RT_OBJ_PLANE) uvw = mk((hp.x + 1) / 2, (hp.y + 1) / 2, 0);    // objects.h:103
+            }
         }
     }
     if (best < 0) return false;
     const DevObject &ob = S.objects[best];
+    h.uvw = uvw;
     for (int c = ob.chain_len - 1; c >= 0; c--) {
         const DevNodeXf &X = S.nodes[ob.chain[c]];
         bp = mmul(X.tm, bp) + ld3(X.pos);
@@ -358,6 +368,70 @@ struct ShadeCtx {
     DevScene S; DevWork W; rt_params P;
     DevRayQueue qout; uint32_t *qout_count;
 };
+
+// ------------------------------------------------------------------------------------------------
+// textures: TextureFile::Sample (FIN/texture.cpp:95-121: tiling + bilinear), TextureChecker::Sample
+// (:125-133), TextureMap (scene.h:376-398: uvw -> itm*(uvw-pos)), TexturedColor::Sample (:422-423)
+// and SampleEnvironment (:426-432).  duvw is always zero on this path, so the 32-tap filtered
+// Texture::Sample (:331-349) reduces to one lookup.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 tile_clamp(V3 uvw)
+{
+    V3 u = mk(uvw.x - (int)uvw.x, uvw.y - (int)uvw.y, uvw.z - (int)uvw.z);
+    if (u.x < 0) u.x += 1;
+    if (u.y < 0) u.y += 1;
+    if (u.z < 0) u.z += 1;
+    return u;
+}
+__device__ V3 texture_sample(const rt_texture &t, const uint8_t *texels, V3 uvw)
+{
+    const V3 u = tile_clamp(uvw);
+    if (t.type == RT_TEX_CHECKER) {
+        const float *c = (u.x <= 0.5f) ? (u.y <= 0.5f ? t.color1 : t.color2) : (u.y <= 0.5f ? t.color2 : t.color1);
+        return ld3(c);
+    }
+    const int width = t.width, height = t.height;
+    if (width + height == 0) return mk(0, 0, 0);
+    const uint8_t *data = texels + t.texel_offset;
+    const float x = width * u.x, y = height * u.y;
+    int ix = (int)x, iy = (int)y;
+    const float fx = x - ix, fy = y - iy;
+    if (ix < 0) ix -= (ix / width - 1) * width;
+    if (ix >= width) ix -= (ix / width) * width;
+    int ixp = ix + 1;
+    if (ixp >= width) ixp -= width;
+    if (iy < 0) iy -= (iy / height - 1) * height;
+    if (iy >= height) iy -= (iy / height) * height;
+    int iyp = iy + 1;
+    if (iyp >= height) iyp -= height;
+    auto texel = [&](int X, int Y) { const uint8_t *q = data + 3 * ((size_t)Y * width + X); return mk(q[0] / 255.0f, q[1] / 255.0f, q[2] / 255.0f); };
+    return texel(ix, iy) * ((1 - fx) * (1 - fy)) + texel(ixp, iy) * (fx * (1 - fy)) + texel(ix, iyp) * ((1 - fx) * fy) + texel(ixp, iyp) * (fx * fy);
+}
+__device__ V3 textured_color(const DevScene &S, V3 color, const rt_texmap &m, V3 uvw)
+{
+    if (m.texture == RT_MAP_NONE) return color;
+    V3 t = mk(0, 0, 0);
+    if (m.texture >= 0 && m.texture < S.n_textures) t = texture_sample(S.textures[m.texture], S.texels, mmul(m.itm, uvw - ld3(m.pos)));
+    return color * t;
+}
+__device__ V3 environment_color(const DevScene &S, V3 dir)
+{
+    if (S.env_map.texture == RT_MAP_NONE) return ld3(S.env);
+    const float z = asinf(-dir.z) / (float)M_PI + 0.5f;
+    const float x = dir.x / (fabsf(dir.x) + fabsf(dir.y));
+    const float y = dir.y / (fabsf(dir.x) + fabsf(dir.y));
+    const V3 uvw = mk(0.5f, 0.5f, 0.0f) + (mk(0.5f, 0.5f, 0) * x + mk(-0.5f, 0.5f, 0) * y) * z;
+    return textured_color(S, ld3(S.env), S.env_map, uvw);
+}
+__device__ __forceinline__ void material_colors(const DevScene &S, const Hit &h, const rt_blinn &m, V3 &kd, V3 &ks)
+{
+    kd = ld3(m.diffuse); ks = ld3(m.specular);
+    if (S.material_maps) {
+        const int mi = S.node_material[h.node];
+        kd = textured_color(S, kd, S.material_maps[2 * mi], h.uvw);       // diffuse.Sample(uvw, duvw), FIN/main.cpp:531
+        ks = textured_color(S, ks, S.material_maps[2 * mi + 1], h.uvw);   // specular.Sample(uvw, duvw), :532
+    }
+}
 
 // Attenuation, FIN/include/materials.h:60-66 (exp on floats resolves to the float overload)
 __device__ __forceinline__ V3 attenuation(V3 a, float l) { return mk(expf(-a.x * l), expf(-a.y * l), expf(-a.z * l)); }
@@ -508,8 +582,8 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
     const V3 p = h.p;
     const V3 N = normalize(h.N);                                        // :521-522
     const V3 direction = normalize(-ray_d);                             // :523-524
-    const V3 kd = ld3(m.diffuse);
-    const V3 ks = ld3(m.specular);
+    V3 kd, ks;
+    material_colors(S, h, m, kd, ks);
     const float gloss = m.glossiness;
     const V3 reflection = ld3(m.reflection), refraction = ld3(m.refraction);
     const float ior = m.ior;
@@ -578,7 +652,8 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
     const rt_blinn &m = S.materials[S.node_material[h.node]];
     V3 N = h.N;
     const V3 Pp = h.p;
-    const V3 Kd = ld3(m.diffuse), Ks = ld3(m.specular);
+    V3 Kd, Ks;
+    material_colors(S, h, m, Kd, Ks);
     const float alpha = m.glossiness;
     V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
     for (int i = 0; i < S.n_lights; i++) {
@@ -694,7 +769,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
         if (in.primary) C.W.sample_hit[in.slot] = 0;
         // a refraction ray that leaves the scene sees the environment (FIN/main.cpp:635); in P13 so
         // does a reflection ray (P13/main.cpp:660-662)
-        else if (in.kind != KIND_REFLECT || p13) add_sample(C, in.slot, thr * ld3(S.env), false);
+        else if (in.kind != KIND_REFLECT || p13) add_sample(C, in.slot, thr * environment_color(S, in.d), false);
     }
     if (active && hit) {
         if (in.primary) { C.W.sample_hit[in.slot] = 1; C.W.sample_z[in.slot] = h.z; }
@@ -1471,6 +1546,7 @@ struct ResolveArgs {
     float threshold; float inv_gamma;
     int phase;
     float bg[3];
+    DevScene S;                 // for the background map
     uint8_t *rgb8; float *z; uint8_t *count;
     int direct_mode;            // rt_shade_rays: no image, leave samples as they are
 };
@@ -1527,7 +1603,9 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
             A.count[index] = (n <= A.min_sample) ? 0 : 255;
             A.z[index] = hitz;
         } else {
-            g[0] = powf(A.bg[0], A.inv_gamma); g[1] = powf(A.bg[1], A.inv_gamma); g[2] = powf(A.bg[2], A.inv_gamma);
+            // background.Sample(Point3(x/W, y/H, 0)), FIN/main.cpp:326-328
+            const V3 bgc = textured_color(A.S, ld3(A.bg), A.S.bg_map, mk((float)x / A.cam.width, (float)y / A.cam.height, 0));
+            g[0] = powf(bgc.x, A.inv_gamma); g[1] = powf(bgc.y, A.inv_gamma); g[2] = powf(bgc.z, A.inv_gamma);
             A.count[index] = 0;
             A.z[index] = BIGFLOAT;
         }
@@ -1588,14 +1666,14 @@ void rtk_launch_gather(hipStream_t st, const DevPhotonMap &pm, const float4 *qa,
     hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(64 * RT_GATHER_WAVES), 0, st, G);
 }
 
-void rtk_launch_resolve(hipStream_t st, const DevWork &W, const DevCamera &cam, const DevTiles &tiles,
+void rtk_launch_resolve(hipStream_t st, const DevScene &S, const DevWork &W, const DevCamera &cam, const DevTiles &tiles,
                         uint32_t q0, uint32_t npix, int min_sample, int max_sample, float threshold,
                         float inv_gamma, int phase, const float bg[3], uint8_t *rgb8, float *z,
                         uint8_t *count, int max_blocks)
 {
     ResolveArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.min_sample = min_sample;
     A.max_sample = max_sample; A.threshold = threshold; A.inv_gamma = inv_gamma; A.phase = phase;
-    A.bg[0] = bg[0]; A.bg[1] = bg[1]; A.bg[2] = bg[2]; A.rgb8 = rgb8; A.z = z; A.count = count; A.direct_mode = 0;
+    A.bg[0] = bg[0]; A.bg[1] = bg[1]; A.bg[2] = bg[2]; A.rgb8 = rgb8; A.z = z; A.count = count; A.direct_mode = 0; A.S = S;
     const int grid = grid_for(npix, 256, max_blocks);
     hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, st, W, A);
 }

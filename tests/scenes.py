@@ -23,7 +23,10 @@ def load_cornell(width=None, height=None):
 def oracle_scene(export, photons=None, env=(0, 0, 0), bg=(0, 0, 0)):
     """orc.Scene over the very arrays the product exports."""
     meshes = [orc.Mesh(m["v"], m["f"], m["vn"], m["fn"], m["nodes"], m["elements"]) for m in export["meshes"]]
-    return orc.Scene(export["nodes"], meshes, export["materials"], export["lights"], photons, env, bg)
+    return orc.Scene(export["nodes"], meshes, export["materials"], export["lights"], photons, env, bg,
+                     textures=export.get("textures"), texels=export.get("texels"),
+                     material_maps=export.get("material_maps"), env_map=export.get("env_map"),
+                     bg_map=export.get("bg_map"))
 
 
 def oracle_camera(cam):

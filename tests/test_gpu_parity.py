@@ -107,7 +107,7 @@ def test_trace_100k_triangle_mesh_bit_exact():
     rays = np.concatenate([o, tgt - o], 1).astype(np.float32)
     for model in (capi.SHADE_FIN, capi.SHADE_P13):
         hit, hits = orc.trace(osc, model, rays)
-        assert hit.mean() > 0.9
+        assert hit.mean() > 0.5         # P13 triangles are back-face culled; some rays pass between the balls
         _assert_hits_equal(s.trace_rays(rays, model), hit, hits)
 
 
@@ -341,6 +341,29 @@ def test_p12_live_gi_model(cornell):
     oframe, oz2, ocnt = orc.render(osc, scenes.oracle_camera(cam2), scenes.oracle_params(p))
     diff = np.abs(frame.astype(int) - oframe.astype(int)).max(axis=2)
     assert (diff <= 1).mean() > 0.97 and (diff <= 4).mean() > 0.995 and (z2 == oz2).mean() > 0.999
+
+
+def test_textured_scene(gold):
+    """checkerboard + file textures with map transforms on planes / sphere / mesh, textured environment
+    (refraction misses) and background (missed pixels): rays and a frame against the oracle"""
+    import os
+    s = capi.Scene()
+    s.load_xml(os.path.join(scenes.GOLD, "cornell_textured.xml"))
+    cam = s.camera()
+    e = s.export()
+    osc = scenes.oracle_scene(e, env=(0.8, 0.8, 0.8), bg=(0.6, 0.7, 1.0))
+    p = capi.default_params()
+    rays = _aimed_rays(cam, 41, n_cam=2500)
+    ohit, orgb, oz = orc.shade_rays(osc, scenes.oracle_params(p), rays)
+    hit, rgb, z = s.shade_rays(p, rays)
+    assert (hit == ohit).all() and z.tobytes() == oz.tobytes()
+    assert _close(rgb, orgb, rel=5e-5, abs_=2e-6).mean() > 0.999
+    assert 0.3 < hit.mean() < 0.95                          # the box is open: some rays see the background
+    frame, zf, cnt, st, _ = s.render(cam, p)
+    oframe, ozf, ocnt = orc.render(osc, scenes.oracle_camera(cam), scenes.oracle_params(p))
+    _frame_gate(frame, oframe, zf, ozf, cnt, ocnt)
+    missed = ozf > 1e29
+    assert missed.mean() > 0.05 and len(np.unique(oframe[missed].reshape(-1, 3), axis=0)) > 50    # textured background
 
 
 def test_depth_of_field_frame(cornell):
