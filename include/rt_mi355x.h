@@ -137,6 +137,12 @@ typedef struct rt_texmap {
 #define RT_SHADE_FIN 0   /* FIN/main.cpp:516-708 (+ FIN primitives, two-sided triangles)      */
 #define RT_SHADE_P13 1   /* P13/main.cpp:485-756 (+ P13 primitives, back-face-culled tris)    */
 #define RT_SHADE_P12 2   /* RayTracingProj12 main.cpp:341-588: P13's tree + live path-traced GI  */
+#define RT_SHADE_P6  3   /* RayTracingProj6 main.cpp:175-340 (BASELINE config 2): children gated by
+                            reflection/refraction.Gray() > 0, no light fall-off, no environment;
+                            its RenderPixel = 1 sample at the pixel centre, no gamma:
+                            min_sample = max_sample = 1, gamma = 1                                 */
+#define RT_SHADE_P3  4   /* RayTracingProj3 main.cpp:152-221 (BASELINE config 1): spheres without
+                            bias, direct light only, V = camera - p                                */
 
 /* The reference's compile-time #defines (FIN/main.cpp:19-32, FIN/include/lights.h:16-18,
  * FIN/include/materials.h:20-25, FIN/main.cpp:699) as one runtime block.

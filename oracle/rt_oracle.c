@@ -130,9 +130,34 @@ static void sphere_uvw(v3 p, float uvw[3])
 }
 
 /* Sphere::IntersectRay, FIN/include/objects.h:24-70 (identical in P13/include/objects.h:23-69). */
+/* Sphere::IntersectRay of RayTracingProj3 (main.cpp:192-221): no bias, z = min(t1,t2), rejected when
+ * negative or not closer; N = p un-normalised; front untouched */
+static int sphere_intersect_p3(const float ray[6], orc_hit *hit)
+{
+    v3 rp = v3p(ray), rd = v3p(ray + 3);
+    float a = vdot(rd, rd);
+    float c = vdot(rp, rp) - 1;
+    float b = 2 * vdot(rp, rd);
+    float insqrt = b * b - (4 * a * c);
+    if (insqrt >= 0) {
+        float t1 = (-b + sqrtf(insqrt)) / (a * 2);
+        float t2 = (-b - sqrtf(insqrt)) / (a * 2);
+        float prez = hit->z;
+        float zz = RMIN(t1, t2);
+        if (zz < 0) return 0;
+        if (zz >= prez) return 0;
+        hit->z = zz;
+        v3 p = vadd(vscale(rd, hit->z), rp);
+        st3(hit->p, p);
+        st3(hit->N, p);
+        return 1;
+    }
+    return 0;
+}
+
 int orc_sphere_intersect(int model, const float ray[6], orc_hit *hit)
 {
-    (void)model;
+    if (model == RT_SHADE_P3) return sphere_intersect_p3(ray, hit);
     v3 rp = v3p(ray), rd = v3p(ray + 3);
     int behitted = 0;
     float a = vdot(rd, rd);
@@ -451,6 +476,13 @@ void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
         return;
     }
     v3 position = v3p(l->position);
+    if (model == RT_SHADE_P6 || model == RT_SHADE_P3) {
+        /* PointLight::Illuminate of P6/P3 (include/lights.h:61): Shadow(Ray(p,position-p),1) * intensity */
+        float ray[6];
+        st3(ray, p); st3(ray + 3, vsub(position, p));
+        st3(out, vscale(I, orc_shadow(s, model, ray, 1)));
+        return;
+    }
     float size = l->size;
     int ns = P->shadow_samples > 0 ? P->shadow_samples : 4;
     const uint32_t li = (uint32_t)(l - s->lights);
@@ -612,12 +644,18 @@ static v3 attenuation(v3 absorption, float l)
     return V3(expf(-absorption.x * l), expf(-absorption.y * l), expf(-absorption.z * l));
 }
 
+static float gray3(v3 c);
+static float clampf(float v, float lo, float hi);
 static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3]);
 static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3]);
+static void shade_p6(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3]);
+static void shade_p3(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, float out[3]);
 
 void orc_shade(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3])
 {
     if (P->shade_model == RT_SHADE_P13 || P->shade_model == RT_SHADE_P12) shade_p13(s, P, ray, h, bounce, out);
+    else if (P->shade_model == RT_SHADE_P6) shade_p6(s, P, ray, h, bounce, out);
+    else if (P->shade_model == RT_SHADE_P3) shade_p3(s, P, ray, h, out);
     else shade_fin(s, P, ray, h, bounce, out);
 }
 
@@ -893,6 +931,119 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
         /* refraction * (ra_ratio*absorb*ra_color + re_ratio*re_ra_color) */
         all = vadd(all, vmul(v3p(m->refraction),
                              vadd(vscale(ra_color, ra_ratio * absorb), vscale(re_ra_color, re_ratio))));
+    }
+    st3(out, all);
+}
+
+/* MtlBlinn::Shade of RayTracingProj3, main.cpp:152-190: ambient + Blinn with V = camera.pos - p
+ * (every P3 ray starts at the camera, so camera.pos is the ray origin) */
+static void shade_p3(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *hInfo, float out[3])
+{
+    const rt_blinn *m = hit_material(s, hInfo);
+    v3 ambient = V3(0, 0, 0), diffuse = V3(0, 0, 0);
+    v3 N = v3p(hInfo->N), Pp = v3p(hInfo->p);
+    v3 Kd = v3p(m->diffuse), Ks = v3p(m->specular);
+    float alpha = m->glossiness;
+    for (int i = 0; i < s->n_lights; i++) {
+        const rt_light *l = &s->lights[i];
+        float Il[3];
+        orc_illuminate(s, P, l, hInfo->p, hInfo->N, Il);
+        if (l->type == RT_LIGHT_AMBIENT) ambient = vadd(ambient, vmul(v3p(Il), Kd));
+        else {
+            v3 L = vscale(light_direction(l, Pp), (float)-1);
+            v3 V = vnorm(vsub(v3p(ray), Pp));                             /* camera.pos - hInfo.p */
+            v3 LpV = vadd(L, V);
+            v3 H = vnorm(vdivs(LpV, vlen(LpV)));                          /* LpV/LpV.Length(); H.Normalize() */
+            v3 kse = vadd(vscale(Ks, powf(vdot(N, H), alpha)), Kd);
+            float theta = vdot(N, L);
+            diffuse = vadd(diffuse, vmul(vscale(v3p(Il), (theta > 0 ? theta : 0)), kse));
+        }
+    }
+    st3(out, vadd(ambient, diffuse));
+}
+
+/* MtlBlinn::Shade of RayTracingProj6, main.cpp:175-340 */
+static void shade_p6(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *hInfo, int bounceCount, float out[3])
+{
+    const rt_blinn *m = hit_material(s, hInfo);
+    v3 ra_color = V3(0, 0, 0), re_color = V3(0, 0, 0), re_ra_color;
+    v3 ambient = V3(0, 0, 0), diffuse = V3(0, 0, 0);
+    v3 N = v3p(hInfo->N), Pp = v3p(hInfo->p);
+    v3 Kd = v3p(m->diffuse), Ks = v3p(m->specular);
+    v3 reflection = v3p(m->reflection), refraction = v3p(m->refraction);
+    float alpha = m->glossiness;
+    for (int i = 0; i < s->n_lights; i++) {
+        const rt_light *l = &s->lights[i];
+        float Il[3];
+        orc_illuminate(s, P, l, hInfo->p, hInfo->N, Il);
+        if (l->type == RT_LIGHT_AMBIENT) ambient = vadd(ambient, vmul(v3p(Il), Kd));            /* :199 */
+        else {
+            v3 L = vscale(light_direction(l, Pp), (float)-1);
+            v3 V = vnorm(vneg(v3p(ray + 3)));
+            v3 H = vnorm(vadd(L, V));
+            v3 kse = vadd(vscale(Ks, powf(vdot(N, H), alpha)), Kd);                             /* :210 */
+            float theta = vdot(N, L);
+            diffuse = vadd(diffuse, vmul(vscale(v3p(Il), (theta > 0.0 ? theta : 0.0f)), kse));  /* :214 */
+        }
+    }
+    v3 all = vadd(ambient, diffuse);
+    v3 V = vneg(vnorm(v3p(ray + 3)));                                                            /* :223 */
+    const int has_re = gray3(reflection) > 0;
+    if (has_re && bounceCount > 0) {                                                             /* :225-238 */
+        float costheta = clampf(vdot(N, V), -1.0f, 1.0f);
+        v3 R = vnorm(vsub(vscale(N, 2 * costheta), V));
+        float r[6];
+        st3(r, Pp); st3(r + 3, R);
+        orc_hit hh;
+        g_cnt.rays_reflect++;
+        if (orc_trace(s, P->shade_model, r, &hh)) { float c[3]; shade_p6(s, P, r, &hh, bounceCount - 1, c); re_color = v3p(c); }
+    }
+    all = vadd(all, vmul(re_color, reflection));                                                 /* :240 */
+    if (gray3(refraction) > 0 && bounceCount > 0) {                                              /* :246-335 */
+        float R0 = 0.0f, re_ratio = 0.0f, ra_ratio = 0.0f;
+        V = vnorm(V);
+        float costheta1 = fabsf(vdot(V, N));
+        float sintheta1 = sqrtf(RMAX(0.0f, 1 - (costheta1 * costheta1)));
+        float n1 = 1.0, n2 = 1.0;
+        if (hInfo->front) n2 = m->ior;
+        else { n1 = m->ior; N = vneg(v3p(hInfo->N)); }
+        float ratio_n = n1 / n2;
+        float sintheta2 = ratio_n * sintheta1;
+        float absorb = 0.0;
+        if (sintheta2 <= 1.0) {
+            float costheta2 = sqrtf(RMAX(0.0f, 1 - (sintheta2 * sintheta2)));
+            v3 S = vcross(N, vcross(N, V));
+            N = vnorm(N);
+            S = vnorm(S);
+            v3 T = vadd(vscale(vneg(N), costheta2), vscale(S, sintheta2));
+            float r[6];
+            st3(r, Pp); st3(r + 3, T);
+            orc_hit hh;
+            g_cnt.rays_refract++;
+            if (orc_trace(s, P->shade_model, r, &hh)) {
+                float c[3];
+                shade_p6(s, P, r, &hh, bounceCount - 1, c);
+                ra_color = v3p(c);
+                absorb = expf(-m->absorption[0] * hh.z);                                         /* :296 */
+                R0 = (n1 - n2) / (n1 + n2);
+                R0 = R0 * R0;
+                double tmp = 1.0 - costheta1;
+                re_ratio = (float)(R0 + (1.0 - R0) * pow(tmp, 5.0));
+                ra_ratio = (float)(1.0 - re_ratio);
+            }
+        } else re_ratio = 1.0f;
+        re_ra_color = re_color;
+        if (has_re && bounceCount > 0) re_ra_color = re_color;
+        else if (re_ratio > 0.0 && bounceCount > 0) {                                            /* :314-329 */
+            float costheta = clampf(vdot(N, V), -1.0f, 1.0f);
+            v3 R = vsub(vscale(N, 2 * costheta), V);                                             /* not normalised */
+            float r[6];
+            st3(r, Pp); st3(r + 3, R);
+            orc_hit hh;
+            g_cnt.rays_reflect++;
+            if (orc_trace(s, P->shade_model, r, &hh)) { float c[3]; shade_p6(s, P, r, &hh, bounceCount - 1, c); re_ra_color = v3p(c); }
+        }
+        all = vadd(all, vmul(refraction, vadd(vscale(ra_color, ra_ratio * absorb), vscale(re_ra_color, re_ratio))));   /* :332 */
     }
     st3(out, all);
 }

@@ -34,7 +34,7 @@ TEX_FILE, TEX_CHECKER, MAP_NONE, MAP_EMPTY = 1, 2, -1, -2
 
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3
 LIGHT_AMBIENT, LIGHT_DIRECT, LIGHT_POINT = 0, 1, 2
-SHADE_FIN, SHADE_P13, SHADE_P12 = 0, 1, 2
+SHADE_FIN, SHADE_P13, SHADE_P12, SHADE_P6, SHADE_P3 = 0, 1, 2, 3, 4
 
 
 class Camera(C.Structure):

@@ -112,7 +112,7 @@ struct DeviceState {
     DevBuf pa, pb, pc, tbox, spill, grid;
     DevScene scene{};
     // workspace
-    DevBuf sample_rgb, sample_z, sample_hit, rq[2][4], pq[3], counts, pixel_list, stats;
+    DevBuf sample_rgb, sample_z, sample_hit, rq[2][5], pq[3], counts, pixel_list, stats;
     size_t ws_samples = 0; uint32_t ws_rq_cap = 0, ws_pq_cap = 0;
     // scratch for the single-stage entry points
     DevBuf t_in, t_out[6];
@@ -122,7 +122,7 @@ struct DeviceState {
         for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &pc, &tbox, &spill, &grid,
                           &sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); }
-        for (int i = 0; i < 2; i++) for (int k = 0; k < 4; k++) rq[i][k].release();
+        for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) rq[i][k].release();
         for (int k = 0; k < 3; k++) pq[k].release();
         for (int k = 0; k < 6; k++) t_out[k].release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -756,7 +756,7 @@ static rt_status ensure_workspace(DeviceState *D, size_t samples, int bounce, si
     if ((st = D->sample_rgb.ensure(samples * 12))) return st;
     if ((st = D->sample_z.ensure(samples * 4))) return st;
     if ((st = D->sample_hit.ensure(samples))) return st;
-    for (int i = 0; i < 2; i++) for (int k = 0; k < 4; k++) if ((st = D->rq[i][k].ensure((size_t)rq_cap * 16))) return st;
+    for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) if ((st = D->rq[i][k].ensure((size_t)rq_cap * 16))) return st;
     for (int k = 0; k < 3; k++) if ((st = D->pq[k].ensure((size_t)pq_cap * 16))) return st;
     if ((st = D->counts.ensure(CNT_TOTAL * 4))) return st;
     if ((st = D->pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
@@ -771,7 +771,7 @@ static DevWork make_work(DeviceState *D)
     W.sample_rgb = (float *)D->sample_rgb.p; W.sample_z = (float *)D->sample_z.p; W.sample_hit = (uint8_t *)D->sample_hit.p;
     for (int i = 0; i < 2; i++) {
         W.rq[i].a = (float4 *)D->rq[i][0].p; W.rq[i].b = (float4 *)D->rq[i][1].p; W.rq[i].c = (float4 *)D->rq[i][2].p;
-        W.rq[i].d = (uint4 *)D->rq[i][3].p; W.rq[i].cap = D->ws_rq_cap;
+        W.rq[i].d = (uint4 *)D->rq[i][3].p; W.rq[i].e = (float4 *)D->rq[i][4].p; W.rq[i].cap = D->ws_rq_cap;
     }
     W.pq.qa = (float4 *)D->pq[0].p; W.pq.qb = (float4 *)D->pq[1].p; W.pq.qc = (float4 *)D->pq[2].p; W.pq.cap = D->ws_pq_cap;
     W.counts = (uint32_t *)D->counts.p; W.pixel_list = (uint32_t *)D->pixel_list.p;
@@ -811,8 +811,9 @@ static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const 
     if ((unsigned long long)cam->width * cam->height * (unsigned long long)p->max_sample >= (1ull << 32))
         return fail(RT_ERR_LIMIT, "render: width*height*max_sample must stay below 2^32 (sample ids are 32-bit)");
     if (p->min_sample < 1 || p->max_sample < p->min_sample || p->max_sample > 4096) return fail(RT_ERR_ARG, "render: need 1 <= min_sample <= max_sample <= 4096");
-    if (p->shade_model != RT_SHADE_FIN && p->shade_model != RT_SHADE_P13 && p->shade_model != RT_SHADE_P12)
+    if (p->shade_model < RT_SHADE_FIN || p->shade_model > RT_SHADE_P3)
         return fail(RT_ERR_ARG, "render: unknown shade model %d", p->shade_model);
+    if (p->shade_model == RT_SHADE_P6 && p->bounce > 7) return fail(RT_ERR_LIMIT, "render: RT_SHADE_P6 supports bounce <= 7");
     if (p->shade_model == RT_SHADE_P12 && (p->hemisphere_sample < 1 || p->hemisphere_sample > 256))
         return fail(RT_ERR_ARG, "render: hemisphere_sample must be 1..256 for RT_SHADE_P12");
     if (p->knn_k < 1 || p->knn_k > 65536 || !(p->knn_radius > 0)) return fail(RT_ERR_ARG, "render: bad photon gather parameters");
@@ -842,7 +843,10 @@ static rt_status run_pipeline(DeviceState *D, hipStream_t st, const DevWork &W, 
     HIP_TRY(hipMemsetAsync(W.counts, 0, (CNT_PHOTONQ + 1) * 4, st));
     if ((s = mark(-1))) return s;
     rtk_launch_primary(st, D->scene, W, P, W.rq[1], W.counts + 1, dc, dt, q0, npix, j0, ns, max_sample, mode, rays_dev, max_blocks);
-    for (int level = 1; level <= P.bounce && level < 15; level++)
+    // P6: a side ray is spawned when its refraction ray ARRIVES, one queue level later than a sibling
+    // would be, so a path can take up to two levels per bounce
+    const int max_level = P.shade_model == RT_SHADE_P6 ? 2 * P.bounce : P.bounce;
+    for (int level = 1; level <= max_level && level < 15; level++)
         rtk_launch_bounce(st, D->scene, W, P, W.rq[level & 1], W.rq[(level + 1) & 1], W.counts + level + 1, level, max_blocks);
     if ((s = mark(0))) return s;
     if (D->scene.pm.n_leaves) {
@@ -1058,7 +1062,7 @@ extern "C" rt_status rt_trace_rays(rt_scene *s, int shade_model, int device, con
 {
     if (!s || n < 0) return fail(RT_ERR_ARG, "rt_trace_rays: NULL scene or negative count");
     if (n > 0 && (!rays || !hit || !z || !p || !N || !node || !front)) return fail(RT_ERR_ARG, "rt_trace_rays: NULL argument");
-    if (shade_model != RT_SHADE_FIN && shade_model != RT_SHADE_P13 && shade_model != RT_SHADE_P12) return fail(RT_ERR_ARG, "rt_trace_rays: unknown shade model");
+    if (shade_model < RT_SHADE_FIN || shade_model > RT_SHADE_P3) return fail(RT_ERR_ARG, "rt_trace_rays: unknown shade model");
     DeviceState *D = nullptr;
     rt_status st = prepare_device(s, device, &D);
     if (st) return st;

@@ -117,7 +117,8 @@ enum {
 
 // ray queue: structure of arrays of float4 (one 16-byte coalesced read per lane per array)
 //   a = (o.xyz, d.x)   b = (d.yz, thr.r, thr.g)   c = (thr.b, absorb.rgb)   d = (slot, bounce|kind<<8, -, -) as uint bits
-struct DevRayQueue { float4 *a, *b, *c; uint4 *d; uint32_t cap; };
+//   e = (side.dir.xyz, side.K.r), with side.K.gb in c.zw: a ray to be spawned when this one HITS (P6 only)
+struct DevRayQueue { float4 *a, *b, *c; uint4 *d; float4 *e; uint32_t cap; };
 // photon query queue: qa = (pos.xyz, N.x)  qb = (N.yz, w.r, w.g)  qc = (w.b, slot bits, -, -)
 struct DevPhotonQueue { float4 *qa, *qb, *qc; uint32_t cap; };
 

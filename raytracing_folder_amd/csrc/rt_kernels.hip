@@ -51,6 +51,7 @@ __device__ __forceinline__ V3 mtmul(const float *d, V3 v)      // TransposeMult,
 {
     return mk(dot(mk(d[0], d[1], d[2]), v), dot(mk(d[3], d[4], d[5]), v), dot(mk(d[6], d[7], d[8]), v));
 }
+__device__ __forceinline__ float gray(V3 c) { return (c.x + c.y + c.z) / 3.0f; }      // Color::Gray, cyColor.h
 #define RMAX(a, b) ((a) > (b) ? (a) : (b))     // the reference's macros, scene.h:48-54
 #define RMIN(a, b) ((a) < (b) ? (a) : (b))
 
@@ -94,6 +95,27 @@ __device__ __forceinline__ bool sphere_hit(V3 rp, V3 rd, float &z, V3 &hp, V3 &h
             hp = rd * z + rp; hN = normalize(hp);
             return true;
         }
+    }
+    return false;
+}
+
+// Sphere::IntersectRay of RayTracingProj3 (main.cpp:192-221): no bias, z = min(t1,t2), rejected when negative
+// or not closer; N = p un-normalised; front untouched
+__device__ __forceinline__ bool sphere_hit_p3(V3 rp, V3 rd, float &z, V3 &hp, V3 &hN)
+{
+    const float a = dot(rd, rd);
+    const float c = dot(rp, rp) - 1;
+    const float b = 2 * dot(rp, rd);
+    const float insqrt = b * b - (4 * a * c);
+    if (insqrt >= 0) {
+        const float sq = sqrtf(insqrt);
+        const float t1 = (-b + sq) / (a * 2);
+        const float t2 = (-b - sq) / (a * 2);
+        const float zz = RMIN(t1, t2);
+        if (zz < 0 || zz >= z) return false;
+        z = zz;
+        hp = rd * z + rp; hN = hp;
+        return true;
     }
     return false;
 }
@@ -250,7 +272,7 @@ __device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN,
 // ancestor in turn (scene.h:502-508; direction NOT renormalised, so t is shared by all spaces),
 // and the closest hit is brought back through FromNodeCoords of each ancestor (scene.h:509-513).
 // ------------------------------------------------------------------------------------------------
-template <bool ANY, int MODEL>
+template <bool ANY, int MODEL, bool TEX = false>
 __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt)
 {
     float z = zinit;
@@ -274,13 +296,13 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
         V3 hp, hN;
         int fr = 1;
         bool hit = false;
-        if (ob.type == RT_OBJ_SPHERE) hit = sphere_hit(lp, ldir, z, hp, hN, fr);
+        if (ob.type == RT_OBJ_SPHERE) hit = (MODEL == RT_SHADE_P3) ? sphere_hit_p3(lp, ldir, z, hp, hN) : sphere_hit(lp, ldir, z, hp, hN, fr);
         else if (ob.type == RT_OBJ_PLANE) hit = plane_hit(MODEL, lp, ldir, z, hp, hN, fr);
         else if (ob.type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes[ob.mesh], lp, ldir, z, hp, hN, fr, stack, cnt);
         if (hit) {
             if (ANY) return true;
             best = oi; bp = hp; bN = hN; bfront = fr;
-            if (S.use_uvw) {
+            if (TEX && S.use_uvw) {
                 if (ob.type == RT_OBJ_SPHERE)               // objects.h:49-51, atan2/asin in double
                     uvw = mk((float)(0.5 - atan2((double)hp.x, (double)hp.y) / (2 * M_PI)), (float)(0.5 + asin((double)hp.z) / M_PI), 0);
                 else if (ob.type == RT_OBJ_PLANE) uvw = mk((hp.x + 1) / 2, (hp.y + 1) / 2, 0);    // objects.h:103
@@ -362,7 +384,7 @@ __device__ __forceinline__ int __reduce_max_sync_compat(int v)
     return v;
 }
 
-struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; bool primary; uint32_t node, sample; };
+struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; bool primary; uint32_t node, sample; V3 side_dir, side_K; };
 
 struct ShadeCtx {
     DevScene S; DevWork W; rt_params P;
@@ -414,19 +436,21 @@ __device__ V3 textured_color(const DevScene &S, V3 color, const rt_texmap &m, V3
     if (m.texture >= 0 && m.texture < S.n_textures) t = texture_sample(S.textures[m.texture], S.texels, mmul(m.itm, uvw - ld3(m.pos)));
     return color * t;
 }
+template <bool TEX>
 __device__ V3 environment_color(const DevScene &S, V3 dir)
 {
-    if (S.env_map.texture == RT_MAP_NONE) return ld3(S.env);
+    if (!TEX || S.env_map.texture == RT_MAP_NONE) return ld3(S.env);
     const float z = asinf(-dir.z) / (float)M_PI + 0.5f;
     const float x = dir.x / (fabsf(dir.x) + fabsf(dir.y));
     const float y = dir.y / (fabsf(dir.x) + fabsf(dir.y));
     const V3 uvw = mk(0.5f, 0.5f, 0.0f) + (mk(0.5f, 0.5f, 0) * x + mk(-0.5f, 0.5f, 0) * y) * z;
     return textured_color(S, ld3(S.env), S.env_map, uvw);
 }
+template <bool TEX>
 __device__ __forceinline__ void material_colors(const DevScene &S, const Hit &h, const rt_blinn &m, V3 &kd, V3 &ks)
 {
     kd = ld3(m.diffuse); ks = ld3(m.specular);
-    if (S.material_maps) {
+    if (TEX && S.material_maps) {
         const int mi = S.node_material[h.node];
         kd = textured_color(S, kd, S.material_maps[2 * mi], h.uvw);       // diffuse.Sample(uvw, duvw), FIN/main.cpp:531
         ks = textured_color(S, ks, S.material_maps[2 * mi + 1], h.uvw);   // specular.Sample(uvw, duvw), :532
@@ -461,10 +485,21 @@ __device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &
     Hit dummy;
     if (l.type == RT_LIGHT_DIRECT) {
         cnt.shadow++;
-        const bool occ = trace<true, MODEL>(S, p, -ld3(l.direction), BIGFLOAT, dummy, stack, cnt);
+        bool occ;
+        if (MODEL == RT_SHADE_P3) { Hit sh; occ = trace<false, MODEL>(S, p, -ld3(l.direction), BIGFLOAT, sh, stack, cnt) && sh.z > 1e-14f; }
+        else occ = trace<true, MODEL>(S, p, -ld3(l.direction), BIGFLOAT, dummy, stack, cnt);
         return I * (occ ? 0.0f : 1.0f);
     }
     const V3 position = ld3(l.position);
+    if (MODEL == RT_SHADE_P6 || MODEL == RT_SHADE_P3) {
+        // PointLight::Illuminate of P6/P3 (include/lights.h:61): Shadow(Ray(p,position-p),1) * intensity.
+        // P3's spheres have no bias: the CLOSEST hit decides (z in (1e-14, 1)), an any-hit would not do
+        cnt.shadow++;
+        bool occ;
+        if (MODEL == RT_SHADE_P3) { Hit sh; occ = trace<false, MODEL>(S, p, position - p, BIGFLOAT, sh, stack, cnt) && sh.z > 1e-14f && sh.z < 1.0f; }
+        else occ = trace<true, MODEL>(S, p, position - p, 1.0f, dummy, stack, cnt);
+        return I * (occ ? 0.0f : 1.0f);
+    }
     const int ns = P.shadow_samples > 0 ? P.shadow_samples : 4;
     if (l.size == 0) {
         cnt.shadow++;
@@ -534,15 +569,20 @@ __device__ __forceinline__ void add_sample(const ShadeCtx &C, uint32_t slot, V3 
     else { atomicAdd(dst, c.x); atomicAdd(dst + 1, c.y); atomicAdd(dst + 2, c.z); }
 }
 
+template <bool SIDE = false>
 __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 d, V3 thr, V3 absorb,
-                                         uint32_t slot, int bounce, uint32_t kind, uint32_t node, uint32_t sample)
+                                         uint32_t slot, int bounce, uint32_t kind, uint32_t node, uint32_t sample,
+                                         V3 side_dir = V3{0, 0, 0}, V3 side_K = V3{0, 0, 0})
 {
     const uint32_t idx = wave_push(pred, C.qout_count);
     if (pred) {
         if (idx < C.qout.cap) {
             C.qout.a[idx] = make_float4(o.x, o.y, o.z, d.x);
             C.qout.b[idx] = make_float4(d.y, d.z, thr.x, thr.y);
-            C.qout.c[idx] = make_float4(thr.z, absorb.x, absorb.y, absorb.z);
+            if (SIDE) {
+                C.qout.c[idx] = make_float4(thr.z, absorb.x, side_K.y, side_K.z);
+                C.qout.e[idx] = make_float4(side_dir.x, side_dir.y, side_dir.z, side_K.x);
+            } else C.qout.c[idx] = make_float4(thr.z, absorb.x, absorb.y, absorb.z);
             C.qout.d[idx] = make_uint4(slot, (uint32_t)bounce | (kind << 8), node, sample);
         } else atomicAdd(&C.W.stats[ST_QUEUE_OVERFLOW], 1ull);
     }
@@ -569,11 +609,14 @@ struct ShadeOut {
     V3 rK, tK;                       // child weights relative to this ray
     V3 child_absorb;                 // what the children need to finish their own weight on arrival
     V3 kd, N;                        // photon query: diffuse colour and shading normal
+    bool want_side;                  // P6: a reflection ray that exists only if the refraction ray hits
+    V3 side_dir, side_K;
     int n_gi;                        // P12: hemisphere rays to spawn (weights/dirs are drawn at push time)
     V3 gi_x, gi_y, gi_z;             // P12: frame of the hemisphere
 };
 
 // MtlBlinn::Shade, FIN/main.cpp:516-708
+template <bool TEX>
 __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
                           ShadeOut &o, uint32_t *stack, Counters &cnt)
 {
@@ -583,7 +626,7 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
     const V3 N = normalize(h.N);                                        // :521-522
     const V3 direction = normalize(-ray_d);                             // :523-524
     V3 kd, ks;
-    material_colors(S, h, m, kd, ks);
+    material_colors<TEX>(S, h, m, kd, ks);
     const float gloss = m.glossiness;
     const V3 reflection = ld3(m.reflection), refraction = ld3(m.refraction);
     const float ior = m.ior;
@@ -644,7 +687,7 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
 // all = ambient + direct; all += re_color*reflection; all += refraction*(ra_ratio*absorb*ra_color +
 // re_ratio*re_color): the reflection child weighs reflection + refraction*re_ratio, the refraction
 // child refraction*ra_ratio*exp(-absorption.r * z_child) (z_child = BIGFLOAT on a miss).
-template <int MODEL>
+template <int MODEL, bool TEX>
 __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
                           ShadeOut &o, uint32_t *stack, Counters &cnt)
 {
@@ -653,7 +696,7 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
     V3 N = h.N;
     const V3 Pp = h.p;
     V3 Kd, Ks;
-    material_colors(S, h, m, Kd, Ks);
+    material_colors<TEX>(S, h, m, Kd, Ks);
     const float alpha = m.glossiness;
     V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
     for (int i = 0; i < S.n_lights; i++) {
@@ -742,40 +785,158 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
     o.child_absorb = mk(m.absorption[0], 0, 0);          // refraction child: *= exp(-absorption.r * z) (:728)
 }
 
+// MtlBlinn::Shade of RayTracingProj3, main.cpp:152-190: ambient + Blinn with V = camera.pos - p (all P3
+// rays start at the camera, so camera.pos is the ray origin); no children
+template <bool TEX>
+__device__ void shade_p3(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_o, const RngCtx &rc, ShadeOut &o,
+                         uint32_t *stack, Counters &cnt)
+{
+    const rt_blinn &m = S.materials[S.node_material[h.node]];
+    const V3 N = h.N, Pp = h.p;
+    V3 Kd, Ks;
+    material_colors<TEX>(S, h, m, Kd, Ks);
+    V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
+    for (int i = 0; i < S.n_lights; i++) {
+        const rt_light &l = S.lights[i];
+        const V3 Il = illuminate<RT_SHADE_P3>(S, P, l, i, Pp, rc, stack, cnt);
+        if (l.type == RT_LIGHT_AMBIENT) ambient = ambient + Il * Kd;
+        else {
+            const V3 L = light_direction(l, Pp) * (float)-1;
+            const V3 V = normalize(ray_o - Pp);
+            const V3 LpV = L + V;
+            const V3 H = normalize(LpV / sqrtf(len2(LpV)));
+            const V3 kse = Ks * powf(dot(N, H), m.glossiness) + Kd;
+            const float theta = dot(N, L);
+            diffuse = diffuse + (Il * (theta > 0 ? theta : 0.0f)) * kse;
+        }
+    }
+    o.color = ambient + diffuse;
+    o.kd = Kd; o.N = N;
+}
+
+// MtlBlinn::Shade of RayTracingProj6, main.cpp:175-340.  Children: a reflection ray only when
+// reflection.Gray() > 0 (weight reflection); a refraction ray only when refraction.Gray() > 0 (weight
+// refraction*ra_ratio*exp(-absorption.r*z)); and refraction*re_ratio times a reflection colour that the
+// reference adds ONLY IF THE REFRACTION RAY HIT something (re_ratio is set inside that branch, :296-303) --
+// or under total internal reflection.  That conditional ray travels with the refraction ray as a
+// "side" ray and is spawned when the refraction ray reports a hit.  Misses add nothing (no environment).
+template <bool TEX>
+__device__ void shade_p6(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
+                         ShadeOut &o, uint32_t *stack, Counters &cnt)
+{
+    const rt_blinn &m = S.materials[S.node_material[h.node]];
+    V3 N = h.N;
+    const V3 Pp = h.p;
+    V3 Kd, Ks;
+    material_colors<TEX>(S, h, m, Kd, Ks);
+    const V3 reflection = ld3(m.reflection), refraction = ld3(m.refraction);
+    V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
+    for (int i = 0; i < S.n_lights; i++) {
+        const rt_light &l = S.lights[i];
+        const V3 Il = illuminate<RT_SHADE_P6>(S, P, l, i, Pp, rc, stack, cnt);
+        if (l.type == RT_LIGHT_AMBIENT) ambient = ambient + Il * Kd;                          // :199
+        else {
+            const V3 L = light_direction(l, Pp) * (float)-1;
+            const V3 V = normalize(-ray_d);
+            const V3 H = normalize(L + V);
+            const V3 kse = Ks * powf(dot(N, H), m.glossiness) + Kd;                           // :210
+            const float theta = dot(N, L);
+            diffuse = diffuse + (Il * (theta > 0.0f ? theta : 0.0f)) * kse;                   // :214
+        }
+    }
+    o.color = ambient + diffuse;
+    o.kd = Kd; o.N = h.N;
+    V3 V = -normalize(ray_d);                                                                 // :223
+    const bool has_re = gray(reflection) > 0;
+    const float ct0 = fminf(fmaxf(dot(N, V), -1.0f), 1.0f);
+    const V3 R1 = normalize(N * (2 * ct0) - V);                                               // :227-229
+    o.rdir = R1;
+    o.rK = reflection;
+    o.want_refl = has_re && bounce > 0;
+    o.want_refr = false; o.want_side = false;
+    o.tK = mk(0, 0, 0); o.tdir = mk(0, 0, 1); o.side_dir = mk(0, 0, 1); o.side_K = mk(0, 0, 0);
+    o.child_absorb = mk(m.absorption[0], 0, 0);
+    if (gray(refraction) > 0 && bounce > 0) {                                                 // :246
+        V = normalize(V);
+        const float costheta1 = fabsf(dot(V, N));
+        const float sintheta1 = sqrtf(RMAX(0.0f, 1 - (costheta1 * costheta1)));
+        float n1 = 1.0f, n2 = 1.0f;
+        if (h.front) n2 = m.ior; else { n1 = m.ior; N = -h.N; }
+        const float ratio_n = n1 / n2;
+        const float sintheta2 = ratio_n * sintheta1;
+        float re_ratio, ra_ratio = 0.0f;
+        const bool transmit = sintheta2 <= 1.0f;
+        if (transmit) {
+            const float costheta2 = sqrtf(RMAX(0.0f, 1 - (sintheta2 * sintheta2)));
+            V3 Sv = cross(N, cross(N, V));
+            N = normalize(N);
+            Sv = normalize(Sv);
+            o.tdir = (-N) * costheta2 + Sv * sintheta2;
+            float R0 = (n1 - n2) / (n1 + n2);
+            R0 = R0 * R0;
+            const double tmp = 1.0 - costheta1;
+            re_ratio = (float)(R0 + (1.0 - R0) * pow(tmp, 5.0));                              // if the refraction ray hits
+            ra_ratio = (float)(1.0 - re_ratio);
+            o.tK = refraction * ra_ratio;
+            o.want_refr = true;
+        } else re_ratio = 1.0f;                                                               // total internal reflection
+        // the reflection colour that refraction*re_ratio multiplies: the first reflection ray again when the
+        // material is reflective (:310), else a second ray about the (flipped, normalised) normal, direction
+        // NOT normalised (:314-319)
+        V3 sdir = R1;
+        if (!has_re) { const float ct = fminf(fmaxf(dot(N, V), -1.0f), 1.0f); sdir = N * (2 * ct) - V; }
+        const V3 sK = refraction * re_ratio;
+        if (re_ratio > 0.0f || has_re) {
+            if (transmit) { o.want_side = true; o.side_dir = sdir; o.side_K = sK; }          // only if the refraction ray hits
+            else if (has_re) o.rK = reflection + sK;                                          // same ray as the first reflection
+            else { o.want_refl = true; o.rdir = sdir; o.rK = sK; }
+        }
+    }
+}
+
 // One node of the ray tree: Trace + MtlBlinn::Shade with the recursion unrolled into queue pushes.
 // Shade is linear in its children (color += K*child), so a ray carries the product `thr` of the K
 // factors above it and adds thr*local colour to its sample; the part of a child's K that depends on
 // the child's own hit (FIN: Attenuation(parent absorption, z) on a back-face hit, FIN/main.cpp:620,
 // 632; P13: exp(-absorption.r*z) on the refraction child, P13/main.cpp:728) is applied on arrival.
-template <int MODEL>
+template <int MODEL, bool TEX>
 __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uint32_t *stack, Counters &cnt)
 {
     const DevScene &S = C.S;
     const rt_params &P = C.P;
-    constexpr bool p13 = MODEL != RT_SHADE_FIN;          // P13 and P12 share primitives, lights and the ray tree
+    constexpr bool p13 = MODEL == RT_SHADE_P13 || MODEL == RT_SHADE_P12;     // they share lights and the ray tree
     Hit h;
     bool hit = false;
-    if (active) hit = trace<false, MODEL>(S, in.o, in.d, BIGFLOAT, h, stack, cnt);
+    if (active) hit = trace<false, MODEL, TEX>(S, in.o, in.d, BIGFLOAT, h, stack, cnt);
     V3 thr = in.thr;
     ShadeOut o;
     o.want_refl = o.want_refr = o.want_photon = false;
     o.rdir = o.tdir = mk(0, 0, 1); o.rK = o.tK = o.child_absorb = o.kd = o.N = mk(0, 0, 0);
     o.n_gi = 0; o.gi_x = o.gi_y = o.gi_z = mk(0, 0, 1);
+    o.want_side = false; o.side_dir = mk(0, 0, 1); o.side_K = mk(0, 0, 0);
+    constexpr bool p6 = MODEL == RT_SHADE_P6, p3 = MODEL == RT_SHADE_P3;
+    bool spawn_side = false;
     if (active && !in.primary) {
-        if (p13) { if (in.kind == KIND_REFRACT) thr = thr * expf(-in.absorb.x * (hit ? h.z : BIGFLOAT)); }   // not for GI rays
+        if (p6) {
+            // refraction ray of P6: weight *= exp(-absorption.r*z) when it hits (main.cpp:296); its side ray
+            // (the reflection that refraction*re_ratio multiplies) exists only in that case
+            if (in.kind == KIND_REFRACT && hit) { thr = thr * expf(-in.absorb.x * h.z); spawn_side = (in.side_K.x != 0.f || in.side_K.y != 0.f || in.side_K.z != 0.f); }
+        } else if (p13) { if (in.kind == KIND_REFRACT) thr = thr * expf(-in.absorb.x * (hit ? h.z : BIGFLOAT)); }   // not for GI rays
         else if (hit && !h.front) thr = thr * attenuation(in.absorb, h.z);
     }
     if (active && !hit) {
         if (in.primary) C.W.sample_hit[in.slot] = 0;
         // a refraction ray that leaves the scene sees the environment (FIN/main.cpp:635); in P13 so
         // does a reflection ray (P13/main.cpp:660-662)
-        else if (in.kind != KIND_REFLECT || p13) add_sample(C, in.slot, thr * environment_color(S, in.d), false);
+        else if (!p6 && !p3 && (in.kind != KIND_REFLECT || p13)) add_sample(C, in.slot, thr * environment_color<TEX>(S, in.d), false);
     }
     if (active && hit) {
         if (in.primary) { C.W.sample_hit[in.slot] = 1; C.W.sample_z[in.slot] = h.z; }
         RngCtx rc; rc.seed = P.seed; rc.sample = in.sample; rc.node = in.node;
-        if (p13) shade_p13<MODEL>(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
-        else shade_fin(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
+        if (p3) shade_p3<TEX>(S, P, h, in.o, rc, o, stack, cnt);
+        else if (p6) shade_p6<TEX>(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
+        else if (p13) shade_p13<MODEL, TEX>(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
+        else shade_fin<TEX>(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
         add_sample(C, in.slot, thr * o.color, in.primary);
         // a child (or query) whose accumulated weight is exactly zero cannot change the pixel
         const V3 wr = thr * o.rK, wt = thr * o.tK, wp = thr * o.kd;
@@ -786,6 +947,13 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
     // pushes are wave-collective: every lane of the wave reaches them
     push_ray(C, o.want_refl, h.p, o.rdir, thr * o.rK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFLECT,
              child_node(in.node, 1u), in.sample);
+    if (p6) {
+        const V3 sK = thr * o.side_K;
+        push_ray<true>(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
+                       child_node(in.node, 2u), in.sample, o.side_dir, o.want_side ? sK : mk(0, 0, 0));
+        // the side ray of an arriving refraction ray: same origin and level as that ray
+        push_ray(C, spawn_side, in.o, in.side_dir, in.side_K, mk(0, 0, 0), in.slot, in.bounce, KIND_REFLECT, child_node(in.node, 4u), in.sample);
+    } else
     push_ray(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
              child_node(in.node, 2u), in.sample);
     push_photon_query(C, o.want_photon, h.p, o.N, thr * o.kd, in.slot);
@@ -860,7 +1028,7 @@ struct PrimaryArgs {
     const float *rays;           // mode 2
 };
 
-template <int MODEL>
+template <int MODEL, bool TEX>
 __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
@@ -877,6 +1045,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
         PathIn in;
         in.thr = mk(1.f, 1.f, 1.f); in.absorb = mk(0, 0, 0); in.bounce = C.P.bounce; in.kind = KIND_REFLECT; in.primary = true;
         in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.slot = 0; in.node = 1; in.sample = 0;
+        in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
         if (active) {
             const uint32_t pi = (uint32_t)(gid / (unsigned long long)A.ns);
             const int j = A.j0 + (int)(gid % (unsigned long long)A.ns);
@@ -919,13 +1088,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
             }
         }
         if (active) nprim++;
-        shade_path<MODEL>(C, in, active, stack, cnt);
+        shade_path<MODEL, TEX>(C, in, active, stack, cnt);
     }
     flush_counters(C.W.stats, cnt, nprim, 0, 0);
 }
 
 // K2-K4 for one level of the ray tree: reads queue `qin` (count in counts[level]).
-template <int MODEL>
+template <int MODEL, bool TEX>
 __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin, int level)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
@@ -941,15 +1110,21 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin
         PathIn in;
         in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
         in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0;
+        in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
         if (active) {
             const float4 a = qin.a[gid], b = qin.b[gid], c = qin.c[gid];
             const uint4 dd = qin.d[gid];
             in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
             in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
             in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.node = dd.z; in.sample = dd.w;
+            if (MODEL == RT_SHADE_P6 && in.kind == KIND_REFRACT) {
+                const float4 e = qin.e[gid];
+                in.side_dir = mk(e.x, e.y, e.z); in.side_K = mk(e.w, c.z, c.w);
+                in.absorb = mk(c.y, 0, 0);
+            }
             if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
         }
-        shade_path<MODEL>(C, in, active, stack, cnt);
+        shade_path<MODEL, TEX>(C, in, active, stack, cnt);
     }
     flush_counters(C.W.stats, cnt, 0, nrefl, nrefr);
 }
@@ -1014,7 +1189,6 @@ struct PhotonArgs {
     uint32_t *count;       // [n_attempts]
 };
 
-__device__ __forceinline__ float gray(V3 c) { return (c.x + c.y + c.z) / 3.0f; }
 
 // MtlBlinn::RandomPhotonBounce, FIN/include/materials.h:99-256 (glossiness 0 branches)
 __device__ bool random_photon_bounce(const rt_blinn &m, const Hit &h, V3 &rp, V3 &rd, V3 &c, Philox &rng)
@@ -1633,9 +1807,17 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
     PrimaryArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.j0 = j0; A.ns = ns;
     A.max_sample = max_sample; A.mode = mode; A.rays = rays;
     const int grid = grid_for((unsigned long long)npix * ns, RT_BLOCK, max_blocks);
-    if (P.shade_model == RT_SHADE_P13) hipLaunchKernelGGL(k_primary<RT_SHADE_P13>, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
-    else if (P.shade_model == RT_SHADE_P12) hipLaunchKernelGGL(k_primary<RT_SHADE_P12>, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
-    else hipLaunchKernelGGL(k_primary<RT_SHADE_FIN>, dim3(grid), dim3(RT_BLOCK), 0, st, C, A);
+    const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
+#define RT_LAUNCH_PRIMARY(M) do { if (tex) hipLaunchKernelGGL((k_primary<M, true>), dim3(grid), dim3(RT_BLOCK), 0, st, C, A); \
+                                  else hipLaunchKernelGGL((k_primary<M, false>), dim3(grid), dim3(RT_BLOCK), 0, st, C, A); } while (0)
+    switch (P.shade_model) {
+    case RT_SHADE_P13: RT_LAUNCH_PRIMARY(RT_SHADE_P13); break;
+    case RT_SHADE_P12: RT_LAUNCH_PRIMARY(RT_SHADE_P12); break;
+    case RT_SHADE_P6: RT_LAUNCH_PRIMARY(RT_SHADE_P6); break;
+    case RT_SHADE_P3: RT_LAUNCH_PRIMARY(RT_SHADE_P3); break;
+    default: RT_LAUNCH_PRIMARY(RT_SHADE_FIN);
+    }
+#undef RT_LAUNCH_PRIMARY
 }
 
 void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
@@ -1643,16 +1825,25 @@ void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, cons
                        int level, int max_blocks)
 {
     ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
-    if (P.shade_model == RT_SHADE_P13) hipLaunchKernelGGL(k_bounce<RT_SHADE_P13>, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
-    else if (P.shade_model == RT_SHADE_P12) hipLaunchKernelGGL(k_bounce<RT_SHADE_P12>, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
-    else hipLaunchKernelGGL(k_bounce<RT_SHADE_FIN>, dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level);
+    const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
+#define RT_LAUNCH_BOUNCE(M) do { if (tex) hipLaunchKernelGGL((k_bounce<M, true>), dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level); \
+                                 else hipLaunchKernelGGL((k_bounce<M, false>), dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level); } while (0)
+    switch (P.shade_model) {
+    case RT_SHADE_P13: RT_LAUNCH_BOUNCE(RT_SHADE_P13); break;
+    case RT_SHADE_P12: RT_LAUNCH_BOUNCE(RT_SHADE_P12); break;
+    case RT_SHADE_P6: RT_LAUNCH_BOUNCE(RT_SHADE_P6); break;
+    case RT_SHADE_P3: break;                               // P3 has no secondary rays
+    default: RT_LAUNCH_BOUNCE(RT_SHADE_FIN);
+    }
+#undef RT_LAUNCH_BOUNCE
 }
 
 void rtk_launch_trace(hipStream_t st, const DevScene &S, int model, const float *rays, long long n,
                       uint8_t *hit, float *z, float *p, float *N, int32_t *node, uint8_t *front)
 {
     const int grid = grid_for((unsigned long long)n, RT_BLOCK, 4096);
-    if (model != RT_SHADE_FIN) hipLaunchKernelGGL(k_trace<RT_SHADE_P13>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
+    if (model == RT_SHADE_P3) hipLaunchKernelGGL(k_trace<RT_SHADE_P3>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
+    else if (model != RT_SHADE_FIN) hipLaunchKernelGGL(k_trace<RT_SHADE_P13>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
     else hipLaunchKernelGGL(k_trace<RT_SHADE_FIN>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
 }
 

@@ -343,6 +343,52 @@ def test_p12_live_gi_model(cornell):
     assert (diff <= 1).mean() > 0.97 and (diff <= 4).mean() > 0.995 and (z2 == oz2).mean() > 0.999
 
 
+def _load(name, width=None, height=None):
+    import os
+    s = capi.Scene()
+    s.load_xml(os.path.join(scenes.GOLD, name))
+    cam = s.camera()
+    if width:
+        cam.width, cam.height = width, height
+    return s, cam
+
+
+def test_config1_p3_spheres_frame():
+    """BASELINE config 1: RayTracingProj3 semantics (spheres without bias, direct light + hard shadows,
+    V = camera - p, 1 sample at the pixel centre, no gamma), 640 x 480"""
+    s, cam = _load("p3_spheres.xml")
+    assert (cam.width, cam.height) == (640, 480)
+    p = capi.default_params(shade_model=capi.SHADE_P3, min_sample=1, max_sample=1, threshold=-1.0, gamma=1.0, bounce=0)
+    rgb, z, cnt, st, progress = s.render(cam, p)
+    orgb, oz, ocnt = orc.render(scenes.oracle_scene(s.export()), scenes.oracle_camera(cam), scenes.oracle_params(p))
+    assert progress == 640 * 480 and st.rays_primary == 640 * 480 and st.rays_reflect == 0
+    diff = np.abs(rgb.astype(int) - orgb.astype(int)).max(axis=2)
+    # P3's unbiased spheres make shadow rays graze their own surface: a last-ulp difference in the hit
+    # point flips such a pixel between lit and shadowed ("acne"); everything else is exact
+    assert (diff == 0).mean() > 0.99 and (z == oz).all()
+    assert (cnt == 0).all()
+
+
+def test_config2_p6_teapots_frame():
+    """BASELINE config 2: RayTracingProj6 semantics (BVH teapots with reflection 0.7, absorbing glass,
+    bounce limit 5, no light fall-off, 1 sample, no gamma), 400 x 300 here (800 x 600 in the config)"""
+    s, cam = _load("p6_scene.xml", 400, 300)
+    p = capi.default_params(shade_model=capi.SHADE_P6, min_sample=1, max_sample=1, threshold=-1.0, gamma=1.0, bounce=5)
+    e = s.export()
+    assert e["nodes"]["mesh"].tolist().count(0) == 2            # two instances share one mesh
+    osc = scenes.oracle_scene(e)
+    rays = _aimed_rays(cam, 51, n_cam=1500)
+    ohit, orgb, oz = orc.shade_rays(osc, scenes.oracle_params(p), rays)
+    hit, rgb1, z1 = s.shade_rays(p, rays)
+    assert (hit == ohit).all() and z1.tobytes() == oz.tobytes()
+    assert _close(rgb1, orgb, rel=5e-5, abs_=2e-6).mean() > 0.999
+    rgb, z, cnt, st, _ = s.render(cam, p)
+    orgb, oz, ocnt = orc.render(osc, scenes.oracle_camera(cam), scenes.oracle_params(p))
+    diff = np.abs(rgb.astype(int) - orgb.astype(int)).max(axis=2)
+    assert (diff <= 1).mean() > 0.999 and (z == oz).all()
+    assert st.rays_reflect > 0 and st.rays_refract > 0
+
+
 def test_textured_scene(gold):
     """checkerboard + file textures with map transforms on planes / sphere / mesh, textured environment
     (refraction misses) and background (missed pixels): rays and a frame against the oracle"""
