@@ -73,6 +73,24 @@ def cpu_baseline(scene_export, balanced, cam, params, budget_s):
             "frame_s_extrapolated": round(cam.width * cam.height / (px / dt), 1)}
 
 
+def measured_traffic(kernel, default_workload):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_bench_pmc_hbm.json,
+    made by tools_profile_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+    command, with the gfx950 x2 fetch correction).  PMC counters cannot be read from inside bench.py, so the
+    figure is only quoted for the default workload it was measured on; otherwise null."""
+    import glob
+    if not default_workload:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_hbm.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return float(d["kernels"][kernel]["hbm_bytes_per_launch"]), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def main():
     a = parse()
     import torch
@@ -161,9 +179,13 @@ def main():
         t_bytes = my_rays * 48.0 + my["instance_visits"] * 84.0 + my["bvh_nodes_visited"] * 28.0 + my["tris_tested"] * 48.0
         t_gbs = t_bytes / (ms["ms_trace"] * 1e-3) / 1e9 if ms["ms_trace"] > 0 else 0.0
         gather_dominant = ms["ms_gather"] >= ms["ms_trace"]
+        default_workload = (a.width, a.height, a.spp, a.photons, a.synthetic_photons, world) == (1920, 1080, 64, 1000000, False, 1)
+        traffic, traffic_src = measured_traffic("k_gather", default_workload and gather_dominant)
         roof = {"bound": "hbm", "kernel": "k_gather" if gather_dominant else "k_primary+k_bounce",
                 "achieved": round(g_gbs if gather_dominant else t_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round((g_gbs if gather_dominant else t_gbs) / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round((g_gbs if gather_dominant else t_gbs) / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(g_bytes / max(launches_g, 1)) if gather_dominant else None,
                 "avg_launch_ms": round(ms["ms_gather"] / max(launches_g, 1), 4) if gather_dominant else None,
                 "launches": int(launches_g) if gather_dominant else int(sum(x["launches_trace"] for x in stats)),
                 "other": {"k_gather_GBps": round(g_gbs, 2), "trace_shade_GBps": round(t_gbs, 2),
