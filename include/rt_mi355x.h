@@ -216,6 +216,14 @@ rt_status rt_scene_set_mesh(rt_scene *s, int32_t mesh,
                             const float *vn, int32_t nvn, const uint32_t *fn,
                             const rt_bvh_node *nodes, int32_t nnodes,
                             const uint32_t *elements);
+/* cyTriMesh VT/FT (FIN/include/cyTriMesh.h:108-109): the texture vertices (uvw triples) and the
+ * 3 texture indices per face of a mesh already set.  Read by the PROJ13-family triangle, whose
+ * hit takes uvw = GetTexCoord(face, barycentric) (P13/include/objects.h:203); the FINAL triangle
+ * never writes uvw (FIN/include/objects.h:226-267).  nvt == 0 removes them; a PROJ13 mesh without
+ * them leaves uvw as it was (the reference dereferences a null vt there).
+ * rt_scene_set_mesh clears them, so call this after it. */
+rt_status rt_scene_set_mesh_texcoords(rt_scene *s, int32_t mesh, const float *vt, int32_t nvt,
+                                      const uint32_t *ft);
 rt_status rt_scene_set_materials(rt_scene *s, const rt_blinn *m, int32_t n);
 rt_status rt_scene_set_lights(rt_scene *s, const rt_light *l, int32_t n);
 /* environment / background colour (FIN/include/scene.h:406-434; textures: not yet) */
@@ -253,6 +261,8 @@ rt_status rt_scene_mesh_counts(const rt_scene *s, int32_t mesh, int32_t *nv, int
                                int32_t *nvn, int32_t *nnodes);
 rt_status rt_scene_get_mesh(const rt_scene *s, int32_t mesh, float *v, uint32_t *f, float *vn,
                             uint32_t *fn, rt_bvh_node *nodes, uint32_t *elements);
+rt_status rt_scene_get_mesh_texcoords(const rt_scene *s, int32_t mesh, int32_t *nvt, float *vt,
+                                      uint32_t *ft);
 
 /* Image files: what TextureFile::Load gets from lodepng::decode(..., LCT_RGB) / LoadPPM
  * (FIN/texture.cpp:33-91) and RenderImage::SavePNG from lodepng::encode (FIN/include/scene.h:645-655).

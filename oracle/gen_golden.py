@@ -148,6 +148,53 @@ def gen_mesh(model):
     print(f"mesh[{model}]: nv={len(v)} nf={len(f)} nvn={len(vn)} nnodes={len(nodes)} hits={int(hits['hit'].sum())}")
 
 
+def gen_mesh_mtl():
+    """tests/golden/twotone.obj + .mtl through the reference loader with loadMtl = true: face
+    regrouping by material, texture vertices/faces, the .mtl fields; and, for the PROJ13 triangle,
+    the uvw each hit carries."""
+    obj = os.path.join(GOLD, "twotone.obj")
+    rng = np.random.default_rng(211)
+    n = 2048
+    o = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+    o[:, 2] = rng.uniform(-3, 5, n)
+    tgt = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1.6, n), rng.uniform(0, 2, n)], 1).astype(np.float32)
+    d = (tgt - o).astype(np.float32)
+    r = np.concatenate([o, d, np.full((n, 1), 1.0e30, np.float32)], 1).astype(np.float32)
+    res = {}
+    for model in ("fin", "p13"):
+        with tempfile.TemporaryDirectory() as td:
+            open(td + "/in.bin", "wb").write(struct.pack("<i", n) + r.tobytes())
+            subprocess.run([HARNESS[model], "meshmtl", td + "/in.bin", td + "/out.bin", obj,
+                            td + "/mtl.bin"], check=True, stdout=subprocess.DEVNULL)
+            out = open(td + "/out.bin", "rb").read()
+            mb = open(td + "/mtl.bin", "rb").read()
+            uv = np.fromfile(td + "/mtl.bin.uvw", "<f4").reshape(n, 3)
+        v, f, vn, fn, nodes, elements, hits = parse_mesh(out)
+        nm, nvt = struct.unpack_from("<2i", mb, 0)
+        off = 8
+        mt = np.zeros(nm, [("Kd", "<f4", 3), ("Ks", "<f4", 3), ("Tf", "<f4", 3), ("Ns", "<f4"), ("Ni", "<f4"),
+                           ("illum", "<i4"), ("mcfc", "<i4")])
+        names = []
+        for i in range(nm):
+            mt[i] = np.frombuffer(mb, mt.dtype, 1, off)[0]
+            off += mt.dtype.itemsize
+            names.append([mb[off:off + 256].split(b"\0")[0].decode(), mb[off + 256:off + 512].split(b"\0")[0].decode()])
+            off += 512
+        vt = np.frombuffer(mb, "<f4", nvt * 3, off).reshape(nvt, 3); off += vt.nbytes
+        ft = np.frombuffer(mb, "<u4", len(f) * 3, off).reshape(len(f), 3)
+        res[model] = dict(v=v, f=f, vn=vn, fn=fn, nodes=nodes, elements=elements, hits=hits, uvw=uv, mtl=mt,
+                          map_Kd=np.array([x[0] for x in names]), map_Ks=np.array([x[1] for x in names]), vt=vt, ft=ft)
+    a, b = res["fin"], res["p13"]
+    for k in ("v", "f", "vn", "fn", "elements", "vt", "ft", "map_Kd", "map_Ks"):
+        assert (a[k] == b[k]).all(), k
+    assert a["nodes"].tobytes() == b["nodes"].tobytes() and a["mtl"].tobytes() == b["mtl"].tobytes()
+    assert (a["uvw"] == 0.5).all()                   # the FINAL triangle never writes uvw
+    np.savez_compressed(os.path.join(GOLD, "mesh_twotone.npz"), rays=r, hits_fin=a["hits"], hits_p13=b["hits"],
+                        uvw_p13=b["uvw"], **{k: a[k] for k in ("v", "f", "vn", "fn", "nodes", "elements", "vt", "ft", "mtl",
+                                                              "map_Kd", "map_Ks")})
+    print(f"mesh_twotone: nf={len(a['f'])} nm={len(a['mtl'])} hits fin={int(a['hits']['hit'].sum())} p13={int(b['hits']['hit'].sum())}")
+
+
 NODE_OPS = {
     # (kind, a0..a3): 0 scale xyz, 1 rotate axis xyz + degrees, 2 translate xyz -- Cornell scene.xml
     "box_group": [(2, 0, 0, 12, 0)],
@@ -323,6 +370,7 @@ def main():
     gen_box()
     gen_mesh("fin")
     gen_mesh("p13")
+    gen_mesh_mtl()
     gen_node()
     gen_misc()
     gen_texture()
@@ -333,4 +381,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:          # regenerate only the named fixtures, e.g. `gen_golden.py mesh_mtl`
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+    else:
+        main()

@@ -58,7 +58,8 @@ def default_params(**kw):
 class _Mesh(C.Structure):
     _fields_ = [("v", C.c_void_p), ("nv", C.c_int32), ("f", C.c_void_p), ("nf", C.c_int32),
                 ("vn", C.c_void_p), ("nvn", C.c_int32), ("fn", C.c_void_p),
-                ("nodes", C.c_void_p), ("nnodes", C.c_int32), ("elements", C.c_void_p)]
+                ("nodes", C.c_void_p), ("nnodes", C.c_int32), ("elements", C.c_void_p),
+                ("vt", C.c_void_p), ("nvt", C.c_int32), ("ft", C.c_void_p)]
 
 
 class _Scene(C.Structure):
@@ -104,17 +105,20 @@ def _c(a, dt):
 
 
 class Mesh:
-    def __init__(self, v, f, vn, fn, nodes, elements):
+    def __init__(self, v, f, vn, fn, nodes, elements, vt=None, ft=None):
         self.v = _c(v, np.float32).reshape(-1, 3)
         self.f = _c(f, np.uint32).reshape(-1, 3)
         self.vn = _c(vn, np.float32).reshape(-1, 3)
         self.fn = _c(fn, np.uint32).reshape(-1, 3)
         self.nodes = _c(nodes, BVHNODE)
         self.elements = _c(elements, np.uint32)
+        self.vt = _c(vt, np.float32).reshape(-1, 3) if vt is not None and len(vt) else None
+        self.ft = _c(ft, np.uint32).reshape(-1, 3) if self.vt is not None else None
 
     def c(self):
         return _Mesh(_p(self.v), len(self.v), _p(self.f), len(self.f), _p(self.vn), len(self.vn),
-                     _p(self.fn), _p(self.nodes), len(self.nodes), _p(self.elements))
+                     _p(self.fn), _p(self.nodes), len(self.nodes), _p(self.elements),
+                     _p(self.vt), len(self.vt) if self.vt is not None else 0, _p(self.ft))
 
 
 class Scene:
@@ -162,6 +166,7 @@ def _prim(fn, model, rays, z0):
     hits = np.zeros(n, HIT)
     hit = np.zeros(n, np.int32)
     hits["z"] = z0
+    hits["uvw"] = 0.5           # HitInfo::Init(), scene.h:163
     hits["front"] = 1
     hits["node"] = -1
     for i in range(n):

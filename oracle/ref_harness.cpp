@@ -102,10 +102,30 @@ static int cmd_box(const char *in, const char *out)
 // in: int32 n; n x {float ray[6]; float z0}
 // out: int32 nv,nf,nvn,nnodes(with node 0); v[nv*3] f[nf*3] vn[nvn*3] fn[nf*3]
 //      nodes[nnodes] x {float box[6]; uint32 data}; elements[nf]; then n x HitRec
-static int cmd_mesh(const char *in, const char *out, const char *objpath)
+static int cmd_mesh(const char *in, const char *out, const char *objpath, bool loadMtl = false, const char *mtlout = nullptr)
 {
     TriObj *tobj = new TriObj;
-    if (!tobj->Load(objpath, false)) { fprintf(stderr, "load failed\n"); return 3; }
+    if (!tobj->Load(objpath, loadMtl)) { fprintf(stderr, "load failed\n"); return 3; }
+    if (mtlout) {
+        // int32 nm, nvt; per material: Kd[3] Ks[3] Tf[3] Ns Ni (floats), illum (int32), cumulative face count (int32),
+        //                 256-byte map_Kd, 256-byte map_Ks; then vt[nvt*3] floats and ft[nf*3] uint32
+        Out m(mtlout);
+        int32_t nm = tobj->NM(), nvt = tobj->NVT();
+        m.put(nm); m.put(nvt);
+        int cum = 0;
+        for (int i = 0; i < nm; i++) {
+            const cyTriMesh::Mtl &mt = tobj->M(i);
+            m.bytes(mt.Kd, 12); m.bytes(mt.Ks, 12); m.bytes(mt.Tf, 12); m.put(mt.Ns); m.put(mt.Ni);
+            int32_t il = mt.illum; m.put(il);
+            cum += tobj->GetMaterialFaceCount(i);
+            int32_t c = cum; m.put(c);
+            char buf[256];
+            memset(buf, 0, 256); if (mt.map_Kd.data) strncpy(buf, mt.map_Kd.data, 255); m.bytes(buf, 256);
+            memset(buf, 0, 256); if (mt.map_Ks.data) strncpy(buf, mt.map_Ks.data, 255); m.bytes(buf, 256);
+        }
+        for (int i = 0; i < nvt; i++) { m.put(tobj->VT(i).x); m.put(tobj->VT(i).y); m.put(tobj->VT(i).z); }
+        if (nvt) for (unsigned i = 0; i < tobj->NF(); i++) for (int k = 0; k < 3; k++) { uint32_t x = tobj->FT(i).v[k]; m.put(x); }
+    }
     // TriObj::bvh is private: rebuild an identical one through the public class (deterministic build)
     cyBVHTriMesh bvh;
     bvh.SetMesh(tobj, 4);
@@ -143,11 +163,17 @@ static int cmd_mesh(const char *in, const char *out, const char *objpath)
     std::vector<char> b = slurp(in);
     int32_t n = *(int32_t *)b.data();
     const float *d = (const float *)(b.data() + 4);
+    std::vector<float> uv;
     for (int i = 0; i < n; i++) {
         Ray r(Point3(d[7 * i], d[7 * i + 1], d[7 * i + 2]), Point3(d[7 * i + 3], d[7 * i + 4], d[7 * i + 5]));
         HitInfo hi; hi.Init(); hi.z = d[7 * i + 6];
         bool h = tobj->TriObj::IntersectRay(r, hi);
         o.put(rec(h, hi));
+        uv.push_back(hi.uvw.x); uv.push_back(hi.uvw.y); uv.push_back(hi.uvw.z);
+    }
+    if (mtlout) {       // HitInfo::uvw after each ray (0.5,0.5,0.5 from Init() unless the triangle wrote it)
+        Out u((std::string(mtlout) + ".uvw").c_str());
+        if (!uv.empty()) u.bytes(uv.data(), uv.size() * sizeof(float));
     }
     return 0;
 }
@@ -343,6 +369,7 @@ int main(int argc, char **argv)
     if (cmd == "prims") return cmd_prims(argv[2], argv[3]);
     if (cmd == "box") return cmd_box(argv[2], argv[3]);
     if (cmd == "mesh") { if (argc < 5) return 1; return cmd_mesh(argv[2], argv[3], argv[4]); }
+    if (cmd == "meshmtl") { if (argc < 6) return 1; return cmd_mesh(argv[2], argv[3], argv[4], true, argv[5]); }
     if (cmd == "node") return cmd_node(argv[2], argv[3]);
     if (cmd == "misc") return cmd_misc(argv[2], argv[3]);
     if (cmd == "photon") return cmd_photon(argv[2], argv[3]);

@@ -338,6 +338,15 @@ static int tri_intersect_p13(const orc_mesh *m, const float ray[6], orc_hit *hit
     st3(hit->p, vadd(vadd(vscale(A, alpha), vscale(B, beta)), vscale(C, gamma_)));
     st3(hit->N, vnorm(PN));
     hit->z = t;
+    /* hInfo.uvw = GetTexCoord(faceID, bc) = Interpolate(faceID, vt, ft, bc), P13/include/objects.h:203,
+     * cyTriMesh.h:173,191.  Without texture vertices the reference reads through a null vt; here uvw
+     * stays as it was. */
+    if (m->vt && m->ft) {
+        const uint32_t *ft = m->ft + 3 * (size_t)face;
+        v3 uvw = vadd(vadd(vscale(v3p(m->vt + 3 * (size_t)ft[0]), alpha), vscale(v3p(m->vt + 3 * (size_t)ft[1]), beta)),
+                      vscale(v3p(m->vt + 3 * (size_t)ft[2]), gamma_));
+        st3(hit->uvw, uvw);
+    }
     return 1;
 }
 

@@ -34,6 +34,8 @@ typedef struct orc_mesh {
     const uint32_t *fn;
     const rt_bvh_node *nodes; int32_t nnodes;
     const uint32_t *elements;
+    const float *vt;     int32_t nvt;     /* texture vertices (uvw triples) or NULL */
+    const uint32_t *ft;                   /* 3 texture indices per face or NULL */
 } orc_mesh;
 
 typedef struct orc_scene {

@@ -71,6 +71,7 @@ class Stats(C.Structure):
 SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_params_default",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_set_nodes", "rt_scene_set_mesh",
+    "rt_scene_set_mesh_texcoords", "rt_scene_get_mesh_texcoords",
     "rt_scene_set_materials", "rt_scene_set_lights", "rt_scene_set_environment",
     "rt_scene_set_photons", "rt_scene_set_textures", "rt_scene_set_material_maps", "rt_scene_set_environment_maps",
     "rt_scene_get_textures", "rt_scene_get_maps", "rt_image_read_rgb", "rt_image_write_png", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
@@ -196,12 +197,19 @@ class Scene:
         nodes = _c(nodes, NODE)
         _check(lib().rt_scene_set_nodes(self._h, _p(nodes), len(nodes)))
 
-    def set_mesh(self, index, v, f, vn, fn, nodes, elements):
+    def set_mesh(self, index, v, f, vn, fn, nodes, elements, vt=None, ft=None):
         v, vn = _c(v, np.float32).reshape(-1, 3), _c(vn, np.float32).reshape(-1, 3)
         f, fn = _c(f, np.uint32).reshape(-1, 3), _c(fn, np.uint32).reshape(-1, 3)
         nodes, elements = _c(nodes, BVHNODE), _c(elements, np.uint32)
         _check(lib().rt_scene_set_mesh(self._h, int(index), _p(v), len(v), _p(f), len(f), _p(vn), len(vn),
                                        _p(fn), _p(nodes), len(nodes), _p(elements)))
+        if vt is not None and len(vt):
+            self.set_mesh_texcoords(index, vt, ft)
+
+    def set_mesh_texcoords(self, index, vt, ft):
+        """cyTriMesh VT/FT of a mesh already set (read by the PROJ13-family triangle)."""
+        vt, ft = _c(vt, np.float32).reshape(-1, 3), _c(ft, np.uint32).reshape(-1, 3)
+        _check(lib().rt_scene_set_mesh_texcoords(self._h, int(index), _p(vt), len(vt), _p(ft)))
 
     def set_materials(self, m):
         m = _c(m, BLINN)
@@ -272,6 +280,11 @@ class Scene:
                      nodes=np.zeros(nn, BVHNODE), elements=np.zeros(nf, np.uint32))
             _check(lib().rt_scene_get_mesh(self._h, m, _p(d["v"]), _p(d["f"]), _p(d["vn"]), _p(d["fn"]),
                                            _p(d["nodes"]), _p(d["elements"])))
+            nvt = C.c_int32()
+            _check(lib().rt_scene_get_mesh_texcoords(self._h, m, C.byref(nvt), None, None))
+            d["vt"], d["ft"] = np.zeros((nvt.value, 3), np.float32), np.zeros((nf if nvt.value else 0, 3), np.uint32)
+            if nvt.value:
+                _check(lib().rt_scene_get_mesh_texcoords(self._h, m, None, _p(d["vt"]), _p(d["ft"])))
             meshes.append(d)
         ntex, nbytes = C.c_int32(), C.c_uint64()
         _check(lib().rt_scene_get_textures(self._h, None, 0, None, C.c_uint64(0), C.byref(ntex), C.byref(nbytes)))

@@ -79,13 +79,21 @@ bool MtlBlinn::Lower(rt_blinn &o) const
     return true;
 }
 
+bool MultiMtl::Lower(rt_blinn &o) const
+{
+    if (mtls.empty()) return false;
+    return mtls[0]->Lower(o);
+}
+
 // ---- OBJ loading -----------------------------------------------------------------------------
 // Behaviour of cyTriMesh::LoadFromFileObj (FIN/include/cyTriMesh.h:263-462) for geometry:
 // whitespace-collapsed lines of at most 1023 characters, '#' comment lines, v / vt / vn /
 // f records, polygons fan-triangulated around their first vertex, 1-based or negative
 // (relative) indices, "v", "v/vt", "v//vn", "v/vt/vn" corner forms.  Normal faces exist from
-// the first `vn` line or the first corner with a normal index onwards.  Material libraries are
-// not read (the Cornell scenes name a scene material for the mesh: loadMtl == false).
+// the first `vn` line or the first corner with a normal index onwards, texture faces likewise
+// from the first `vt`.  With loadMtl (the node names no scene material, xmlload.cpp:204) `usemtl`
+// groups the faces by material in order of first use and `mtllib` files are read for
+// Kd/Ks/Tf/Ns/Ni/illum/map_Kd/map_Ks (:437-447, 466-544).
 namespace {
 struct LineReader {
     FILE *fp;
@@ -122,15 +130,19 @@ struct LineReader {
 };
 }  // namespace
 
-bool TriObj::LoadFromFileObj(const char *filename, std::string *err)
+bool TriObj::LoadFromFileObj(const char *filename, bool loadMtl, std::string *err)
 {
     FILE *fp = fopen(filename, "r");
     if (!fp) { if (err) *err = std::string("cannot open OBJ file ") + filename; return false; }
-    v.clear(); vn.clear(); f.clear(); fn.clear();
+    v.clear(); vn.clear(); vt.clear(); f.clear(); fn.clear(); ft.clear(); mtls.clear(); mcfc.clear();
     LineReader in; in.fp = fp;
-    std::vector<float> vt;                  // counted only (relative vt indices)
-    std::vector<uint32_t> tf;
-    bool hasNormals = false;
+    std::vector<uint32_t> rf, rfn, rft;     // faces in file order
+    std::vector<int> faceMtl;               // material of every triangle (-1: none)
+    struct MtlData { std::string name; uint32_t firstFace = 0, faceCount = 0; };
+    std::vector<MtlData> mtlList;
+    std::vector<std::string> mtlFiles;
+    int currentMtl = -1;
+    bool hasNormals = false, hasTextures = false;
     while (int rb = in.ReadLine()) {
         if (in.IsCommand("v") || in.IsCommand("vt") || in.IsCommand("vn")) {
             float p[3] = {0, 0, 0};
@@ -138,25 +150,32 @@ bool TriObj::LoadFromFileObj(const char *filename, std::string *err)
             std::vector<float> &dst = in.data[1] == 't' ? vt : (in.data[1] == 'n' ? vn : v);
             dst.insert(dst.end(), p, p + 3);
             if (in.data[1] == 'n') hasNormals = true;
+            if (in.data[1] == 't') hasTextures = true;
         } else if (in.IsCommand("f")) {
             int facevert = -1;
             bool inspace = true, negative = false;
             int type = 0;
             uint32_t index = 0;
-            uint32_t face[3] = {0, 0, 0}, nface[3] = {0, 0, 0};
+            uint32_t face[3] = {0, 0, 0}, nface[3] = {0, 0, 0}, tface[3] = {0, 0, 0};
+            const size_t before = rf.size() / 3;
+            auto emit = [&]() {
+                rf.insert(rf.end(), face, face + 3);
+                if (hasTextures) rft.insert(rft.end(), tface, tface + 3);
+                if (hasNormals) rfn.insert(rfn.end(), nface, nface + 3);
+                faceMtl.push_back(currentMtl);
+            };
             for (int i = 2; i < rb; i++) {
                 const char ch = in.data[i];
                 if (ch == ' ') { inspace = true; continue; }
                 if (inspace) {
                     inspace = false; negative = false; type = 0; index = 0;
                     if (facevert < 2) {
-                        if (facevert == -1) { face[0] = face[1] = face[2] = 0; nface[0] = nface[1] = nface[2] = 0; }
+                        if (facevert == -1) for (int k = 0; k < 3; k++) face[k] = nface[k] = tface[k] = 0;
                         facevert++;
                     } else {
                         // emit the triangle gathered so far and keep (v0, last) for the fan
-                        f.insert(f.end(), face, face + 3);
-                        face[1] = face[2];
-                        if (hasNormals) { fn.insert(fn.end(), nface, nface + 3); nface[1] = nface[2]; }
+                        emit();
+                        face[1] = face[2]; tface[1] = tface[2]; nface[1] = nface[2];
                     }
                 }
                 if (ch == '/') { type++; index = 0; }
@@ -165,24 +184,102 @@ bool TriObj::LoadFromFileObj(const char *filename, std::string *err)
                     index = index * 10 + (uint32_t)(ch - '0');
                     switch (type) {
                     case 0: face[facevert] = negative ? (uint32_t)(v.size() / 3) - index : index - 1; break;
-                    case 1: break;   // texture index: not used on this path
+                    case 1: tface[facevert] = negative ? (uint32_t)(vt.size() / 3) - index : index - 1; hasTextures = true; break;
                     case 2: nface[facevert] = negative ? (uint32_t)(vn.size() / 3) - index : index - 1; hasNormals = true; break;
                     }
                 }
             }
-            f.insert(f.end(), face, face + 3);
-            if (hasNormals) fn.insert(fn.end(), nface, nface + 3);
+            emit();
+            if (currentMtl >= 0) mtlList[currentMtl].faceCount += (uint32_t)(rf.size() / 3 - before);
+        } else if (loadMtl) {
+            if (in.IsCommand("usemtl")) {
+                // MtlList::CreateMtl (cyTriMesh.h:335-345); an empty name means material 0 there, which
+                // is only defined once a material exists
+                const char *nm = rb > 7 ? in.data + 7 : "";
+                int idx = -1;
+                for (size_t i = 0; i < mtlList.size(); i++) if (mtlList[i].name == nm) { idx = (int)i; break; }
+                if (nm[0] == '\0') idx = mtlList.empty() ? -1 : 0;
+                else if (idx < 0) { MtlData m; m.name = nm; m.firstFace = (uint32_t)(rf.size() / 3); mtlList.push_back(m); idx = (int)mtlList.size() - 1; }
+                currentMtl = idx;
+            }
+            if (in.IsCommand("mtllib") && rb > 7) mtlFiles.push_back(in.data + 7);
         }
         if (feof(fp)) break;
     }
     fclose(fp);
-    if (vn.empty()) fn.clear();
-    // the reference sizes fn to the face count once normals exist (SetNumNormals) and copies the
-    // normal faces gathered so far to its front; the tail (faces read before the first normal)
-    // is uninitialised there and zero here
-    if (!vn.empty() && fn.size() < f.size()) fn.insert(fn.end(), f.size() - fn.size(), 0u);
+    const size_t nfaces = rf.size() / 3;
+    if (vn.empty()) rfn.clear();
+    if (vt.empty()) rft.clear();
+    // the reference sizes fn/ft to the face count once normals/texture vertices exist and copies the
+    // faces gathered so far to their front; the tail (faces read before the first one) is
+    // uninitialised there and zero here
+    if (!vn.empty() && rfn.size() < rf.size()) rfn.insert(rfn.end(), rf.size() - rfn.size(), 0u);
+    if (!vt.empty() && rft.size() < rf.size()) rft.insert(rft.end(), rf.size() - rft.size(), 0u);
+    if (!mtlList.empty()) {
+        // faces regrouped by material, materials in order of first use, unassigned faces last
+        // (cyTriMesh.h:466-491)
+        f.reserve(rf.size());
+        auto take = [&](size_t i) {
+            f.insert(f.end(), rf.begin() + 3 * i, rf.begin() + 3 * i + 3);
+            if (!rfn.empty()) fn.insert(fn.end(), rfn.begin() + 3 * i, rfn.begin() + 3 * i + 3);
+            if (!rft.empty()) ft.insert(ft.end(), rft.begin() + 3 * i, rft.begin() + 3 * i + 3);
+        };
+        for (size_t m = 0; m < mtlList.size(); m++) {
+            for (size_t i = mtlList[m].firstFace, j = 0; j < mtlList[m].faceCount && i < nfaces; i++)
+                if (faceMtl[i] == (int)m) { take(i); j++; }
+            mcfc.push_back((uint32_t)(f.size() / 3));
+        }
+        if (f.size() / 3 < nfaces) for (size_t i = 0; i < nfaces; i++) if (faceMtl[i] < 0) take(i);
+        if (f.size() != rf.size()) { if (err) *err = "OBJ material grouping lost faces"; return false; }
+    } else { f.swap(rf); fn.swap(rfn); ft.swap(rft); }
     for (uint32_t idx : f) if (idx >= v.size() / 3) { if (err) *err = "OBJ face index out of range"; return false; }
     for (uint32_t idx : fn) if (idx >= vn.size() / 3) { if (err) *err = "OBJ normal index out of range"; return false; }
+    for (uint32_t idx : ft) if (idx >= vt.size() / 3) { if (err) *err = "OBJ texture index out of range"; return false; }
+
+    // the .mtl files, looked up next to the OBJ (cyTriMesh.h:497-544)
+    if (loadMtl) {
+        mtls.resize(mtlList.size());
+        std::string base = filename;
+        size_t cut = base.find_last_of('\\');
+        if (cut == std::string::npos) cut = base.find_last_of('/');
+        base = cut == std::string::npos ? std::string() : base.substr(0, cut + 1);
+        for (const std::string &lib : mtlFiles) {
+            FILE *mf = fopen((base + lib).c_str(), "r");
+            if (!mf) { fprintf(stderr, "rt_mi355x: cannot open material library \"%s\"\n", (base + lib).c_str()); continue; }
+            LineReader ml; ml.fp = mf;
+            int id = -1;
+            auto f3 = [&](float *dst) {     // Buffer::ReadFloat3: one value means grey
+                dst[0] = dst[1] = dst[2] = 0;
+                const int n = sscanf(ml.data + 2, "%f %f %f", &dst[0], &dst[1], &dst[2]);
+                if (n == 1) dst[2] = dst[1] = dst[0];
+            };
+            auto str = [&](int start, int len) {
+                std::string r;
+                if (len > start) { int st = start; while (ml.data[st] != '\0' && ml.data[st] <= ' ') st++; r = ml.data + st; }
+                return r;
+            };
+            while (int rb = ml.ReadLine()) {
+                if (ml.IsCommand("newmtl")) {
+                    id = -1;
+                    const char *nm = rb > 7 ? ml.data + 7 : "";
+                    for (size_t i = 0; i < mtlList.size(); i++) if (mtlList[i].name == nm) { id = (int)i; break; }
+                    if (id >= 0) mtls[id].name = nm;
+                } else if (id >= 0) {
+                    ObjMtl &m = mtls[id];
+                    if (ml.IsCommand("Kd")) f3(m.Kd);
+                    else if (ml.IsCommand("Ks")) f3(m.Ks);
+                    else if (ml.IsCommand("Tf")) f3(m.Tf);
+                    else if (ml.IsCommand("Ns")) sscanf(ml.data + 2, "%f", &m.Ns);
+                    else if (ml.IsCommand("Ni")) sscanf(ml.data + 2, "%f", &m.Ni);
+                    else if (ml.IsCommand("illum") && rb > 5) sscanf(ml.data + 5, "%d", &m.illum);
+                    else if (ml.IsCommand("map_Kd")) m.map_Kd = str(7, rb);
+                    else if (ml.IsCommand("map_Ks")) m.map_Ks = str(7, rb);
+                }
+                if (feof(mf)) break;
+            }
+            fclose(mf);
+        }
+    }
     return true;
 }
 
@@ -214,9 +311,8 @@ void TriObj::BuildBVH(unsigned maxElementsPerNode)
 // TriObj::Load, FIN/include/objects.h:137-145
 bool TriObj::Load(const char *filename, bool loadMtl, std::string *err)
 {
-    (void)loadMtl;
     nodes.clear(); elements.clear();
-    if (!LoadFromFileObj(filename, err)) return false;
+    if (!LoadFromFileObj(filename, loadMtl, err)) return false;
     if (!HasNormals()) ComputeNormals();
     BuildBVH(4);
     return true;
@@ -478,7 +574,7 @@ bool Lower(const Scene &scene, SceneData &out, std::string *err)
     if (!L.ok) return false;
     for (const TriObj *t : L.meshes) {
         MeshData m;
-        m.v = t->v; m.vn = t->vn; m.f = t->f; m.fn = t->fn; m.nodes = t->nodes; m.elements = t->elements;
+        m.v = t->v; m.vn = t->vn; m.f = t->f; m.fn = t->fn; m.vt = t->vt; m.ft = t->ft; m.nodes = t->nodes; m.elements = t->elements;
         out.meshes.push_back(std::move(m));
     }
     for (const Material *m : L.mats) {

@@ -146,20 +146,34 @@ class Sphere : public Object { public: int Kind() const override { return RT_OBJ
 class Plane : public Object { public: int Kind() const override { return RT_OBJ_PLANE; } };
 
 // cyTriMesh arrays + cyBVH arrays of one OBJ (FIN/include/objects.h:124-145)
+// cyTriMesh::Mtl (FIN/include/cyTriMesh.h:74-102): the fields of a .mtl entry this path consumes
+struct ObjMtl {
+    std::string name;
+    float Kd[3] = {1, 1, 1}, Ks[3] = {0, 0, 0}, Tf[3] = {0, 0, 0};
+    float Ns = 0, Ni = 1;
+    int illum = 2;
+    std::string map_Kd, map_Ks;          // empty = not given
+};
+
 class TriObj : public Object {
 public:
-    std::vector<float> v, vn;            // xyz triples
-    std::vector<uint32_t> f, fn;         // 3 indices per face
+    std::vector<float> v, vn, vt;        // xyz triples (vt: uvw)
+    std::vector<uint32_t> f, fn, ft;     // 3 indices per face
+    std::vector<ObjMtl> mtls;            // in order of first `usemtl` (loadMtl only)
+    std::vector<uint32_t> mcfc;          // material cumulative face count (cyTriMesh.h:113)
     std::vector<rt_bvh_node> nodes;      // reference layout, node 0 unused
     std::vector<uint32_t> elements;
     int Kind() const override { return RT_OBJ_MESH; }
     unsigned NV() const { return (unsigned)(v.size() / 3); }
     unsigned NF() const { return (unsigned)(f.size() / 3); }
     unsigned NVN() const { return (unsigned)(vn.size() / 3); }
+    unsigned NVT() const { return (unsigned)(vt.size() / 3); }
+    unsigned NM() const { return (unsigned)mtls.size(); }
     bool HasNormals() const { return NVN() > 0; }
+    bool HasTextureVertices() const { return NVT() > 0; }
     // TriObj::Load: LoadFromFileObj + ComputeNormals if needed + bvh.SetMesh(this,4)
     bool Load(const char *filename, bool loadMtl, std::string *err = nullptr);
-    bool LoadFromFileObj(const char *filename, std::string *err = nullptr);
+    bool LoadFromFileObj(const char *filename, bool loadMtl, std::string *err = nullptr);
     void ComputeNormals();
     void BuildBVH(unsigned maxElementsPerNode = 4);
 };
@@ -227,6 +241,21 @@ public:
     bool Lower(rt_blinn &o) const override;
 };
 
+// MultiMtl (FIN/include/materials.h:385-404): Shade/RandomPhotonBounce/IsPhotonSurface pick
+// mtls[hInfo.mtlID], and nothing on the render path ever sets HitInfo::mtlID after Init() zeroes it
+// (scene.h:163) -- so a MultiMtl renders as its FIRST sub-material on every face, which is what the
+// lowering hands the device.  (With no sub-material Shade returns white; the loader never makes one.)
+class MultiMtl : public Material {
+    std::vector<std::unique_ptr<MtlBlinn>> mtls;
+public:
+    void AppendMaterial(MtlBlinn *m) { mtls.emplace_back(m); }
+    int NumMaterials() const { return (int)mtls.size(); }
+    const MtlBlinn *Sub(int i) const { return mtls[i].get(); }
+    bool Lower(rt_blinn &o) const override;
+    const TextureMap *DiffuseMap() const override { return mtls.empty() ? nullptr : mtls[0]->DiffuseMap(); }
+    const TextureMap *SpecularMap() const override { return mtls.empty() ? nullptr : mtls[0]->SpecularMap(); }
+};
+
 // ---- Node (FIN/include/scene.h:438-514): owns its children, not its Object/Material -------
 class Node : public Transformation {
     std::vector<Node *> child;
@@ -278,8 +307,8 @@ int LoadScene(Scene &scene, const char *filename, std::string *err = nullptr);
 
 // ---- lowered form: exactly what the C ABI setters take -------------------------------------
 struct MeshData {
-    std::vector<float> v, vn;
-    std::vector<uint32_t> f, fn;
+    std::vector<float> v, vn, vt;        // vt/ft empty: the mesh has no texture vertices
+    std::vector<uint32_t> f, fn, ft;
     std::vector<rt_bvh_node> nodes;
     std::vector<uint32_t> elements;
 };

@@ -168,6 +168,21 @@ struct Loader {
 
     void Error(const std::string &m) { ok = false; if (err && err->empty()) *err = m; }
 
+    // ReadTexture(const char*), FIN/xmlload.cpp:535-554: an image shared through the TextureList
+    Texture *ReadTextureFile(const char *texName)
+    {
+        Texture *tex = sc.FindTexture(texName);
+        if (!tex) {
+            std::unique_ptr<TextureFile> f(new TextureFile);
+            const std::string n = texName;
+            f->name = (!n.empty() && n[0] == '/') ? n : dir + n;
+            std::string e2;
+            if (!f->Load(&e2)) fprintf(stderr, "rt_mi355x: cannot load texture \"%s\": %s\n", f->name.c_str(), e2.c_str());   // map stays, samples black
+            else { f->name = texName; tex = f.get(); sc.textureList.push_back(std::move(f)); }
+        }
+        return tex;
+    }
+
     // ReadTexture(TiXmlElement*), FIN/xmlload.cpp:500-530: attribute texture="checkerboard" (children
     // color1/color2) or a PNG/PPM file name shared through the TextureList; the element's own
     // scale/rotate/translate children transform the map
@@ -185,17 +200,7 @@ struct Loader {
             c->name = texName;
             tex = c.get();
             sc.textureList.push_back(std::move(c));
-        } else {
-            tex = sc.FindTexture(texName);
-            if (!tex) {
-                std::unique_ptr<TextureFile> f(new TextureFile);
-                const std::string n = texName;
-                f->name = (!n.empty() && n[0] == '/') ? n : dir + n;
-                std::string e2;
-                if (!f->Load(&e2)) fprintf(stderr, "rt_mi355x: cannot load texture \"%s\": %s\n", f->name.c_str(), e2.c_str());   // map stays, samples black
-                else { f->name = texName; tex = f.get(); sc.textureList.push_back(std::move(f)); }
-            }
-        }
+        } else tex = ReadTextureFile(texName);
         TextureMap *map = new TextureMap(tex);
         LoadTransform(*map, e);
         return map;
@@ -243,6 +248,7 @@ struct Loader {
                     } else {
                         obj = t.get();
                         sc.objList.emplace_back(key, std::move(t));
+                        if (obj->NM() > 0 && !sc.FindMaterial(key)) MakeMultiMtl(*obj, key, node);
                     }
                 }
                 node->SetNodeObj(obj);
@@ -251,6 +257,34 @@ struct Loader {
         }
         for (auto &c : e.children) if (Is(*c, "object")) LoadNode(*node, *c);
         LoadTransform(*node, e);
+    }
+
+    // the multi-material LoadNode generates for an OBJ that brought its own .mtl
+    // (FIN/xmlload.cpp:211-240), including that a map_Ks REPLACES the diffuse texture (:223-224;
+    // the reflection texture of :227 is never sampled by Shade).  Texture names resolve like the
+    // XML's own: relative to the scene file's directory.
+    void MakeMultiMtl(const TriObj &obj, const std::string &name, Node *node)
+    {
+        std::unique_ptr<MultiMtl> mm(new MultiMtl);
+        for (unsigned i = 0; i < obj.NM(); i++) {
+            const ObjMtl &mtl = obj.mtls[i];
+            MtlBlinn *m = new MtlBlinn;
+            m->SetDiffuse(Color(mtl.Kd[0], mtl.Kd[1], mtl.Kd[2]));
+            m->SetSpecular(Color(mtl.Ks[0], mtl.Ks[1], mtl.Ks[2]));
+            m->SetGlossiness(mtl.Ns);
+            m->SetRefractionIndex(mtl.Ni);
+            if (!mtl.map_Kd.empty()) m->SetDiffuseTexture(new TextureMap(ReadTextureFile(mtl.map_Kd.c_str())));
+            if (!mtl.map_Ks.empty()) m->SetDiffuseTexture(new TextureMap(ReadTextureFile(mtl.map_Ks.c_str())));
+            if (mtl.illum > 2 && mtl.illum <= 7) {
+                m->SetReflection(Color(mtl.Ks[0], mtl.Ks[1], mtl.Ks[2]));
+                if (mtl.illum >= 6) m->SetRefraction(Color(1 - mtl.Tf[0], 1 - mtl.Tf[1], 1 - mtl.Tf[2]));
+            }
+            mm->AppendMaterial(m);
+        }
+        mm->name = name;
+        sc.materials.push_back(std::move(mm));
+        node->mtlName = name;
+        nodeMtl.emplace_back(node, name);
     }
 
     // LoadMaterial, FIN/xmlload.cpp:295-371 (textures are not read on this path)

@@ -102,7 +102,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
-struct DevMeshBufs { DevBuf nodes, tris, tri_face, nrm; };
+struct DevMeshBufs { DevBuf nodes, tris, tri_face, nrm, tex; };
 
 struct DeviceState {
     int device = -1;
@@ -121,7 +121,7 @@ struct DeviceState {
     {
         for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &pc, &tbox, &spill, &grid,
                           &sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &stats, &t_in}) b->release();
-        for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); }
+        for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
         for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) rq[i][k].release();
         for (int k = 0; k < 3; k++) pq[k].release();
         for (int k = 0; k < 6; k++) t_out[k].release();
@@ -214,7 +214,35 @@ extern "C" rt_status rt_scene_set_mesh(rt_scene *s, int32_t mesh, const float *v
     m.v.assign(v, v + 3 * (size_t)nv); m.f.assign(f, f + 3 * (size_t)nf);
     m.vn.assign(vn, vn + 3 * (size_t)nvn); m.fn.assign(fn, fn + 3 * (size_t)nf);
     m.nodes.assign(nodes, nodes + nnodes); m.elements.assign(elements, elements + nf);
+    m.vt.clear(); m.ft.clear();
     s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_mesh_texcoords(rt_scene *s, int32_t mesh, const float *vt, int32_t nvt, const uint32_t *ft)
+{
+    rt_status st = check_idle(s, "rt_scene_set_mesh_texcoords");
+    if (st) return st;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (mesh < 0 || (size_t)mesh >= s->data.meshes.size() || s->data.meshes[mesh].f.empty())
+        return fail(RT_ERR_ARG, "rt_scene_set_mesh_texcoords: mesh %d has not been set", mesh);
+    rt::MeshData &m = s->data.meshes[mesh];
+    if (nvt < 0 || (nvt > 0 && (!vt || !ft))) return fail(RT_ERR_ARG, "rt_scene_set_mesh_texcoords: bad arrays");
+    for (size_t i = 0; nvt > 0 && i < m.f.size(); i++)
+        if (ft[i] >= (uint32_t)nvt) return fail(RT_ERR_ARG, "rt_scene_set_mesh_texcoords: texture index %u >= nvt", ft[i]);
+    if (nvt == 0) { m.vt.clear(); m.ft.clear(); }
+    else { m.vt.assign(vt, vt + 3 * (size_t)nvt); m.ft.assign(ft, ft + m.f.size()); }
+    s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_get_mesh_texcoords(const rt_scene *s, int32_t mesh, int32_t *nvt, float *vt, uint32_t *ft)
+{
+    if (!s || mesh < 0 || (size_t)mesh >= s->data.meshes.size()) return fail(RT_ERR_ARG, "rt_scene_get_mesh_texcoords: bad mesh index");
+    const rt::MeshData &m = s->data.meshes[mesh];
+    if (nvt) *nvt = (int32_t)(m.vt.size() / 3);
+    if (vt) memcpy(vt, m.vt.data(), m.vt.size() * 4);
+    if (ft) memcpy(ft, m.ft.data(), m.ft.size() * 4);
     return RT_OK;
 }
 
@@ -531,7 +559,7 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
     if ((st = D->materials.upload(sd.materials.data(), sd.materials.size() * sizeof(rt_blinn)))) return st;
     if ((st = D->lights.upload(sd.lights.data(), sd.lights.size() * sizeof(rt_light)))) return st;
 
-    for (auto &mb : D->mesh_bufs) { mb.nodes.release(); mb.tris.release(); mb.tri_face.release(); mb.nrm.release(); }
+    for (auto &mb : D->mesh_bufs) { mb.nodes.release(); mb.tris.release(); mb.tri_face.release(); mb.nrm.release(); mb.tex.release(); }
     D->mesh_bufs.assign(sd.meshes.size(), DevMeshBufs());
     std::vector<DevMesh> dm(sd.meshes.size());
     for (size_t mi = 0; mi < sd.meshes.size(); mi++) {
@@ -565,6 +593,14 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
         if ((st = mb.tris.upload(tris.data(), tris.size() * sizeof(DevTri)))) return st;
         if ((st = mb.tri_face.upload(tri_face.data(), tri_face.size() * 4))) return st;
         if ((st = mb.nrm.upload(nrm.data(), nrm.size() * 4))) return st;
+        dm[mi].tex = nullptr;
+        if (!m.vt.empty() && m.ft.size() == m.f.size()) {      // vt[ft0], vt[ft1], vt[ft2] per face, like nrm
+            std::vector<float> tex(9 * nf);
+            for (size_t face = 0; face < nf; face++)
+                for (int k = 0; k < 3; k++) memcpy(&tex[9 * face + 3 * k], &m.vt[3 * (size_t)m.ft[3 * face + k]], 12);
+            if ((st = mb.tex.upload(tex.data(), tex.size() * 4))) return st;
+            dm[mi].tex = (const float *)mb.tex.p;
+        }
         dm[mi].nodes = (const DevBvhNode *)mb.nodes.p; dm[mi].tris = (const DevTri *)mb.tris.p;
         dm[mi].tri_face = (const uint32_t *)mb.tri_face.p; dm[mi].nrm = (const float *)mb.nrm.p;
         memcpy(dm[mi].root_box, m.nodes[1].box, 24);

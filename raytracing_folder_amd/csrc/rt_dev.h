@@ -54,6 +54,7 @@ struct DevMesh {
     const DevTri     *tris;
     const uint32_t   *tri_face;
     const float      *nrm;       // 9 floats per face: vn[fn0], vn[fn1], vn[fn2]
+    const float      *tex;       // 9 floats per face: vt[ft0], vt[ft1], vt[ft2]; NULL without texture vertices
     float    root_box[6];
     uint32_t root_ref;           // child-ref encoding of the root (leaf or node index)
     uint32_t n_tris;

@@ -220,7 +220,7 @@ __device__ __forceinline__ bool tri_hit_p13(const DevTri &T, V3 rp, V3 rd, float
 // near-first traversal with a per-lane stack in LDS.  ANY: stop at the first accepted triangle.
 template <bool ANY, int MODEL>
 __device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN, int &front,
-                         uint32_t *stack, Counters &cnt)
+                         uint32_t *stack, Counters &cnt, V3 *uvw = nullptr)
 {
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (box_entry(M.root_box, M.root_box + 3, o, inv, z) > 2.0e30f) return false;
@@ -263,6 +263,11 @@ __device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN,
     const float *n9 = M.nrm + 9 * (size_t)M.tri_face[best_slot];
     const V3 Ni = ld3(n9) * bc.x + ld3(n9 + 3) * bc.y + ld3(n9 + 6) * bc.z;
     hN = (MODEL != RT_SHADE_FIN) ? normalize(Ni) : Ni;     // FIN leaves it un-normalised (:262)
+    // the PROJ13 triangle also sets uvw = GetTexCoord(face, bc) (P13/include/objects.h:203)
+    if (MODEL != RT_SHADE_FIN && uvw && M.tex) {
+        const float *t9 = M.tex + 9 * (size_t)M.tri_face[best_slot];
+        *uvw = ld3(t9) * bc.x + ld3(t9 + 3) * bc.y + ld3(t9 + 6) * bc.z;
+    }
     return true;
 }
 
@@ -281,6 +286,7 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
     // HitInfo::uvw starts at (0.5,0.5,0.5) (scene.h:163); spheres and planes overwrite it whenever they
     // accept a hit (objects.h:49-51,103), FIN's triangles never do (:226-267) -- so a mesh hit keeps the
     // coordinate of whatever sphere/plane hit the ray had accepted before it.  Reproduced as is.
+    // (The PROJ13 triangle does write it, from the mesh's texture vertices.)
     V3 uvw = mk(0.5f, 0.5f, 0.5f);
     for (int oi = 0; oi < S.n_objects; oi++) {
         const DevObject &ob = S.objects[oi];
@@ -298,7 +304,7 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
         bool hit = false;
         if (ob.type == RT_OBJ_SPHERE) hit = (MODEL == RT_SHADE_P3) ? sphere_hit_p3(lp, ldir, z, hp, hN) : sphere_hit(lp, ldir, z, hp, hN, fr);
         else if (ob.type == RT_OBJ_PLANE) hit = plane_hit(MODEL, lp, ldir, z, hp, hN, fr);
-        else if (ob.type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes[ob.mesh], lp, ldir, z, hp, hN, fr, stack, cnt);
+        else if (ob.type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes[ob.mesh], lp, ldir, z, hp, hN, fr, stack, cnt, (TEX && S.use_uvw) ? &uvw : nullptr);
         if (hit) {
             if (ANY) return true;
             best = oi; bp = hp; bN = hN; bfront = fr;

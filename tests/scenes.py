@@ -22,7 +22,7 @@ def load_cornell(width=None, height=None):
 
 def oracle_scene(export, photons=None, env=(0, 0, 0), bg=(0, 0, 0)):
     """orc.Scene over the very arrays the product exports."""
-    meshes = [orc.Mesh(m["v"], m["f"], m["vn"], m["fn"], m["nodes"], m["elements"]) for m in export["meshes"]]
+    meshes = [orc.Mesh(m["v"], m["f"], m["vn"], m["fn"], m["nodes"], m["elements"], m.get("vt"), m.get("ft")) for m in export["meshes"]]
     return orc.Scene(export["nodes"], meshes, export["materials"], export["lights"], photons, env, bg,
                      textures=export.get("textures"), texels=export.get("texels"),
                      material_maps=export.get("material_maps"), env_map=export.get("env_map"),
@@ -66,7 +66,7 @@ def rebuild(export, materials=None, lights=None):
     s = capi.Scene()
     s.set_nodes(export["nodes"])
     for i, m in enumerate(export["meshes"]):
-        s.set_mesh(i, m["v"], m["f"], m["vn"], m["fn"], m["nodes"], m["elements"])
+        s.set_mesh(i, m["v"], m["f"], m["vn"], m["fn"], m["nodes"], m["elements"], m.get("vt"), m.get("ft"))
     s.set_materials(export["materials"] if materials is None else materials)
     s.set_lights(export["lights"] if lights is None else lights)
     return s

@@ -412,6 +412,43 @@ def test_textured_scene(gold):
     assert missed.mean() > 0.05 and len(np.unique(oframe[missed].reshape(-1, 3), axis=0)) > 50    # textured background
 
 
+def test_obj_materials_and_texture_vertices(gold):
+    """OBJ nodes that bring their own .mtl (multi-material = first sub-material) and texture vertices:
+    device hits against the REFERENCE's own hit records, then rays and frames against the oracle under
+    both triangle versions (only PROJ13's reads the texture vertices)"""
+    import os
+    g = gold("mesh_twotone.npz")
+    m = capi.Scene()
+    m.set_nodes(np.concatenate([scenes.identity_node(), scenes.identity_node(0, capi.OBJ_MESH, 0, 0)]))
+    m.set_mesh(0, g["v"], g["f"], g["vn"], g["fn"], g["nodes"], g["elements"], g["vt"], g["ft"])
+    m.set_materials(np.zeros(1, capi.BLINN))
+    for model, tag in ((capi.SHADE_FIN, "fin"), (capi.SHADE_P13, "p13")):
+        ref = g["hits_" + tag]
+        got = m.trace_rays(g["rays"][:, :6], model)
+        h = ref["hit"].astype(bool)
+        assert (got["hit"].astype(bool) == h).all() and h.sum() > 1500
+        for f in ("z", "p", "N"):
+            assert got[f][h].tobytes() == ref[f][h].tobytes(), (tag, f)
+    s = capi.Scene()
+    s.load_xml(os.path.join(scenes.GOLD, "twotone.xml"))
+    cam = s.camera()
+    osc = scenes.oracle_scene(s.export(), env=(0.5, 0.5, 0.5), bg=(0.1, 0.1, 0.2))
+    rays = scenes.camera_rays(cam, 4000, seed=77)
+    frames = {}
+    for model in (capi.SHADE_FIN, capi.SHADE_P13):
+        p = capi.default_params(shade_model=model, bounce=3)
+        ohit, orgb, oz = orc.shade_rays(osc, scenes.oracle_params(p), rays)
+        hit, rgb, z = s.shade_rays(p, rays)
+        assert (hit == ohit).all() and z.tobytes() == oz.tobytes()
+        assert _close(rgb, orgb, rel=5e-5, abs_=2e-6).mean() > 0.999
+        frame, zf, cnt, st, _ = s.render(cam, p)
+        oframe, ozf, ocnt = orc.render(osc, scenes.oracle_camera(cam), scenes.oracle_params(p))
+        _frame_gate(frame, oframe, zf, ozf, cnt, ocnt)
+        frames[model] = frame
+    # the brick wall is textured through its vt under PROJ13 and with the stale uvw under FINAL
+    assert (np.abs(frames[capi.SHADE_FIN].astype(int) - frames[capi.SHADE_P13].astype(int)).max(axis=2) > 8).mean() > 0.02
+
+
 def test_depth_of_field_frame(cornell):
     """camera.dof: per-pixel lens table + per-sample pick (FIN/main.cpp:246-262, 283-291)"""
     s0, cam0, e = cornell

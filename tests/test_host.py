@@ -83,6 +83,35 @@ def test_obj_loader_polygons_negative_indices_and_missing_normals(tmp_path):
     assert (m["fn"] == m["f"]).all()
 
 
+def test_obj_materials_and_texture_vertices_match_reference(gold):
+    """an OBJ node without a material attribute: usemtl regrouping, vt/ft, the .mtl fields and the
+    multi-material LoadNode generates from them (rendered as its first sub-material)"""
+    s = capi.Scene()
+    s.load_xml(os.path.join(scenes.GOLD, "twotone.xml"))
+    e = s.export()
+    g = gold("mesh_twotone.npz")
+    m = e["meshes"][1]                                   # meshes in node order: brickwall, twotone
+    for k in ("v", "f", "vn", "fn", "vt", "ft", "elements"):
+        assert (m[k] == g[k]).all(), k
+    assert m["nodes"][1:].tobytes() == g["nodes"][1:].tobytes()
+    assert g["mtl"]["mcfc"].tolist() == [5, 11] and g["map_Kd"].tolist() == ["", "texture_52x37.png"]
+    n = e["nodes"]
+    assert n["mesh"].tolist() == [-1, -1, 0, 1, 1, -1]
+    brick, chrome = e["materials"][n["material"][2]], e["materials"][n["material"][3]]
+    assert n["material"][4] == n["material"][5]           # the third OBJ node names a scene material
+    gm = g["mtl"]                                         # reference order: chrome (first use), brick
+    assert (chrome["diffuse"] == gm["Kd"][0]).all() and (chrome["specular"] == gm["Ks"][0]).all()
+    assert chrome["glossiness"] == gm["Ns"][0] and chrome["ior"] == gm["Ni"][0]
+    assert (chrome["reflection"] == gm["Ks"][0]).all()                            # illum 6
+    assert (chrome["refraction"] == np.float32(1) - gm["Tf"][0]).all()
+    assert (brick["diffuse"] == gm["Kd"][1]).all() and (brick["reflection"] == 0).all() and brick["glossiness"] == 25
+    maps = e["material_maps"]
+    assert maps["texture"][2 * n["material"][2]] == 0 and maps["texture"][2 * n["material"][3]] == capi.MAP_NONE
+    assert e["textures"]["width"][0] == 52 and len(e["textures"]) == 1          # shared with the ball's texture
+    bw = e["meshes"][0]
+    assert bw["vt"].max() == 2 and bw["ft"].shape == bw["f"].shape
+
+
 @pytest.mark.parametrize("tag", ["k8", "k50", "k400"])
 def test_photon_pack_and_balance_match_reference(gold, tag):
     g = gold(f"photon_{tag}.npz")
