@@ -282,6 +282,14 @@ rt_status rt_bvh_build(const float *v, int32_t nv, const uint32_t *f, int32_t nf
  * `in` is permuted in place exactly like the reference permutes its vector. */
 rt_status rt_photon_balance(rt_photon *in, uint32_t n, rt_photon *out);
 
+/* The photon dump generatePhotonMap leaves behind (FIN/main.cpp:397-400: fwrite of
+ * Photon[NumPhotons], before balancing) and the way the reference's viewer reads it back
+ * (PhotonMap/PhotonMapViz.cpp:172-193: whole 24-byte records, a trailing partial one dropped).
+ * photons[0] is unused on both sides, records are photons[1..n].  rt_photons_read_dat with
+ * out == NULL only counts. */
+rt_status rt_photons_write_dat(const char *path, const rt_photon *photons, uint32_t n);
+rt_status rt_photons_read_dat(const char *path, rt_photon *out, uint32_t cap, uint32_t *n);
+
 /* Photon pass on the GPU: generatePhotonMap up to and including ScalePhotonPowers
  * (FIN/main.cpp:350-396; PhotonTracing :439-459; PointLight::RandomPhoton :489-497;
  * MtlBlinn::RandomPhotonBounce FIN/include/materials.h:99-256).  rand() is replaced by a

@@ -292,6 +292,44 @@ def gen_photon(tag, npho, k, radius, nq, seed):
     print(f"photon[{tag}]: n={npho} k={k} r={radius} half={half} queries with light: {nz}/{nq}")
 
 
+def gen_photon_dat():
+    """the photon dump the reference itself holds (PhotonMap/PhotonMap/causticmap.dat, 48 140 records of
+    its Cornell scene written by main.cpp:397-400): copied as a data fixture, balanced and queried by the
+    reference's cyPhotonMap."""
+    import hashlib, shutil
+    src = os.path.join(REF, "PhotonMap", "PhotonMap", "causticmap.dat")
+    dst = os.path.join(GOLD, "causticmap.dat")
+    shutil.copyfile(src, dst)
+    os.chmod(dst, 0o644)
+    raw = np.fromfile(dst, PHOTON)
+    rng = np.random.default_rng(311)
+    out = {}
+    for tag, k, radius, nq in (("k100", 100, 1.5, 384), ("k400", 400, 4.0, 192)):
+        qi = rng.integers(0, len(raw), nq)
+        qpos = raw["position"][qi] + rng.normal(0, 0.05, (nq, 3)).astype(np.float32)
+        # normals: the wall the photon sits on, guessed from the Cornell box, else random
+        qn = rng.normal(size=(nq, 3))
+        qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+        p = raw["position"][qi]
+        qn[np.abs(p[:, 2]) < 1e-3] = (0, 0, 1)
+        qn[np.abs(p[:, 2] - 24) < 1e-3] = (0, 0, -1)
+        qn[np.abs(p[:, 0] + 15) < 1e-3] = (1, 0, 0)
+        qn[np.abs(p[:, 0] - 15) < 1e-3] = (-1, 0, 0)
+        qn[np.abs(p[:, 1] - 20) < 1e-3] = (0, -1, 0)
+        q = np.concatenate([qpos, qn], 1).astype(np.float32)
+        res = run("fin", "photondat", struct.pack("<ifi", k, radius, nq) + q.tobytes(), dst)
+        n = struct.unpack_from("<i", res, 0)[0]
+        assert n == len(raw)
+        bal = np.frombuffer(res, PHOTON, n + 1, 4)
+        half = struct.unpack_from("<i", res, 4 + (n + 1) * 24)[0]
+        r = np.frombuffer(res, "<f4", nq * 6, 8 + (n + 1) * 24).reshape(nq, 6)
+        out.update({f"q_{tag}": q, f"res_{tag}": r, f"k_{tag}": k, f"radius_{tag}": np.float32(radius)})
+        digest = hashlib.sha256(bal[1:].tobytes()).hexdigest()
+        print(f"photon_dat[{tag}]: n={n} half={half} lit {int((r[:, :3].sum(1) > 0).sum())}/{nq}")
+    np.savez_compressed(os.path.join(GOLD, "photon_caustic.npz"), n=n, half=half, balanced_sha256=digest,
+                        balanced_head=bal[:64], **out)
+
+
 def write_png_all_filters(path, img):
     """PNG written here (not by the product): every scanline filter type in turn, zlib level 9
     (dynamic Huffman) -- exercises the product's own inflate + unfilter against lodepng's."""
@@ -377,6 +415,7 @@ def main():
     gen_photon("k400", 12000, 400, 1.0, 384, 106)
     gen_photon("k50", 3001, 50, 1.5, 256, 107)
     gen_photon("k8", 64, 8, 4.0, 64, 108)
+    gen_photon_dat()
     print("fixtures written to", GOLD)
 
 

@@ -304,6 +304,51 @@ static int cmd_photon(const char *in, const char *out)
     return 0;
 }
 
+// photondat <in.bin> <out.bin> <photonmap.dat>
+// the reference's own photon dump (main.cpp:397-400: fwrite of Photon[NumPhotons]) read the way its viewer
+// reads it (PhotonMapViz.cpp:172-193), put into a cyPhotonMap as is, balanced and queried.
+// in: int32 k; float radius; int32 nq; nq x float[6] (pos, normal)
+// out: int32 n; (n+1) x Photon balanced; int32 half; nq x float[6]
+static int cmd_photondat(const char *in, const char *out, const char *dat)
+{
+    FILE *fp = fopen(dat, "rb");
+    if (!fp) { fprintf(stderr, "cannot open %s\n", dat); return 3; }
+    int n = 0;
+    cy::PhotonMap::Photon buffer;
+    for (; !feof(fp); n++) { if (fread(&buffer, sizeof buffer, 1, fp) != 1) {} }
+    n--;
+    if (n <= 0) return 4;
+    PM pm;
+    pm.AllocatePhotons(n);
+    pm.vec().resize(n + 1);
+    rewind(fp);
+    memset((void *)&pm.vec()[0], 0, sizeof buffer);
+    if ((int)fread((void *)&pm.vec()[1], sizeof buffer, n, fp) != n) return 5;
+    fclose(fp);
+    std::vector<char> b = slurp(in);
+    const char *c = b.data();
+    int32_t k = *(int32_t *)c; c += 4;
+    float radius = *(float *)c; c += 4;
+    int32_t nq = *(int32_t *)c; c += 4;
+    const float *q = (const float *)c;
+    pm.PrepareForIrradianceEstimation();
+    Out o(out);
+    int32_t n32 = n; o.put(n32);
+    o.bytes(pm.vec().data(), (size_t)(n + 1) * 24);
+    int32_t half = pm.half(); o.put(half);
+    for (int i = 0; i < nq; i++) {
+        float res[6];
+        switch (k) {
+        case 50: estimate<50>(pm, radius, q + 6 * i, res); break;
+        case 100: estimate<100>(pm, radius, q + 6 * i, res); break;
+        case 400: estimate<400>(pm, radius, q + 6 * i, res); break;
+        default: fprintf(stderr, "k=%d not instantiated\n", k); return 4;
+        }
+        o.bytes(res, sizeof res);
+    }
+    return 0;
+}
+
 // Texture that returns the coordinate it is asked for: shows what TextureMap / SampleEnvironment compute
 struct ProbeTexture : public Texture { Color Sample(const Point3 &uvw) const { return Color(uvw.x, uvw.y, uvw.z); } };
 
@@ -373,6 +418,7 @@ int main(int argc, char **argv)
     if (cmd == "node") return cmd_node(argv[2], argv[3]);
     if (cmd == "misc") return cmd_misc(argv[2], argv[3]);
     if (cmd == "photon") return cmd_photon(argv[2], argv[3]);
+    if (cmd == "photondat") { if (argc < 5) return 1; return cmd_photondat(argv[2], argv[3], argv[4]); }
     if (cmd == "tex") { if (argc < 5) return 1; return cmd_tex(argv[2], argv[3], argv[4]); }
     if (cmd == "time") return cmd_time(argv[2], argv[3]);
     fprintf(stderr, "unknown command %s\n", cmd.c_str());

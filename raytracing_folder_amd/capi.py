@@ -76,7 +76,7 @@ SYMBOLS = [
     "rt_scene_set_photons", "rt_scene_set_textures", "rt_scene_set_material_maps", "rt_scene_set_environment_maps",
     "rt_scene_get_textures", "rt_scene_get_maps", "rt_image_read_rgb", "rt_image_write_png", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
     "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
-    "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photon_pass", "rt_render_begin",
+    "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photons_write_dat", "rt_photons_read_dat", "rt_photon_pass", "rt_render_begin",
     "rt_render_tiles_device", "rt_render_progress", "rt_render_stop", "rt_render_wait",
     "rt_job_stats", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
 ]
@@ -164,6 +164,21 @@ def identity_map(texture=MAP_NONE):
     m["tm"][0, [0, 4, 8]] = 1
     m["itm"][0, [0, 4, 8]] = 1
     return m
+
+
+def photons_write_dat(path, photons_1based):
+    """the reference's photonmap.dat: records [1..n] of a 1-based photon array, 24 bytes each"""
+    a = _c(photons_1based, PHOTON)
+    _check(lib().rt_photons_write_dat(str(path).encode(), _p(a), C.c_uint32(max(0, len(a) - 1))))
+
+
+def photons_read_dat(path):
+    """1-based photon array (entry 0 unused) from a photonmap.dat"""
+    n = C.c_uint32()
+    _check(lib().rt_photons_read_dat(str(path).encode(), None, 0, C.byref(n)))
+    out = np.zeros(n.value + 1, PHOTON)
+    _check(lib().rt_photons_read_dat(str(path).encode(), _p(out), len(out), C.byref(n)))
+    return out
 
 
 def photon_balance(photons_1based):

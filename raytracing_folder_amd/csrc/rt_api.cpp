@@ -467,6 +467,39 @@ extern "C" rt_status rt_bvh_build(const float *v, int32_t nv, const uint32_t *f,
     return RT_OK;
 }
 
+extern "C" rt_status rt_photons_write_dat(const char *path, const rt_photon *photons, uint32_t n)
+{
+    if (!path || (n > 0 && !photons)) return fail(RT_ERR_ARG, "rt_photons_write_dat: NULL argument");
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return fail(RT_ERR_IO, "rt_photons_write_dat: cannot create \"%s\"", path);
+    const size_t w = n ? fwrite(photons + 1, sizeof(rt_photon), n, fp) : 0;
+    const bool ok = (fclose(fp) == 0) && w == n;
+    return ok ? RT_OK : fail(RT_ERR_IO, "rt_photons_write_dat: short write to \"%s\"", path);
+}
+
+extern "C" rt_status rt_photons_read_dat(const char *path, rt_photon *out, uint32_t cap, uint32_t *n)
+{
+    if (!path || !n) return fail(RT_ERR_ARG, "rt_photons_read_dat: NULL argument");
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(RT_ERR_IO, "rt_photons_read_dat: cannot open \"%s\"", path);
+    fseek(fp, 0, SEEK_END);
+    const long bytes = ftell(fp);
+    rewind(fp);
+    const uint64_t count = bytes > 0 ? (uint64_t)bytes / sizeof(rt_photon) : 0;
+    if (count > 0xFFFFFFF0ull) { fclose(fp); return fail(RT_ERR_ARG, "rt_photons_read_dat: \"%s\" holds too many photons", path); }
+    *n = (uint32_t)count;
+    rt_status st = RT_OK;
+    if (out) {
+        if (cap < count + 1) st = fail(RT_ERR_ARG, "rt_photons_read_dat: buffer of %u records, %llu needed", cap, (unsigned long long)count + 1);
+        else {
+            memset(out, 0, sizeof(rt_photon));
+            if (count && fread(out + 1, sizeof(rt_photon), count, fp) != count) st = fail(RT_ERR_IO, "rt_photons_read_dat: short read from \"%s\"", path);
+        }
+    }
+    fclose(fp);
+    return st;
+}
+
 extern "C" rt_status rt_photon_balance(rt_photon *in, uint32_t n, rt_photon *out)
 {
     if (!in || !out) return fail(RT_ERR_ARG, "rt_photon_balance: NULL argument");

@@ -146,6 +146,26 @@ def test_irradiance_against_reference_vectors(gold, tag):
     assert oirr.tobytes() == ref[:, :3].tobytes()
 
 
+def test_irradiance_on_the_reference_photon_dump(gold):
+    """the photon map the reference ships (causticmap.dat): read, balanced and uploaded through the C ABI,
+    estimates against what the reference's cyPhotonMap returns on it (same heap-quirk allowance as above)"""
+    import os
+    g = gold("photon_caustic.npz")
+    bal = capi.photon_balance(capi.photons_read_dat(os.path.join(scenes.GOLD, "causticmap.dat")))
+    s = capi.Scene()
+    s.set_nodes(scenes.identity_node())
+    s.set_photons(bal)
+    for tag in ("k100", "k400"):
+        k, radius, q, ref = int(g["k_" + tag]), float(g["radius_" + tag]), g["q_" + tag], g["res_" + tag]
+        irr, d = s.estimate_irradiance(k, radius, q[:, :3], q[:, 3:])
+        scale = np.abs(ref[:, :3]).max(axis=1, keepdims=True) + 1e-30
+        rel = (np.abs(irr - ref[:, :3]) / scale).max(axis=1)
+        tight = rel < 2e-5
+        assert tight.mean() > 0.9, (tag, rel)
+        assert (rel[~tight] < 2.5 / k + 1e-4).all(), (tag, rel[~tight])
+        assert (np.abs(d - ref[:, 3:]).max(axis=1)[tight] < 2e-5).all()
+
+
 def test_irradiance_sparse_dense_and_empty():
     bal = photons.synth_cornell_photon_map(30000, seed=11)
     s = capi.Scene()
@@ -427,8 +447,12 @@ def test_obj_materials_and_texture_vertices(gold):
         got = m.trace_rays(g["rays"][:, :6], model)
         h = ref["hit"].astype(bool)
         assert (got["hit"].astype(bool) == h).all() and h.sum() > 1500
-        for f in ("z", "p", "N"):
+        for f in ("z", "p"):
             assert got[f][h].tobytes() == ref[f][h].tobytes(), (tag, f)
+        # the node level renormalises N (FromNodeCoords), the reference record is the object's own:
+        # N goes through the oracle's trace, whose triangle is pinned to these records on the CPU
+        ohit, ohits = orc.trace(scenes.oracle_scene(m.export()), model, g["rays"][:, :6])
+        _assert_hits_equal(got, ohit, ohits)
     s = capi.Scene()
     s.load_xml(os.path.join(scenes.GOLD, "twotone.xml"))
     cam = s.camera()

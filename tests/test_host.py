@@ -123,6 +123,27 @@ def test_photon_pack_and_balance_match_reference(gold, tag):
     assert bal[1:].tobytes() == g["balanced"][1:].tobytes()
 
 
+def test_photon_dat_round_trip_and_reference_dump(gold, tmp_path):
+    """rt_photons_read_dat / write_dat on the dump the reference ships, and the host balance of it
+    against the reference's cyPhotonMap"""
+    import hashlib
+    g = gold("photon_caustic.npz")
+    path = os.path.join(scenes.GOLD, "causticmap.dat")
+    ph = capi.photons_read_dat(path)
+    assert len(ph) == 48141 and ph[1:].tobytes() == open(path, "rb").read()
+    capi.photons_write_dat(tmp_path / "copy.dat", ph)
+    assert open(tmp_path / "copy.dat", "rb").read() == open(path, "rb").read()
+    with open(tmp_path / "ragged.dat", "wb") as f:        # a trailing partial record is dropped
+        f.write(ph[1:4].tobytes() + b"xyz")
+    assert len(capi.photons_read_dat(tmp_path / "ragged.dat")) == 4
+    open(tmp_path / "empty.dat", "wb").close()
+    assert len(capi.photons_read_dat(tmp_path / "empty.dat")) == 1
+    with pytest.raises(capi.RtError):
+        capi.photons_read_dat(tmp_path / "missing.dat")
+    bal = capi.photon_balance(ph)
+    assert hashlib.sha256(bal[1:].tobytes()).hexdigest() == str(g["balanced_sha256"])
+
+
 def test_xml_errors_are_reported(tmp_path):
     s = capi.Scene()
     with pytest.raises(capi.RtError) as e:
