@@ -99,9 +99,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RtError(-3, f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
-        _lib = C.CDLL(LIB_PATH)
+        path = os.environ.get("RT_MI355X_LIB", LIB_PATH)      # another build of the same ABI (tuning runs)
+        if not os.path.exists(path):
+            raise RtError(-3, f"{path} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        _lib = C.CDLL(path)
         _lib.rt_last_error.restype = C.c_char_p
         for name in SYMBOLS:
             getattr(_lib, name)          # AttributeError here = header/library mismatch

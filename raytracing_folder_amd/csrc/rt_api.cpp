@@ -30,7 +30,19 @@ void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const 
 void rtk_launch_resolve(hipStream_t, const DevScene &, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
                         float, float, int, const float *, uint8_t *, float *, uint8_t *, int);
 
-#define GATHER_BLOCKS (256 * 4)
+// k_gather is a persistent grid that pulls query batches from a counter: enough workgroups to fill
+// every CU at the kernel's occupancy (256 CUs x 5 resident workgroups of 4 waves)
+static int gather_blocks()
+{
+    static int n = 0;
+    if (n == 0) {
+        const char *e = getenv("RT_GATHER_BLOCKS");     // tuning experiments only
+        const long v = e ? atol(e) : 0;
+        n = (v >= 64 && v <= 16384) ? (int)v : 256 * 5;
+    }
+    return n;
+}
+#define GATHER_BLOCKS gather_blocks()
 
 void rtk_launch_photon_trace(hipStream_t, const DevScene &, unsigned long long, uint32_t, uint32_t, int, float *, uint32_t *);
 
@@ -109,7 +121,7 @@ struct DeviceState {
     bool scene_valid = false, photons_valid = false;
     DevBuf nodes, objects, meshes, materials, lights, node_material, textures, texels, material_maps;
     std::vector<DevMeshBufs> mesh_bufs;
-    DevBuf pa, pb, pc, tbox, spill, grid;
+    DevBuf pa, pb, tbox, spill, grid;
     DevScene scene{};
     // workspace
     DevBuf sample_rgb, sample_z, sample_hit, rq[2][5], pq[3], counts, pixel_list, stats;
@@ -119,7 +131,7 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     void release()
     {
-        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &pc, &tbox, &spill, &grid,
+        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &tbox, &spill, &grid,
                           &sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
         for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) rq[i][k].release();
@@ -524,7 +536,8 @@ static rt_status convert_bvh(const rt::MeshData &m, std::vector<DevBvhNode> &out
         const rt::MeshData &m; std::vector<DevBvhNode> &out; int max_depth = 0; bool bad = false;
         uint32_t go(uint32_t id, int depth)
         {
-            if (id == 0 || id >= m.nodes.size() || depth > 512) { bad = true; return LEAFREF(0, 1); }
+            // a well-formed tree visits every node once: more device nodes than input nodes means a cycle
+            if (bad || id == 0 || id >= m.nodes.size() || depth > 512 || out.size() > m.nodes.size()) { bad = true; return LEAFREF(0, 1); }
             if (depth > max_depth) max_depth = depth;
             const rt_bvh_node &n = m.nodes[id];
             if (n.data & 0x80000000u) {
@@ -533,7 +546,7 @@ static rt_status convert_bvh(const rt::MeshData &m, std::vector<DevBvhNode> &out
                 return LEAFREF(off, cnt);
             }
             const uint32_t c = n.data & 0x7FFFFFFFu;
-            if (c == 0 || (size_t)c + 1 >= m.nodes.size() + 0 || c + 1 >= m.nodes.size()) { bad = true; return LEAFREF(0, 1); }
+            if (c == 0 || (size_t)c + 1 >= m.nodes.size()) { bad = true; return LEAFREF(0, 1); }
             const uint32_t me = (uint32_t)out.size();
             out.push_back(DevBvhNode{});
             DevBvhNode d{};
@@ -689,7 +702,7 @@ static void photon_direction(const rt_photon &p, float d[3])
     if (p.plane_and_dirz & 0x8) d[2] = -d[2];
 }
 
-struct PRec { float pos[3], dir[3], maxp, pw[3]; };
+struct PRec { float pos[3], dir[3], maxp; uint32_t color; };
 
 // Gather structure: the photons LocatePhotons can reach (it descends only while index <
 // halfStoredPhotons = n/2 - 1, cyPhotonMap.h:217,371, so indices >= 2*half are never visited)
@@ -714,17 +727,18 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D)
         memcpy(r.pos, p.position, 12);
         photon_direction(p, r.dir);
         r.maxp = p.power;                                               // GetMaxPower :60
-        for (int c = 0; c < 3; c++) r.pw[c] = (p.color[c] / 255.0f) * p.power;   // GetPower :58
+        // GetPower :58 = Color(color) * power, Color24 -> Color = byte / 255.0f (cyColor.h): the device
+        // forms the correctly rounded byte / 255.0f itself and multiplies by power, the same two roundings
+        r.color = (uint32_t)p.color[0] | ((uint32_t)p.color[1] << 8) | ((uint32_t)p.color[2] << 16);
     }
     uint32_t n_leaves = 1;
     while ((size_t)n_leaves * RT_LEAF_PHOTONS < recs.size()) n_leaves <<= 1;
     if (n_leaves > 65536) return fail(RT_ERR_LIMIT, "photon map too large for the gather structure (%zu photons)", recs.size());
     std::vector<float> tbox(6 * 2 * (size_t)n_leaves);
     std::vector<float4> pa((size_t)n_leaves * RT_LEAF_PHOTONS), pb(pa.size());
-    std::vector<float2> pc(pa.size());
-    for (size_t i = 0; i < pa.size(); i++) { pa[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0); pb[i] = make_float4(0, 0, 0, 0); pc[i] = make_float2(0, 0); }
+    for (size_t i = 0; i < pa.size(); i++) { pa[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0); pb[i] = make_float4(0, 0, 0, 0); }
     struct Build {
-        std::vector<PRec> &r; std::vector<float> &tbox; std::vector<float4> &pa, &pb; std::vector<float2> &pc; uint32_t n_leaves;
+        std::vector<PRec> &r; std::vector<float> &tbox; std::vector<float4> &pa, &pb; uint32_t n_leaves;
         void go(uint32_t node, size_t lo, size_t hi)
         {
             float *b = &tbox[6 * (size_t)node];
@@ -735,8 +749,9 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D)
                 for (size_t i = lo; i < hi; i++) {
                     const PRec &q = r[i];
                     pa[base + (i - lo)] = make_float4(q.pos[0], q.pos[1], q.pos[2], q.dir[0]);
-                    pb[base + (i - lo)] = make_float4(q.dir[1], q.dir[2], q.maxp, q.pw[0]);
-                    pc[base + (i - lo)] = make_float2(q.pw[1], q.pw[2]);
+                    float cbits;
+                    memcpy(&cbits, &q.color, 4);
+                    pb[base + (i - lo)] = make_float4(q.dir[1], q.dir[2], q.maxp, cbits);
                 }
                 return;
             }
@@ -749,14 +764,13 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D)
             go(2 * node, lo, mid);
             go(2 * node + 1, mid, hi);
         }
-    } B{recs, tbox, pa, pb, pc, n_leaves};
+    } B{recs, tbox, pa, pb, n_leaves};
     B.go(1, 0, recs.size());
     rt_status st;
     if ((st = D->pa.upload(pa.data(), pa.size() * sizeof(float4)))) return st;
     if ((st = D->pb.upload(pb.data(), pb.size() * sizeof(float4)))) return st;
-    if ((st = D->pc.upload(pc.data(), pc.size() * sizeof(float2)))) return st;
     if ((st = D->tbox.upload(tbox.data(), tbox.size() * 4))) return st;
-    pm.pa = (const float4 *)D->pa.p; pm.pb = (const float4 *)D->pb.p; pm.pc = (const float2 *)D->pc.p; pm.tbox = (const float *)D->tbox.p;
+    pm.pa = (const float4 *)D->pa.p; pm.pb = (const float4 *)D->pb.p; pm.tbox = (const float *)D->tbox.p;
     pm.n_leaves = n_leaves; pm.n_photons = (uint32_t)recs.size();
     {   // density grid over the photons' bounding box, at most 64 cells along the longest axis
         const float *rb = &tbox[6];

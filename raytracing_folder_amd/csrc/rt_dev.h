@@ -61,9 +61,8 @@ struct DevMesh {
 };
 
 struct DevPhotonMap {
-    const float4 *pa;            // [n_leaves*64]
-    const float4 *pb;
-    const float2 *pc;
+    const float4 *pa;            // [n_leaves*64]  position.xyz, direction.x
+    const float4 *pb;            //                direction.yz, GetMaxPower(), colour bytes r|g<<8|b<<16 (as uint bits)
     const float  *tbox;          // [2*n_leaves][6]
     uint32_t n_leaves;           // power of two, 0 = no photon map
     uint32_t n_photons;          // photons stored in the leaves

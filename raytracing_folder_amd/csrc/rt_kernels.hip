@@ -20,11 +20,18 @@
 
 #define BIGFLOAT 1.0e30f
 #define LEAF_BIT 0x80000000u
-#ifndef RT_GATHER_UNROLL
-#define RT_GATHER_UNROLL 1
+// k_gather tuning knobs (the defaults are the measured best on MI355X)
+#ifndef RT_GATHER_AHEAD
+#define RT_GATHER_AHEAD 1      // 1: the next leaf is fetched while the current one is processed (0: -27 % on MI355X)
 #endif
-#ifndef RT_GATHER_CACHE
-#define RT_GATHER_CACHE 16     // leaves whose per-lane distances are kept in registers between the passes
+#ifndef RT_GATHER_BRANCHY
+#define RT_GATHER_BRANCHY 1    // 1: accepted lanes accumulate under a branch; 0: predicated, branch-free
+#endif
+#ifndef RT_GATHER_GUESS
+#define RT_GATHER_GUESS 1.3f   // photons expected inside the first trial radius, in units of k (1.2-1.6 measured flat)
+#endif
+#ifndef RT_GATHER_BATCH
+#define RT_GATHER_BATCH 32     // queries a wave lists per phase A (32 halves the LDS leaf lists: 5 waves/SIMD instead of 4)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1351,16 +1358,52 @@ struct GatherArgs {
     uint16_t *spill;                 // [waves in the grid][n_leaves]: leaf lists too long for LDS
 };
 
-__device__ __forceinline__ float wave_sum(float x)
+// Wave-wide inclusive scans on the DPP path (row_shr 1/2/4/8 inside each row of 16 lanes, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3): six VALU instructions, no LDS
+// crossbar traffic (__shfl is ds_bpermute: an LDS round trip per step).  All 64 lanes must be active.
+// Lanes without a source keep `old` = the identity.  Fixed order => deterministic float sums.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float x)
 {
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t identity, uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+__device__ __forceinline__ float wave_scan_add(float x)
+{
+    x += dpp_f<DPP_ROW_SHR(1), 0xF>(0.0f, x); x += dpp_f<DPP_ROW_SHR(2), 0xF>(0.0f, x);
+    x += dpp_f<DPP_ROW_SHR(4), 0xF>(0.0f, x); x += dpp_f<DPP_ROW_SHR(8), 0xF>(0.0f, x);
+    x += dpp_f<DPP_ROW_BCAST15, 0xA>(0.0f, x); x += dpp_f<DPP_ROW_BCAST31, 0xC>(0.0f, x);
     return x;
 }
-__device__ __forceinline__ uint32_t wave_sum_u(uint32_t x)
+__device__ __forceinline__ uint32_t wave_scan_add_u(uint32_t x)
 {
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    x += dpp_u<DPP_ROW_SHR(1), 0xF>(0u, x); x += dpp_u<DPP_ROW_SHR(2), 0xF>(0u, x);
+    x += dpp_u<DPP_ROW_SHR(4), 0xF>(0u, x); x += dpp_u<DPP_ROW_SHR(8), 0xF>(0u, x);
+    x += dpp_u<DPP_ROW_BCAST15, 0xA>(0u, x); x += dpp_u<DPP_ROW_BCAST31, 0xC>(0u, x);
     return x;
 }
+__device__ __forceinline__ float wave_scan_max0(float x)          // x >= 0
+{
+    x = fmaxf(x, dpp_f<DPP_ROW_SHR(1), 0xF>(0.0f, x)); x = fmaxf(x, dpp_f<DPP_ROW_SHR(2), 0xF>(0.0f, x));
+    x = fmaxf(x, dpp_f<DPP_ROW_SHR(4), 0xF>(0.0f, x)); x = fmaxf(x, dpp_f<DPP_ROW_SHR(8), 0xF>(0.0f, x));
+    x = fmaxf(x, dpp_f<DPP_ROW_BCAST15, 0xA>(0.0f, x)); x = fmaxf(x, dpp_f<DPP_ROW_BCAST31, 0xC>(0.0f, x));
+    return x;
+}
+// totals: lane 63 of the inclusive scan, as a scalar
+__device__ __forceinline__ float wave_sum(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan_add(x)), 63)); }
+__device__ __forceinline__ uint32_t wave_sum_u(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add_u(x), 63); }
+__device__ __forceinline__ float wave_max0(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan_max0(x)), 63)); }
+
+// value of lane l (wave-uniform l) as a scalar: v_readlane, no LDS traffic, result lives in an SGPR
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ uint32_t lane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 __device__ __forceinline__ float box_dist2(const float *b, float px, float py, float pz)
 {
@@ -1380,12 +1423,26 @@ __device__ __forceinline__ void wave_sync()
 }
 
 struct GatherLds {
-    uint16_t leaves[64][RT_LEAFLIST_CAP];   // per query (lane) leaf ids
+    uint16_t leaves[RT_GATHER_BATCH][RT_LEAFLIST_CAP];   // per query (lane) leaf ids
     uint32_t hist[256];
     float    sel_d[64];
     uint32_t sel_i[64];
     uint32_t sel_n;
 };
+
+// Color24 -> Color (cyColor.h): byte / 255.0f, correctly rounded, without the ~10-instruction IEEE
+// division and without a table: q = c * RN(1/255) is off by at most one ulp, one Newton step
+// (e = c - q*255 exactly by fma, q + e/255) lands on the correctly rounded quotient for every byte
+// value (all 256 checked against the division on the host: tests/test_host.py, and on the device:
+// test_gpu_parity.py::test_irradiance_single_photon_colour_bytes).
+__device__ __forceinline__ float byte_over_255(uint32_t c)
+{
+    const float r = 1.0f / 255.0f;
+    const float x = (float)c;
+    const float q = x * r;
+    const float e = __fmaf_rn(-q, 255.0f, x);
+    return __fmaf_rn(e, r, q);
+}
 
 // one lane's photon of one leaf against one query (the test of LocatePhotons :383-392)
 struct Cand { bool ok; float d2; uint32_t key; float4 pa, pb; };
@@ -1403,27 +1460,50 @@ __device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuer
 }
 
 // Visit every photon slot of the query's leaves: f(candidate, slot) is called wave-uniformly (all 64
-// lanes, same leaf) so it may use ballots.  RT_GATHER_UNROLL leaves are fetched per step (more
-// loads in flight per lane vs. registers/occupancy; measured on MI355X: 1 beats 4).
-template <class F>
-__device__ __forceinline__ void scan_leaves(const DevPhotonMap &pm, const uint16_t *list, uint32_t it0, uint32_t n_iter,
+// lanes, same leaf) so it may use ballots.  The loads of leaf it+1 are issued before leaf it is
+// processed (one leaf = two coalesced 16-byte loads per lane, nothing else is fetched per photon), so a
+// wave always has a leaf in flight while it works: measured on MI355X the un-pipelined version spent
+// 78 % of its wave cycles parked on s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES).
+template <class L, class F>
+__device__ __forceinline__ void scan_leaves(const DevPhotonMap &pm, L &&leaf_at, uint32_t n_iter,
                                             int lane, const GatherQuery &Q, F &&f)
 {
-    uint32_t it = it0;
-#if RT_GATHER_UNROLL >= 2
-    for (; it + 2 <= n_iter; it += 2) {
-        const size_t s0 = (size_t)list[it] * RT_LEAF_PHOTONS + lane, s1 = (size_t)list[it + 1] * RT_LEAF_PHOTONS + lane;
-        const float4 a0 = pm.pa[s0], a1 = pm.pa[s1];
-        const float4 b0 = pm.pb[s0], b1 = pm.pb[s1];
-        f(make_cand(a0, b0, Q, true), s0); f(make_cand(a1, b1, Q, true), s1);
+    if (n_iter == 0) return;
+    // leaf ids are wave-uniform (SGPR): base pointer arithmetic stays on the scalar unit and the loads
+    // take the "scalar base + lane offset" form
+    auto ld = [&](uint32_t it, float4 &a, float4 &b, uint32_t &slot) {
+        const uint32_t leaf = leaf_at(it);
+        slot = leaf * RT_LEAF_PHOTONS + (uint32_t)lane;
+        a = (pm.pa + (size_t)leaf * RT_LEAF_PHOTONS)[lane];
+        b = (pm.pb + (size_t)leaf * RT_LEAF_PHOTONS)[lane];
+    };
+#if RT_GATHER_AHEAD == 0
+    for (uint32_t it = 0; it < n_iter; it++) {
+        float4 a, b; uint32_t sl;
+        ld(it, a, b, sl);
+        f(make_cand(a, b, Q, true), (size_t)sl);
     }
+#else
+    // two register sets used alternately, each refilled right after it was consumed; the reload index
+    // is clamped instead of branched over (the last leaf may be fetched twice) so that neither set
+    // is a loop-carried copy of the other
+    float4 a0, b0, a1, b1;
+    uint32_t s0, s1;
+    ld(0u, a0, b0, s0);
+    uint32_t it = 0;
+    for (; it + 1 < n_iter; it += 2) {
+        ld(it + 1, a1, b1, s1);
+        f(make_cand(a0, b0, Q, true), (size_t)s0);
+        ld(min(it + 2, n_iter - 1), a0, b0, s0);
+        f(make_cand(a1, b1, Q, true), (size_t)s1);
+    }
+    if (it < n_iter) f(make_cand(a0, b0, Q, true), (size_t)s0);
 #endif
-    for (; it < n_iter; it++) {
-        const size_t s0 = (size_t)list[it] * RT_LEAF_PHOTONS + lane;
-        f(make_cand(pm.pa[s0], pm.pb[s0], Q, true), s0);
-    }
 }
 
+#ifdef RT_GATHER_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(RT_GATHER_WAVES_PER_EU, RT_GATHER_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
 {
     __shared__ GatherLds lds_all[RT_GATHER_WAVES];
@@ -1441,21 +1521,21 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
 
     // 64-query batches are handed out dynamically (one atomic per batch): query cost varies by two
     // orders of magnitude with the local photon density, so a static split leaves a long tail
-    const uint32_t n_batches = (nq + 63u) / 64u;
-    const float guess_c = 1.4f * (float)K * G.pm.cell * G.pm.cell / (float)M_PI;
+    const uint32_t n_batches = (nq + (uint32_t)RT_GATHER_BATCH - 1u) / (uint32_t)RT_GATHER_BATCH;
+    const float guess_c = RT_GATHER_GUESS * (float)K * G.pm.cell * G.pm.cell / (float)M_PI;
 
     for (;;) {
         uint32_t batch = 0;
         if (lane == 0) batch = atomicAdd(G.next_batch, 1u);
-        batch = __shfl(batch, 0);
+        batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch);
         if (batch >= n_batches) break;
-        const uint32_t qbase = batch * 64u;
+        const uint32_t qbase = batch * (uint32_t)RT_GATHER_BATCH;
         const uint32_t qi = qbase + lane;
-        const bool have = qi < nq;
+        const bool have = lane < RT_GATHER_BATCH && qi < nq;
         float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
         if (have) { a = G.qa[qi]; b = G.qb[qi]; c = G.qc[qi]; }
         bool pending = have;
-        // first trial radius from the density grid: about 1.4 k photons expected inside (count ~ r^2
+        // first trial radius from the density grid: about RT_GATHER_GUESS * k photons expected inside (count ~ r^2
         // on a surface through a cell of side h: c photons per h^2)
         float r2cur = r2;
         if (have && n_leaves > 1) {
@@ -1492,12 +1572,12 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 const int q = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 GatherQuery Q;
-                Q.px = __shfl(a.x, q); Q.py = __shfl(a.y, q); Q.pz = __shfl(a.z, q);
-                Q.nx = __shfl(a.w, q); Q.ny = __shfl(b.x, q); Q.nz = __shfl(b.y, q);
-                Q.rq2 = __shfl(r2cur, q);
+                Q.px = lane_f(a.x, q); Q.py = lane_f(a.y, q); Q.pz = lane_f(a.z, q);
+                Q.nx = lane_f(a.w, q); Q.ny = lane_f(b.x, q); Q.nz = lane_f(b.y, q);
+                Q.rq2 = lane_f(r2cur, q);
                 Q.kscale = 16777216.0f / Q.rq2;            // 24-bit fixed-point distance key
                 const float rq2 = Q.rq2, nx = Q.nx, ny = Q.ny, nz = Q.nz;
-                const uint32_t qnl = __shfl(nl, q);
+                const uint32_t qnl = lane_u(nl, q);
                 const bool final_round = rq2 >= r2;
                 const bool slow = qnl > RT_LEAFLIST_CAP;   // the LDS list overflowed
                 uint32_t n_iter = qnl;
@@ -1515,42 +1595,37 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     wave_sync();
                 }
                 n_rounds++; n_slow += slow ? 1u : 0u; n_reads += n_iter;
-                // run one pass over the query's leaves, from the LDS list or from the spill list
-                auto for_each = [&](uint32_t from, auto &&f) {
-                    if (slow) scan_leaves(G.pm, spill, from, n_iter, lane, Q, f);
-                    else scan_leaves(G.pm, L.leaves[q], from, n_iter, lane, Q, f);
+                // run one pass over the query's leaves.  An LDS list has at most 64 entries: lane i keeps
+                // entry i in a register and the loop reads it with v_readlane (no LDS round trip in the
+                // address path); a spill list is read from this wave's global scratch.
+                const uint32_t my_leaf = (!slow && (uint32_t)lane < n_iter) ? (uint32_t)L.leaves[q][lane] : 0u;
+                auto for_each = [&](auto &&f) {
+                    if (slow) scan_leaves(G.pm, [&](uint32_t it) { return (uint32_t)spill[it]; }, n_iter, lane, Q, f);
+                    else scan_leaves(G.pm, [&](uint32_t it) { return (uint32_t)__builtin_amdgcn_readlane((int)my_leaf, (int)it); }, n_iter, lane, Q, f);
                 };
-                // the squared distances of the first RT_GATHER_CACHE leaves stay in registers (the loops
-                // over them are fully unrolled) so that pass 2 neither reloads nor re-tests those photons
-                float d2c[RT_GATHER_CACHE];
-                const uint32_t n_cached = slow ? 0u : min(n_iter, (uint32_t)RT_GATHER_CACHE);
+                float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // pass 1: sums over ALL candidates
+                // sum of power (GetPower = Color24 -> Color times power) and of dir * maxPower for one photon
+                // (branch-free variant: take == false adds exact zeros; measured slower than the branch)
+                auto accumulate = [&](const float4 &pa, const float4 &pb, bool take) {
+#if RT_GATHER_BRANCHY
+                    if (!take) return;
+#endif
+                    const uint32_t cbits = __float_as_uint(pb.w);
+                    const float mp = take ? pb.z : 0.0f;
+                    s_pr += byte_over_255(cbits & 255u) * mp; s_pg += byte_over_255((cbits >> 8) & 255u) * mp; s_pb += byte_over_255((cbits >> 16) & 255u) * mp;
+                    s_dx += pa.w * mp; s_dy += pb.x * mp; s_dz += pb.y * mp;
+                };
 
-                float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // sums over ALL candidates
                 uint32_t my_cnt = 0;
                 for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                 wave_sync();
                 // pass 1
-                auto pass1 = [&](const Cand &cd, size_t s) {
-                    if (cd.ok) {
-                        const float2 pc = G.pm.pc[s];
-                        s_pr += cd.pb.w; s_pg += pc.x; s_pb += pc.y;
-                        s_dx += cd.pa.w * cd.pb.z; s_dy += cd.pb.x * cd.pb.z; s_dz += cd.pb.y * cd.pb.z;
-                        my_cnt++;
-                        atomicAdd(&L.hist[cd.key >> 16], 1u);
-                    }
-                    visited += 1;
-                };
-#pragma unroll
-                for (int it = 0; it < RT_GATHER_CACHE; it++) {
-                    d2c[it] = 3.0e38f;
-                    if ((uint32_t)it < n_cached) {
-                        const size_t s0 = (size_t)L.leaves[q][it] * RT_LEAF_PHOTONS + lane;
-                        const Cand cd = make_cand(G.pm.pa[s0], G.pm.pb[s0], Q, true);
-                        pass1(cd, s0);
-                        if (cd.ok) d2c[it] = cd.d2;
-                    }
-                }
-                for_each(n_cached, pass1);
+                for_each([&](const Cand &cd, size_t) {
+                    accumulate(cd.pa, cd.pb, cd.ok);
+                    my_cnt += cd.ok ? 1u : 0u;
+                    if (cd.ok) atomicAdd(&L.hist[cd.key >> 16], 1u);
+                });
+                visited += n_iter;
                 const uint32_t M = wave_sum_u(my_cnt);
                 if (!final_round && M <= K) {
                     // not enough inside the trial radius: grow it (count ~ r^2 on a surface) and retry
@@ -1570,8 +1645,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         wave_sync();
                         const uint32_t h0 = L.hist[4 * lane], h1 = L.hist[4 * lane + 1], h2 = L.hist[4 * lane + 2], h3 = L.hist[4 * lane + 3];
                         const uint32_t mine = h0 + h1 + h2 + h3;
-                        uint32_t incl = mine;
-                        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+                        const uint32_t incl = wave_scan_add_u(mine);
                         const uint32_t excl = incl - mine;
                         const unsigned long long m = __ballot(incl >= need);
                         const int owner = __ffsll((long long)m) - 1;      // first lane whose range reaches `need`
@@ -1583,7 +1657,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                             else if (cum + h0 + h1 + h2 >= need) { digit = 4 * lane + 2; before = cum + h0 + h1; cntb = h2; }
                             else { digit = 4 * lane + 3; before = cum + h0 + h1 + h2; cntb = h3; }
                         }
-                        digit = __shfl(digit, owner); before = __shfl(before, owner); cntb = __shfl(cntb, owner);
+                        digit = lane_u(digit, owner); before = lane_u(before, owner); cntb = lane_u(cntb, owner);
                         need -= before;
                         prefix |= digit << shift;
                         in_bin = cntb;
@@ -1594,7 +1668,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                         wave_sync();
                         const uint32_t hi_mask = ~((1u << (shift + 8)) - 1u) & 0xFFFFFFu;
-                        for_each(0u, [&](const Cand &cd, size_t) {
+                        for_each([&](const Cand &cd, size_t) {
                             if (cd.ok && (cd.key & hi_mask) == prefix) atomicAdd(&L.hist[(cd.key >> shift) & 255u], 1u);
                         });
                     }
@@ -1606,51 +1680,34 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     wave_sync();
                     uint32_t tie_taken = 0;                // only used when in_bin > 64 (identical keys)
                     float tmax = 0.0f;
-                    auto pass2 = [&](bool ok, float d2, uint32_t key, size_t s) {
-                        const uint32_t kb = key & bin_mask;
-                        bool take = ok && kb < prefix;
-                        const bool inb = ok && kb == prefix;
+                    for_each([&](const Cand &cd, size_t s) {
+                        const uint32_t kb = cd.key & bin_mask;
+                        bool take = cd.ok && kb < prefix;
+                        const bool inb = cd.ok && kb == prefix;
                         const unsigned long long mb = __ballot(inb);
                         if (in_bin <= 64u) {
                             if (mb) {
                                 uint32_t base = 0;
                                 const int leader = __ffsll((long long)mb) - 1;
                                 if (lane == leader) { base = L.sel_n; L.sel_n = base + (uint32_t)__popcll(mb); }
-                                base = __shfl(base, leader);
+                                base = lane_u(base, leader);
                                 if (inb) {
                                     const uint32_t at = base + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                                    if (at < 64u) { L.sel_d[at] = d2; L.sel_i[at] = (uint32_t)s; }
+                                    if (at < 64u) { L.sel_d[at] = cd.d2; L.sel_i[at] = (uint32_t)s; }
                                 }
                             }
                         } else {
                             // more than 64 photons share all 24 key bits: take the first `need` in scan order
                             const uint32_t rank = tie_taken + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                            if (inb && rank < need) { take = true; tmax = fmaxf(tmax, d2); }
+                            if (inb && rank < need) { take = true; tmax = fmaxf(tmax, cd.d2); }
                             tie_taken += (uint32_t)__popcll(mb);
                         }
-                        if (take) {
-                            const float4 pa = G.pm.pa[s];
-                            const float4 pb = G.pm.pb[s];
-                            const float2 pc = G.pm.pc[s];
-                            s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
-                            s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
-                        }
-                    };
-#pragma unroll
-                    for (int it = 0; it < RT_GATHER_CACHE; it++) {
-                        if ((uint32_t)it < n_cached) {
-                            const float d2 = d2c[it];
-                            const bool ok = d2 < 1.0e38f;
-                            uint32_t key = (uint32_t)(d2 * Q.kscale);
-                            key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
-                            pass2(ok, d2, key, (size_t)L.leaves[q][it] * RT_LEAF_PHOTONS + lane);
-                        }
-                    }
-                    for_each(n_cached, [&](const Cand &cd, size_t s) { pass2(cd.ok, cd.d2, cd.key, s); });
+                        accumulate(cd.pa, cd.pb, take);
+                    });
                     wave_sync();
                     if (in_bin <= 64u) {
                         // exact selection: rank by (d2, list position); take ranks < need
-                        const uint32_t n_sel = min(L.sel_n, 64u);
+                        const uint32_t n_sel = lane_u(min(L.sel_n, 64u), 0);
                         const bool mine = (uint32_t)lane < n_sel;
                         const float md = mine ? L.sel_d[lane] : 3.0e38f;
                         uint32_t rank = 0;
@@ -1660,16 +1717,11 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         }
                         if (mine && rank < need) {
                             const size_t s = L.sel_i[lane];
-                            const float4 pa = G.pm.pa[s];
-                            const float4 pb = G.pm.pb[s];
-                            const float2 pc = G.pm.pc[s];
-                            s_pr += pb.w; s_pg += pc.x; s_pb += pc.y;
-                            s_dx += pa.w * pb.z; s_dy += pb.x * pb.z; s_dz += pb.y * pb.z;
+                            accumulate(G.pm.pa[s], G.pm.pb[s], true);
                             tmax = md;
                         }
                     }
-                    for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
-                    area_d2 = tmax;                        // np.dist2[0] = largest kept distance
+                    area_d2 = wave_max0(tmax);                        // np.dist2[0] = largest kept distance
                 }
                 float irr_r = wave_sum(s_pr), irr_g = wave_sum(s_pg), irr_b = wave_sum(s_pb);
                 float dx = wave_sum(s_dx), dy = wave_sum(s_dy), dz = wave_sum(s_dz);
@@ -1687,8 +1739,8 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     }
                 } else {
                     // idr_Color += kd * photonrad * max(0, N.(-dir)) (FIN/main.cpp:701-704), times the ray weight
-                    const float wr = __shfl(b.z, q), wg = __shfl(b.w, q), wb = __shfl(c.x, q);
-                    const uint32_t slot = __float_as_uint(__shfl(c.y, q));
+                    const float wr = lane_f(b.z, q), wg = lane_f(b.w, q), wb = lane_f(c.x, q);
+                    const uint32_t slot = __float_as_uint(lane_f(c.y, q));
                     float theta = nx * (-dx) + ny * (-dy) + nz * (-dz);
                     theta = theta > 0.0f ? theta : 0.0f;
                     if (lane < 3) {

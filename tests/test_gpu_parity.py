@@ -166,6 +166,32 @@ def test_irradiance_on_the_reference_photon_dump(gold):
         assert (np.abs(d - ref[:, 3:]).max(axis=1)[tight] < 2e-5).all()
 
 
+def test_irradiance_single_photon_colour_bytes():
+    """one photon per query, every colour byte value: the estimate is power * (byte / 255.0f) / area
+    with nothing to sum, so the device's division-free byte / 255.0f must equal the oracle's bit for bit"""
+    n = 1200
+    pos = np.zeros((n, 3), np.float32)
+    pos[:, 0] = np.arange(n) * 5.0
+    pos[:, 1] = (np.arange(n) % 7) * 5.0
+    d = np.tile(np.array([[0, 0, -1]], np.float32), (n, 1))
+    ph = photons.pack_photons(pos, d, np.full((n, 3), 0.37, np.float32))
+    i = np.arange(n)
+    ph["color"] = np.stack([i % 256, 255 - i % 256, (i * 7) % 256], 1).astype(np.uint8)      # every byte value
+    ph["power"] = (np.float32(0.37) + np.float32(0.001) * (i % 97)).astype(np.float32)
+    bal = capi.photon_balance(np.concatenate([np.zeros(1, capi.PHOTON), ph]))
+    s = capi.Scene()
+    s.set_nodes(scenes.identity_node())
+    s.set_photons(bal)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (n, 1))
+    irr, dd = s.estimate_irradiance(50, 1.0, pos, nrm)
+    oirr, od = orc.estimate_irradiance(bal, 50, 1.0, pos, nrm)
+    lit = oirr.max(axis=1) > 0
+    assert lit.sum() > 1100                                   # all but the photons the reference cannot reach
+    assert irr.tobytes() == oirr.tobytes()
+    assert len(np.unique(bal["color"][1:].reshape(-1))) == 256
+    assert dd[lit].tobytes() == od[lit].tobytes()
+
+
 def test_irradiance_sparse_dense_and_empty():
     bal = photons.synth_cornell_photon_map(30000, seed=11)
     s = capi.Scene()

@@ -144,6 +144,18 @@ def test_photon_dat_round_trip_and_reference_dump(gold, tmp_path):
     assert hashlib.sha256(bal[1:].tobytes()).hexdigest() == str(g["balanced_sha256"])
 
 
+def test_byte_over_255_newton_step_is_the_correctly_rounded_quotient():
+    """the device forms Color24 -> Color (byte / 255.0f) as q = c*RN(1/255), e = fma(-q, 255, c),
+    q + e*RN(1/255): emulated here with exact products in float64 and one rounding per fma"""
+    c = np.arange(256, dtype=np.float32)
+    r = np.float32(1) / np.float32(255)
+    q = (c * r).astype(np.float64)
+    e = np.float32(c.astype(np.float64) - q * 255.0)                 # exact, then rounded once
+    q2 = np.float32(q + e.astype(np.float64) * np.float64(r))
+    assert (q2 == c / np.float32(255)).all()
+    assert ((c * r) != c / np.float32(255)).sum() > 100              # the plain product is NOT enough
+
+
 def test_xml_errors_are_reported(tmp_path):
     s = capi.Scene()
     with pytest.raises(capi.RtError) as e:
