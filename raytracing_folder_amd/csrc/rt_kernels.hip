@@ -27,6 +27,9 @@
 #ifndef RT_GATHER_BRANCHY
 #define RT_GATHER_BRANCHY 1    // 1: accepted lanes accumulate under a branch; 0: predicated, branch-free
 #endif
+#ifndef RT_GATHER_LUT
+#define RT_GATHER_LUT 0        // 1: byte / 255.0f from a 256-entry LDS table instead of the two-fma form
+#endif
 #ifndef RT_GATHER_GUESS
 #define RT_GATHER_GUESS 1.3f   // photons expected inside the first trial radius, in units of k (1.2-1.6 measured flat)
 #endif
@@ -295,16 +298,32 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
     // coordinate of whatever sphere/plane hit the ray had accepted before it.  Reproduced as is.
     // (The PROJ13 triangle does write it, from the mesh's texture vertices.)
     V3 uvw = mk(0.5f, 0.5f, 0.5f);
+    // Node::ToNodeCoords (scene.h:502-508) of one level; the direction is the image of p+d minus the image of p
+    auto to_node = [&](int node, V3 &lp, V3 &ldir) {
+        const DevNodeXf &X = S.nodes[node];
+        const V3 pos = ld3(X.pos);
+        const V3 rp = mmul(X.itm, lp - pos);
+        ldir = mmul(X.itm, (lp + ldir) - pos) - rp;
+        lp = rp;
+    };
+    // Every chain starts at the root (node 0) and siblings share their parent: the ray in the root's and
+    // in the last visited level-1 group's coordinates is kept instead of being recomputed per object
+    // (same operations on the same inputs, so the results do not change).  The object loop is
+    // wave-uniform, so the bookkeeping is scalar.
+    V3 p0 = o, d0 = d;
+    to_node(0, p0, d0);
+    V3 p1 = p0, d1 = d0;
+    int cached1 = -1;
     for (int oi = 0; oi < S.n_objects; oi++) {
         const DevObject &ob = S.objects[oi];
-        V3 lp = o, ldir = d;
-        for (int c = 0; c < ob.chain_len; c++) {
-            const DevNodeXf &X = S.nodes[ob.chain[c]];
-            const V3 pos = ld3(X.pos);
-            const V3 rp = mmul(X.itm, lp - pos);
-            ldir = mmul(X.itm, (lp + ldir) - pos) - rp;
-            lp = rp;
+        V3 lp = p0, ldir = d0;
+        int c = 1;
+        if (ob.chain_len > 2) {
+            const int n1 = ob.chain[1];
+            if (n1 != cached1) { p1 = p0; d1 = d0; to_node(n1, p1, d1); cached1 = n1; }
+            lp = p1; ldir = d1; c = 2;
         }
+        for (; c < ob.chain_len; c++) to_node(ob.chain[c], lp, ldir);
         cnt.inst++;
         V3 hp, hN;
         int fr = 1;
@@ -1041,8 +1060,11 @@ struct PrimaryArgs {
     const float *rays;           // mode 2
 };
 
+// Register budget: the texture-free instantiations are held to 168 VGPRs (3 waves/SIMD; a few values
+// spill to scratch) -- measured 4 % faster on MI355X than letting them grow to 192 VGPRs at 2 waves.
+#define RT_TRACE_OCC __attribute__((amdgpu_waves_per_eu(TEX ? 2 : 3)))
 template <int MODEL, bool TEX>
-__global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
+RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
     uint32_t *stack = s_stack + threadIdx.x;
@@ -1108,7 +1130,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
 
 // K2-K4 for one level of the ray tree: reads queue `qin` (count in counts[level]).
 template <int MODEL, bool TEX>
-__global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin, int level)
+RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin, int level)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
     uint32_t *stack = s_stack + threadIdx.x;
@@ -1454,8 +1476,9 @@ __device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuer
     const float dfx = pa.x - Q.px, dfy = pa.y - Q.py, dfz = pa.z - Q.pz;       // dif = p.position - np.pos
     c.d2 = dfx * dfx + dfy * dfy + dfz * dfz;                                   // LengthSquared
     c.ok = valid && (c.d2 < Q.rq2) && !((pa.w * Q.nx + pb.x * Q.ny + pb.y * Q.nz) >= 0);   // dist2 < dist2[0]; dir.N >= 0 rejects
-    uint32_t key = (uint32_t)(c.d2 * Q.kscale);
-    c.key = key > 0xFFFFFFu ? 0xFFFFFFu : key;
+    // 24-bit fixed-point distance key: kscale = 16777000 / rq2, so an accepted photon (d2 < rq2) gives
+    // at most 16777000 * (1 + 2^-22) < 2^24 whatever the roundings; rejected ones are never looked at
+    c.key = (uint32_t)(c.d2 * Q.kscale);
     return c;
 }
 
@@ -1509,6 +1532,14 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     __shared__ GatherLds lds_all[RT_GATHER_WAVES];
     GatherLds &L = lds_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
+#if RT_GATHER_LUT
+    __shared__ float s_lut[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = byte_over_255((uint32_t)i);
+    __syncthreads();
+#define BYTE_OVER_255(c) s_lut[c]
+#else
+#define BYTE_OVER_255(c) byte_over_255(c)
+#endif
     uint32_t nq = *G.count_ptr;
     if (nq > G.count_cap) nq = G.count_cap;
     const uint32_t n_leaves = G.pm.n_leaves;
@@ -1575,7 +1606,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 Q.px = lane_f(a.x, q); Q.py = lane_f(a.y, q); Q.pz = lane_f(a.z, q);
                 Q.nx = lane_f(a.w, q); Q.ny = lane_f(b.x, q); Q.nz = lane_f(b.y, q);
                 Q.rq2 = lane_f(r2cur, q);
-                Q.kscale = 16777216.0f / Q.rq2;            // 24-bit fixed-point distance key
+                Q.kscale = 16777000.0f / Q.rq2;            // 24-bit fixed-point distance key (see make_cand)
                 const float rq2 = Q.rq2, nx = Q.nx, ny = Q.ny, nz = Q.nz;
                 const uint32_t qnl = lane_u(nl, q);
                 const bool final_round = rq2 >= r2;
@@ -1612,21 +1643,20 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
 #endif
                     const uint32_t cbits = __float_as_uint(pb.w);
                     const float mp = take ? pb.z : 0.0f;
-                    s_pr += byte_over_255(cbits & 255u) * mp; s_pg += byte_over_255((cbits >> 8) & 255u) * mp; s_pb += byte_over_255((cbits >> 16) & 255u) * mp;
+                    s_pr += BYTE_OVER_255(cbits & 255u) * mp; s_pg += BYTE_OVER_255((cbits >> 8) & 255u) * mp; s_pb += BYTE_OVER_255((cbits >> 16) & 255u) * mp;
                     s_dx += pa.w * mp; s_dy += pb.x * mp; s_dz += pb.y * mp;
                 };
 
-                uint32_t my_cnt = 0;
+                uint32_t M = 0;                            // accepted photons (wave-uniform: popcount of the ballots)
                 for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                 wave_sync();
                 // pass 1
                 for_each([&](const Cand &cd, size_t) {
                     accumulate(cd.pa, cd.pb, cd.ok);
-                    my_cnt += cd.ok ? 1u : 0u;
+                    M += (uint32_t)__popcll(__ballot(cd.ok));
                     if (cd.ok) atomicAdd(&L.hist[cd.key >> 16], 1u);
                 });
                 visited += n_iter;
-                const uint32_t M = wave_sum_u(my_cnt);
                 if (!final_round && M <= K) {
                     // not enough inside the trial radius: grow it (count ~ r^2 on a surface) and retry
                     float grow = 1.5f * (float)K / (float)(M > 0 ? M : 1u);
