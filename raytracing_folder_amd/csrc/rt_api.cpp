@@ -594,6 +594,36 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
         if (len > RT_MAX_DEPTH) return fail(RT_ERR_LIMIT, "node %d is nested %d deep; the device supports %d levels", i, len, RT_MAX_DEPTH);
         o.chain_len = len;
         for (int c = 0; c < len; c++) o.chain[c] = chain[len - 1 - c];      // root .. self
+        {   // bounds in the ROOT node's coordinates (where every ray is taken first): the 8 corners of the
+            // local extent through tm*p + pos of self .. the root's child (double), inflated by 1e-3 of
+            // the extent (the exact test runs in float in local space)
+            double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};                 // unit sphere; unit square at z = 0
+            if (n.obj_type == RT_OBJ_PLANE) lo[2] = hi[2] = 0;
+            if (n.obj_type == RT_OBJ_MESH) {
+                const float *b = sd.meshes[n.mesh].nodes[1].box;
+                for (int a = 0; a < 3; a++) { lo[a] = b[a]; hi[a] = b[a + 3]; }
+            }
+            double wlo[3] = {1e300, 1e300, 1e300}, whi[3] = {-1e300, -1e300, -1e300};
+            bool finite = true;
+            for (int corner = 0; corner < 8; corner++) {
+                double q[3] = {(corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]};
+                for (int c = 0; c + 1 < len; c++) {                          // chain[] here is still self .. root
+                    const rt_node &X = sd.nodes[chain[c]];
+                    const double r[3] = {q[0] * X.tm[0] + q[1] * X.tm[3] + q[2] * X.tm[6] + X.pos[0],
+                                         q[0] * X.tm[1] + q[1] * X.tm[4] + q[2] * X.tm[7] + X.pos[1],
+                                         q[0] * X.tm[2] + q[1] * X.tm[5] + q[2] * X.tm[8] + X.pos[2]};
+                    q[0] = r[0]; q[1] = r[1]; q[2] = r[2];
+                }
+                for (int a = 0; a < 3; a++) { if (!std::isfinite(q[a])) finite = false; wlo[a] = std::min(wlo[a], q[a]); whi[a] = std::max(whi[a], q[a]); }
+            }
+            const double ext = std::max(std::max(whi[0] - wlo[0], whi[1] - wlo[1]), whi[2] - wlo[2]);
+            const double pad = 1e-3 * ext + 1e-5;
+            for (int a = 0; a < 3; a++) {
+                // a degenerate transform (non-finite corner) disables the cull for this object
+                o.wlo[a] = finite ? (float)(wlo[a] - pad) : -3.0e38f;
+                o.whi[a] = finite ? (float)(whi[a] + pad) : 3.0e38f;
+            }
+        }
         objs.push_back(o);
     }
     if (objs.size() > RT_MAX_OBJECTS) return fail(RT_ERR_LIMIT, "too many objects (%zu)", objs.size());

@@ -37,7 +37,12 @@ struct DevObject {
     int32_t type, mesh, material, node;
     int32_t chain_len;
     int32_t chain[RT_MAX_DEPTH];
-    int32_t pad[3];
+    // conservative bounds of the object in the root node's coordinates (its local extent taken through
+    // FromNodeCoords of every ancestor below the root, inflated): a ray that misses them, or enters them
+    // beyond its closest hit so far, cannot be given a hit by the exact local-space test, so the
+    // object's transforms are skipped
+    float wlo[3], whi[3];
+    int32_t pad;
 };
 
 struct DevBvhNode {              // 64 bytes

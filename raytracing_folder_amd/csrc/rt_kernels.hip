@@ -314,8 +314,13 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
     to_node(0, p0, d0);
     V3 p1 = p0, d1 = d0;
     int cached1 = -1;
+    // reciprocal direction (in the root's coordinates) for the bounds cull only: approximate is fine, the
+    // bounds are inflated
+    const V3 winv = mk(__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y), __builtin_amdgcn_rcpf(d0.z));
     for (int oi = 0; oi < S.n_objects; oi++) {
         const DevObject &ob = S.objects[oi];
+        // skip the object when no lane's ray can reach its bounds before that lane's closest hit so far
+        if (!__any(box_entry(ob.wlo, ob.whi, p0, winv, z) < 2.0e30f)) continue;
         V3 lp = p0, ldir = d0;
         int c = 1;
         if (ob.chain_len > 2) {
@@ -1546,7 +1551,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     const float r2 = G.radius * G.radius;
     const uint32_t K = (uint32_t)G.k;
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long visited = 0;
     uint32_t n_rounds = 0, n_slow = 0, n_reads = 0;       // wave-uniform tallies
 
