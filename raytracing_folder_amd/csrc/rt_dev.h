@@ -107,11 +107,46 @@ struct DevCamera {
 };
 
 // tile walk of one rt_render_* call
+// Unsigned division by a launch-constant divisor without the ~30-instruction generic sequence
+// (Granlund & Montgomery 1994, "round-up" form, exact for every 32-bit dividend):
+//   m = floor(2^32 * (2^L - d) / d) + 1, L = ceil(log2 d);  t = mulhi(x, m);  q = (t + ((x - t) >> 1)) >> (L - 1)
+struct FastDiv { uint32_t d, m, sh; };
+static inline FastDiv fastdiv_make(uint32_t d)
+{
+    FastDiv f; f.d = d; f.m = 0; f.sh = 0;
+    if (d <= 1) return f;
+    uint32_t L = 0;
+    while ((1ull << L) < (unsigned long long)d) L++;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << L) - (unsigned long long)d)) / (unsigned long long)d + 1ull);
+    f.sh = L - 1;
+    return f;
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint32_t fastdiv(uint32_t x, const FastDiv &f)
+{
+    if (f.d <= 1) return x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(x, f.m);
+#else
+    const uint32_t t = (uint32_t)(((unsigned long long)x * (unsigned long long)f.m) >> 32);
+#endif
+    return (((x - t) >> 1) + t) >> f.sh;
+}
+
 struct DevTiles {
     int32_t tile_w, tile_h, first, stride;
     int32_t tiles_x, tiles_total;
     int32_t n_tiles;          // tiles owned by this call
+    FastDiv div_per, div_tile_w, div_tiles_x;     // by tile_w*tile_h, tile_w, tiles_x (tiles_prepare)
 };
+static inline void tiles_prepare(DevTiles &t)
+{
+    t.div_per = fastdiv_make((uint32_t)(t.tile_w * t.tile_h));
+    t.div_tile_w = fastdiv_make((uint32_t)t.tile_w);
+    t.div_tiles_x = fastdiv_make((uint32_t)t.tiles_x);
+}
 
 // device-side statistics block (uint64 counters, see rt_stats)
 enum {

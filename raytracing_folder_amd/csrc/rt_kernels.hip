@@ -1042,12 +1042,13 @@ __device__ __forceinline__ void flush_counters(unsigned long long *stats, const 
 __device__ __forceinline__ bool pixel_of(const DevTiles &T, const DevCamera &cam, uint32_t q, int &x, int &y)
 {
     const uint32_t per = (uint32_t)(T.tile_w * T.tile_h);
-    const uint32_t k = q / per, w = q % per;
+    const uint32_t k = fastdiv(q, T.div_per), w = q - k * per;
     if (k >= (uint32_t)T.n_tiles) return false;
-    const int t = T.first + (int)k * T.stride;
-    const int tx = t % T.tiles_x, ty = t / T.tiles_x;
-    x = tx * T.tile_w + (int)(w % (uint32_t)T.tile_w);
-    y = ty * T.tile_h + (int)(w / (uint32_t)T.tile_w);
+    const uint32_t t = (uint32_t)T.first + k * (uint32_t)T.stride;
+    const uint32_t ty = fastdiv(t, T.div_tiles_x), tx = t - ty * (uint32_t)T.tiles_x;
+    const uint32_t wy = fastdiv(w, T.div_tile_w), wx = w - wy * (uint32_t)T.tile_w;
+    x = (int)(tx * (uint32_t)T.tile_w + wx);
+    y = (int)(ty * (uint32_t)T.tile_h + wy);
     return x < cam.width && y < cam.height;
 }
 
@@ -1063,6 +1064,7 @@ struct PrimaryArgs {
     uint32_t q0, npix;           // chunk range (mode 0)
     int j0, ns, max_sample, mode;
     const float *rays;           // mode 2
+    FastDiv div_ns;
 };
 
 // Register budget: the texture-free instantiations are held to 168 VGPRs (3 waves/SIMD; a few values
@@ -1078,6 +1080,12 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, P
     const uint32_t npix = (A.mode == 1) ? C.W.counts[CNT_PIXLIST] : A.npix;
     const unsigned long long total = (unsigned long long)npix * (unsigned long long)A.ns;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    // Halton(j, 2) and Halton(j, 3) of this launch's sample indices, once per workgroup (the loop in
+    // halton() divides; the values are the same floats either way)
+    __shared__ float s_h2[RT_BLOCK], s_h3[RT_BLOCK];
+    const bool h_table = A.mode != 2 && A.ns <= RT_BLOCK;
+    if (h_table && (int)threadIdx.x < A.ns) { s_h2[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 2); s_h3[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 3); }
+    __syncthreads();
     // every lane iterates the same number of times (wave-collective pushes inside shade_path)
     for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < total; base += stride) {
         const unsigned long long gid = base + threadIdx.x;
@@ -1087,8 +1095,10 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, P
         in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.slot = 0; in.node = 1; in.sample = 0;
         in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
         if (active) {
-            const uint32_t pi = (uint32_t)(gid / (unsigned long long)A.ns);
-            const int j = A.j0 + (int)(gid % (unsigned long long)A.ns);
+            uint32_t pi, jj;
+            if (total <= 0xFFFFFFFFull) { pi = fastdiv((uint32_t)gid, A.div_ns); jj = (uint32_t)gid - pi * (uint32_t)A.ns; }
+            else { pi = (uint32_t)(gid / (unsigned long long)A.ns); jj = (uint32_t)(gid % (unsigned long long)A.ns); }
+            const int j = A.j0 + (int)jj;
             const uint32_t ql = (A.mode == 1) ? C.W.pixel_list[pi] : pi;      // chunk-local pixel
             in.slot = ql * (uint32_t)A.max_sample + (uint32_t)j;
             if (A.mode == 2) {
@@ -1100,8 +1110,8 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, P
                 if (!pixel_of(A.tiles, A.cam, A.q0 + ql, x, y)) active = false;
                 else {
                     const V3 tmp = mk(x * A.cam.u, y * A.cam.v, 0) + ld3(A.cam.b);     // :235-236
-                    float sx = halton(j, 2) * A.cam.u;                                 // :153
-                    float sy = A.cam.v * halton(j, 3);                                 // :154
+                    float sx = (h_table ? s_h2[jj] : halton(j, 2)) * A.cam.u;          // :153
+                    float sy = A.cam.v * (h_table ? s_h3[jj] : halton(j, 3));          // :154
                     sx += tmp.x; sy += tmp.y;
                     const V3 sample = mk(sx, sy, tmp.z);
                     const uint32_t pixel_id = (uint32_t)y * (uint32_t)A.cam.width + (uint32_t)x;
@@ -1898,6 +1908,8 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
     ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
     PrimaryArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.j0 = j0; A.ns = ns;
     A.max_sample = max_sample; A.mode = mode; A.rays = rays;
+    tiles_prepare(A.tiles);
+    A.div_ns = fastdiv_make((uint32_t)(ns > 0 ? ns : 1));
     const int grid = grid_for((unsigned long long)npix * ns, RT_BLOCK, max_blocks);
     const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
 #define RT_LAUNCH_PRIMARY(M) do { if (tex) hipLaunchKernelGGL((k_primary<M, true>), dim3(grid), dim3(RT_BLOCK), 0, st, C, A); \
@@ -1957,6 +1969,7 @@ void rtk_launch_resolve(hipStream_t st, const DevScene &S, const DevWork &W, con
     ResolveArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.min_sample = min_sample;
     A.max_sample = max_sample; A.threshold = threshold; A.inv_gamma = inv_gamma; A.phase = phase;
     A.bg[0] = bg[0]; A.bg[1] = bg[1]; A.bg[2] = bg[2]; A.rgb8 = rgb8; A.z = z; A.count = count; A.direct_mode = 0; A.S = S;
+    tiles_prepare(A.tiles);
     const int grid = grid_for(npix, 256, max_blocks);
     hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, st, W, A);
 }

@@ -14,7 +14,7 @@ stats = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
 shutil.copy(stats, f"profiles/{tag}_bench_kernel_stats.csv")
 out = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                   "--no-cpu-baseline (one pass per counter; stats pass: --kernel-trace --stats, --steps 2 --warmup 1)",
-       "workload": "Cornell 1920x1080x64spp, 1M-photon map from the GPU photon pass, 32 chunks per frame",
+       "workload": "Cornell 1920x1080x64spp, 1M-photon map from the GPU photon pass, 16 chunks of 8 Mi samples per frame (32 of 4 Mi before r01d)",
        "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
        "note": "gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM "
                "section); hbm_bytes_per_launch applies that x2 to the fetch side",
