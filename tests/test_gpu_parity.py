@@ -564,6 +564,48 @@ def test_render_fixed_spp_with_photon_map_and_tile_sharding(cornell):
             assert (other[0][sl] == 0).all()             # a rank never writes foreign tiles
 
 
+def test_ragged_frames_odd_tiles_and_sample_counts(cornell):
+    """image sizes that are no multiple of the tile, tiles of odd size, sample counts that are no power of
+    two (3 -> 7, the pixel/sample index split divides by 3 and by 4) and more samples than a workgroup
+    has threads (300: the Halton table falls back to the loop); a 1 x 1 image; an empty tile range"""
+    s0, cam0, e = cornell
+    osc = scenes.oracle_scene(e)
+    s, cam = scenes.load_cornell(53, 37)
+    for kw, tiles in ((dict(min_sample=3, max_sample=7), capi.TileRange(5, 3, 0, 1)),
+                      (dict(min_sample=5, max_sample=5, threshold=-1.0), capi.TileRange(7, 11, 0, 1)),
+                      (dict(min_sample=1, max_sample=2), capi.TileRange(64, 64, 0, 1))):
+        p = capi.default_params(**kw)
+        rgb, z, cnt, st, progress = s.render(cam, p, tiles)
+        orgb, oz, ocnt = orc.render(osc, scenes.oracle_camera(cam), scenes.oracle_params(p))
+        assert progress == 53 * 37
+        diff = np.abs(rgb.astype(int) - orgb.astype(int)).max(axis=2)
+        assert (diff <= 1).mean() >= 0.99 and (z == oz).mean() > 0.995 and (cnt == ocnt).mean() > 0.99, kw
+    # interleaved odd tiles: three ranks cover the frame exactly once and agree with the single call
+    p = capi.default_params(min_sample=3, max_sample=3, threshold=-1.0)
+    whole, zw, _, _, _ = s.render(cam, p, capi.TileRange(5, 3, 0, 1))
+    acc, hits = np.zeros_like(whole, dtype=np.int32), np.zeros((37, 53), np.int32)
+    for rank in range(3):
+        r, zz, _, _, _ = s.render(cam, p, capi.TileRange(5, 3, rank, 3))
+        acc += r
+        hits += (zz != 0)
+    assert (hits == 1).all() and (np.abs(acc - whole.astype(np.int32)) <= 1).all()
+    # more samples per pixel than threads in a workgroup
+    s2, cam2 = scenes.load_cornell(9, 7)
+    p = capi.default_params(min_sample=300, max_sample=300, threshold=-1.0)
+    rgb, z, cnt, st, _ = s2.render(cam2, p)
+    orgb, oz, ocnt = orc.render(osc, scenes.oracle_camera(cam2), scenes.oracle_params(p))
+    assert st.rays_primary == 300 * 63 and (np.abs(rgb.astype(int) - orgb.astype(int)) <= 1).all() and (z == oz).all()
+    # 1 x 1
+    s3, cam3 = scenes.load_cornell(1, 1)
+    p = capi.default_params()
+    rgb, z, cnt, _, progress = s3.render(cam3, p)
+    orgb, oz, ocnt = orc.render(osc, scenes.oracle_camera(cam3), scenes.oracle_params(p))
+    assert progress == 1 and (np.abs(rgb.astype(int) - orgb.astype(int)) <= 1).all() and (z == oz).all()
+    # a rank that owns no tile leaves the buffers alone
+    rgb, z, cnt, st, progress = s.render(cam, p, capi.TileRange(32, 8, 50, 64))
+    assert progress == 0 and st.rays_primary == 0 and (rgb == 0).all() and (z == 0).all()
+
+
 def test_full_size_frame_properties():
     """BASELINE size (1920 x 1080) with 2 fixed samples: size-independent properties"""
     s, cam = scenes.load_cornell(1920, 1080)
