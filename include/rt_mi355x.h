@@ -305,7 +305,10 @@ rt_status rt_photon_pass(rt_scene *s, int device, uint32_t max_photons, int phot
  *      (FIN/main.cpp:202-344,984-1012; FIN/include/scene.h:586-589) ---------------------- */
 /* Asynchronous: returns after the job's worker thread has started.  Output buffers are
  * caller-owned host memory of width*height pixels (rgb8: 3 bytes per pixel) and may be read
- * at any time (partially filled while the job runs, as in the reference). */
+ * at any time: finished bands of rows are copied into them chunk by chunk while the job runs
+ * (the reference's viewport shows renderImage.GetPixels() as it fills, viewport.cpp:367), and
+ * rt_render_progress counts only pixels that have already arrived.  Pixels of tiles this call
+ * does not own, and of chunks not reached before rt_render_stop, keep the caller's values. */
 rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt_params *p,
                           const rt_tile_range *tiles, int device,
                           uint8_t *rgb8, float *z, uint8_t *count, rt_job **out);

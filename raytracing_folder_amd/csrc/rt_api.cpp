@@ -162,6 +162,10 @@ struct rt_job {
     rt_status status = RT_OK;
     std::string error;
     rt_stats stats{};
+    // caller-owned host image (rt_render_begin): finished bands are copied back chunk by chunk, so a
+    // viewer that polls rt_render_progress can show the frame as it fills (viewport.cpp:367 reads
+    // renderImage.GetPixels() while the workers run)
+    uint8_t *host_rgb = nullptr, *host_count = nullptr; float *host_z = nullptr;
 };
 
 // ---- scene store ---------------------------------------------------------------------------------------
@@ -1018,7 +1022,6 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
         HIP_TRY(hipEventRecord(e_begin, stream));
     }
     const float inv_gamma = (float)(1.0 / p->gamma);        // powf(x, 1.0/gamma): double quotient narrowed to float
-    uint64_t samples = 0;
     double ms_resolve = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> resolve_ev;
     for (uint64_t q0 = 0; q0 < total_px; q0 += ppc) {
@@ -1041,7 +1044,6 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
             if ((st = timed_resolve(1))) return st;
         }
         HIP_TRY(hipGetLastError());
-        samples += (uint64_t)npix * p->min_sample;
         if (job) {
             HIP_TRY(hipStreamSynchronize(stream));
             // pixels of this chunk that lie inside the image
@@ -1051,6 +1053,18 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
                 const int tx = t % dt.tiles_x, ty = t / dt.tiles_x;
                 const int w = std::min(dt.tile_w, cam->width - tx * dt.tile_w), h = std::min(dt.tile_h, cam->height - ty * dt.tile_h);
                 if (w > 0 && h > 0) done += w * h;
+            }
+            if (job->host_rgb) {
+                // rows spanned by this chunk's tiles (tile-major order: a contiguous band of tile rows)
+                const uint64_t k0 = q0 / tile_px, k1 = (q0 + npix - 1) / tile_px;
+                const int ty0 = (dt.first + (int)k0 * dt.stride) / dt.tiles_x, ty1 = (dt.first + (int)k1 * dt.stride) / dt.tiles_x;
+                const size_t y0 = (size_t)ty0 * dt.tile_h, y1 = std::min<size_t>((size_t)cam->height, (size_t)(ty1 + 1) * dt.tile_h);
+                if (y1 > y0) {
+                    const size_t o = y0 * cam->width, n = (y1 - y0) * cam->width;
+                    HIP_TRY(hipMemcpy(job->host_rgb + 3 * o, rgb8_dev + 3 * o, 3 * n, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(job->host_z + o, z_dev + o, 4 * n, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(job->host_count + o, count_dev + o, n, hipMemcpyDeviceToHost));
+                }
             }
             job->progress.fetch_add(done);
         }
@@ -1118,6 +1132,7 @@ extern "C" rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt
     if ((st = prepare_device(s, device, &D))) return st;      // fail early (and loudly) when there is no GPU
     rt_job *job = new rt_job;
     job->scene = s;
+    job->host_rgb = rgb8; job->host_z = z; job->host_count = count;
     s->live_jobs.fetch_add(1);
     const rt_camera camv = *cam; const rt_params pv = *p; const rt_tile_range tv = *tiles;
     job->worker = std::thread([=]() {
@@ -1130,12 +1145,8 @@ extern "C" rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt
             HIP_TRY(hipMemcpy(d_rgb, rgb8, npx * 3, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(d_z, z, npx * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(d_cnt, count, npx, hipMemcpyHostToDevice));
-            rt_status q = render_tiles(s, &camv, &pv, &tv, device, nullptr, false, d_rgb, d_z, d_cnt, true, nullptr, job);
-            if (q) return q;
-            HIP_TRY(hipMemcpy(rgb8, d_rgb, npx * 3, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(z, d_z, npx * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(count, d_cnt, npx, hipMemcpyDeviceToHost));
-            return RT_OK;
+            // render_tiles copies every finished band of rows back into the caller's buffers
+            return render_tiles(s, &camv, &pv, &tv, device, nullptr, false, d_rgb, d_z, d_cnt, true, nullptr, job);
         };
         r = body();
         if (d_rgb) (void)hipFree(d_rgb);

@@ -606,6 +606,42 @@ def test_ragged_frames_odd_tiles_and_sample_counts(cornell):
     assert progress == 0 and st.rays_primary == 0 and (rgb == 0).all() and (z == 0).all()
 
 
+def test_job_progress_stop_and_partial_image(cornell, monkeypatch):
+    """BeginRender/StopRender semantics: the caller's buffers fill band by band, progress counts pixels that
+    have arrived, a stopped job leaves the rest untouched and what arrived equals the full render"""
+    import ctypes as C
+    import time
+    monkeypatch.setenv("RT_CHUNK_SAMPLES", "8192")            # many chunks on a small frame
+    s, cam = scenes.load_cornell(128, 96)
+    p = capi.default_params(min_sample=8, max_sample=8, threshold=-1.0)
+    full, zfull, _, _, prog = s.render(cam, p)
+    assert prog == 128 * 96
+    rgb, z, cnt = np.zeros((96, 128, 3), np.uint8), np.zeros((96, 128), np.float32), np.zeros((96, 128), np.uint8)
+    job = C.c_void_p()
+    tiles = capi.TileRange(32, 8, 0, 1)
+    capi._check(capi.lib().rt_render_begin(s._h, C.byref(cam), C.byref(p), C.byref(tiles), 0, capi._p(rgb), capi._p(z),
+                                           capi._p(cnt), C.byref(job)))
+    try:
+        with pytest.raises(capi.RtError):                     # the scene is locked while a job is live
+            s.set_lights(np.zeros(0, capi.LIGHT))
+        seen = 0
+        t0 = time.time()
+        while seen == 0 and time.time() - t0 < 30:
+            seen = capi.lib().rt_render_progress(job)
+        capi._check(capi.lib().rt_render_stop(job))
+        capi._check(capi.lib().rt_render_wait(job))
+        done = capi.lib().rt_render_progress(job)
+    finally:
+        capi.lib().rt_job_destroy(job)
+    assert 0 < seen <= done <= 128 * 96
+    arrived = z != 0
+    assert arrived.sum() == done
+    assert (z[arrived] == zfull[arrived]).all()
+    assert (np.abs(rgb[arrived].astype(int) - full[arrived].astype(int)) <= 1).all()
+    assert (rgb[~arrived] == 0).all()
+    s.set_lights(s.export()["lights"])                        # unlocked again
+
+
 def test_full_size_frame_properties():
     """BASELINE size (1920 x 1080) with 2 fixed samples: size-independent properties"""
     s, cam = scenes.load_cornell(1920, 1080)
