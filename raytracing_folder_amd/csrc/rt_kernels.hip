@@ -239,21 +239,14 @@ __device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN,
     bool any = false;
     uint32_t best_slot = 0;
     V3 bc = mk(0, 0, 0);
-    for (;;) {
-        if (cur & LEAF_BIT) {
-            const uint32_t count = ((cur >> 28) & 7u) + 1;
-            const uint32_t first = cur & 0x0FFFFFFFu;
-            for (uint32_t i = 0; i < count; i++) {
-                const DevTri T = M.tris[first + i];
-                cnt.tris++;
-                const bool h = (MODEL != RT_SHADE_FIN) ? tri_hit_p13(T, o, d, z, hp, bc, front)
-                                                       : tri_hit_fin(T, o, d, z, hp, bc, front);
-                if (h) { any = true; best_slot = first + i; }
-            }
-            if (ANY && any) return true;
-            if (sp == 0) break;
-            cur = stack[(--sp) * RT_BLOCK];
-        } else {
+    // "while-while" traversal: every lane first walks down to its next leaf (inner loop), then all lanes
+    // that hold a leaf test its triangles together.  With one loop that does either step per iteration a
+    // single lane at a leaf makes the whole wave sit through the triangle code; for the reflected rays of
+    // the 100 k-triangle scene that costs about half the bounce kernel's time.  Each lane still visits
+    // the same nodes and triangles in the same order (near child first, far child on the stack).
+    const uint32_t DONE = 0xFFFFFFFFu;                  // has LEAF_BIT set: ends the inner loop
+    while (cur != DONE) {
+        while (!(cur & LEAF_BIT)) {
             const DevBvhNode nd = M.nodes[cur];
             cnt.nodes++;
             const float e0 = box_entry(nd.lo0, nd.hi0, o, inv, z);
@@ -265,8 +258,20 @@ __device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN,
                 cur = first0 ? nd.c0 : nd.c1;
             } else if (h0) cur = nd.c0;
             else if (h1) cur = nd.c1;
-            else { if (sp == 0) break; cur = stack[(--sp) * RT_BLOCK]; }
+            else cur = sp ? stack[(--sp) * RT_BLOCK] : DONE;
         }
+        if (cur == DONE) break;
+        const uint32_t count = ((cur >> 28) & 7u) + 1;
+        const uint32_t first = cur & 0x0FFFFFFFu;
+        for (uint32_t i = 0; i < count; i++) {
+            const DevTri T = M.tris[first + i];
+            cnt.tris++;
+            const bool h = (MODEL != RT_SHADE_FIN) ? tri_hit_p13(T, o, d, z, hp, bc, front)
+                                                   : tri_hit_fin(T, o, d, z, hp, bc, front);
+            if (h) { any = true; best_slot = first + i; }
+        }
+        if (ANY && any) return true;
+        cur = sp ? stack[(--sp) * RT_BLOCK] : DONE;
     }
     if (!any) return false;
     // cyTriMesh::GetNormal = vn[fn0]*bc.x + vn[fn1]*bc.y + vn[fn2]*bc.z (cyTriMesh.h:167,191)
