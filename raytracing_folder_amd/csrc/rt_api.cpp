@@ -116,26 +116,42 @@ struct DevBuf {
 
 struct DevMeshBufs { DevBuf nodes, tris, tri_face, nrm, tex; };
 
+// Per-chunk working set.  A frame's chunks alternate between RT_STREAMS of these, each on its own HIP
+// stream, so that the short launches of one chunk (deep bounce levels with few rays, whose duration is
+// the latency of one ray's path) overlap the wide launches of the other.
+#define RT_STREAMS 4                    /* slots compiled in; render_streams() says how many are used */
+struct Workspace {
+    DevBuf sample_rgb, sample_z, sample_hit, rq[2][5], pq[3], counts, pixel_list, spill;
+    size_t samples = 0; uint32_t rq_cap = 0, pq_cap = 0;
+    hipStream_t stream = nullptr;       // slot 0 runs on the caller's / the device's main stream instead
+    void release()
+    {
+        for (DevBuf *b : {&sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &spill}) b->release();
+        for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) rq[i][k].release();
+        for (int k = 0; k < 3; k++) pq[k].release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
 struct DeviceState {
     int device = -1;
     bool scene_valid = false, photons_valid = false;
     DevBuf nodes, objects, meshes, materials, lights, node_material, textures, texels, material_maps;
     std::vector<DevMeshBufs> mesh_bufs;
-    DevBuf pa, pb, tbox, spill, grid;
+    DevBuf pa, pb, tbox, grid;
     DevScene scene{};
-    // workspace
-    DevBuf sample_rgb, sample_z, sample_hit, rq[2][5], pq[3], counts, pixel_list, stats;
-    size_t ws_samples = 0; uint32_t ws_rq_cap = 0, ws_pq_cap = 0;
+    Workspace ws[RT_STREAMS];
+    DevBuf stats;
     // scratch for the single-stage entry points
     DevBuf t_in, t_out[6];
     hipStream_t stream = nullptr;
     void release()
     {
-        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &tbox, &spill, &grid,
-                          &sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &stats, &t_in}) b->release();
+        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &tbox, &grid,
+                          &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
-        for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) rq[i][k].release();
-        for (int k = 0; k < 3; k++) pq[k].release();
+        for (Workspace &w : ws) w.release();
         for (int k = 0; k < 6; k++) t_out[k].release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
@@ -824,8 +840,6 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D)
         for (int a = 0; a < 3; a++) { pm.grid_min[a] = rb[a]; pm.grid_dim[a] = dim[a]; }
         pm.cell = cell; pm.inv_cell = 1.0f / cell;
     }
-    // spill lists: one per wave of the gather grid (GATHER_BLOCKS x RT_GATHER_WAVES), n_leaves ids each
-    if ((st = D->spill.ensure((size_t)GATHER_BLOCKS * RT_GATHER_WAVES * n_leaves * sizeof(uint16_t)))) return st;
     return RT_OK;
 }
 
@@ -860,9 +874,19 @@ static size_t chunk_samples_limit()
     return (size_t)v;
 }
 
-static rt_status ensure_workspace(DeviceState *D, size_t samples, int bounce, size_t list_pixels, int fan = 2)
+// Chunks of a frame in flight at once (each on its own stream with its own working set): 2 by default,
+// 1..RT_STREAMS with RT_STREAMS=n in the environment (tuning / debugging)
+static int render_streams()
+{
+    const char *e = getenv("RT_STREAMS");
+    const int v = e ? atoi(e) : 3;         // measured on MI355X (Cornell / 100 k-triangle frame): 1: 89 / 60 ms, 2: 79 / 43, 3: 78 / 39, 4: 80 / 43
+    return v < 1 ? 1 : (v > RT_STREAMS ? RT_STREAMS : v);
+}
+
+static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int bounce, size_t list_pixels, int fan = 2)
 {
     rt_status st;
+    Workspace &w = D->ws[slot];
     if (bounce < 0) bounce = 0;
     if (bounce > 12) return fail(RT_ERR_LIMIT, "bounce limit %d > 12", bounce);
     // worst case: every hit spawns `fan` rays, level after level (overflow is detected and reported)
@@ -875,28 +899,32 @@ static rt_status ensure_workspace(DeviceState *D, size_t samples, int bounce, si
     if (pq_cap > lim) pq_cap = lim;
     if (rq_cap < 64) rq_cap = 64;
     if (pq_cap < 64) pq_cap = 64;
-    if ((st = D->sample_rgb.ensure(samples * 12))) return st;
-    if ((st = D->sample_z.ensure(samples * 4))) return st;
-    if ((st = D->sample_hit.ensure(samples))) return st;
-    for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) if ((st = D->rq[i][k].ensure((size_t)rq_cap * 16))) return st;
-    for (int k = 0; k < 3; k++) if ((st = D->pq[k].ensure((size_t)pq_cap * 16))) return st;
-    if ((st = D->counts.ensure(CNT_TOTAL * 4))) return st;
-    if ((st = D->pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
+    if ((st = w.sample_rgb.ensure(samples * 12))) return st;
+    if ((st = w.sample_z.ensure(samples * 4))) return st;
+    if ((st = w.sample_hit.ensure(samples))) return st;
+    for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) if ((st = w.rq[i][k].ensure((size_t)rq_cap * 16))) return st;
+    for (int k = 0; k < 3; k++) if ((st = w.pq[k].ensure((size_t)pq_cap * 16))) return st;
+    if ((st = w.counts.ensure(CNT_TOTAL * 4))) return st;
+    if ((st = w.pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
+    // gather spill lists: one per wave of the gather grid (GATHER_BLOCKS x RT_GATHER_WAVES), n_leaves ids each
+    if ((st = w.spill.ensure((size_t)GATHER_BLOCKS * RT_GATHER_WAVES * std::max<uint32_t>(D->scene.pm.n_leaves, 1u) * sizeof(uint16_t)))) return st;
     if (!D->stats.p) { if ((st = D->stats.ensure(ST_COUNT * 8))) return st; }
-    D->ws_samples = samples; D->ws_rq_cap = (uint32_t)rq_cap; D->ws_pq_cap = (uint32_t)pq_cap;
+    if (slot > 0 && !w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    w.samples = samples; w.rq_cap = (uint32_t)rq_cap; w.pq_cap = (uint32_t)pq_cap;
     return RT_OK;
 }
 
-static DevWork make_work(DeviceState *D)
+static DevWork make_work(DeviceState *D, int slot)
 {
+    const Workspace &w = D->ws[slot];
     DevWork W;
-    W.sample_rgb = (float *)D->sample_rgb.p; W.sample_z = (float *)D->sample_z.p; W.sample_hit = (uint8_t *)D->sample_hit.p;
+    W.sample_rgb = (float *)w.sample_rgb.p; W.sample_z = (float *)w.sample_z.p; W.sample_hit = (uint8_t *)w.sample_hit.p;
     for (int i = 0; i < 2; i++) {
-        W.rq[i].a = (float4 *)D->rq[i][0].p; W.rq[i].b = (float4 *)D->rq[i][1].p; W.rq[i].c = (float4 *)D->rq[i][2].p;
-        W.rq[i].d = (uint4 *)D->rq[i][3].p; W.rq[i].e = (float4 *)D->rq[i][4].p; W.rq[i].cap = D->ws_rq_cap;
+        W.rq[i].a = (float4 *)w.rq[i][0].p; W.rq[i].b = (float4 *)w.rq[i][1].p; W.rq[i].c = (float4 *)w.rq[i][2].p;
+        W.rq[i].d = (uint4 *)w.rq[i][3].p; W.rq[i].e = (float4 *)w.rq[i][4].p; W.rq[i].cap = w.rq_cap;
     }
-    W.pq.qa = (float4 *)D->pq[0].p; W.pq.qb = (float4 *)D->pq[1].p; W.pq.qc = (float4 *)D->pq[2].p; W.pq.cap = D->ws_pq_cap;
-    W.counts = (uint32_t *)D->counts.p; W.pixel_list = (uint32_t *)D->pixel_list.p;
+    W.pq.qa = (float4 *)w.pq[0].p; W.pq.qb = (float4 *)w.pq[1].p; W.pq.qc = (float4 *)w.pq[2].p; W.pq.cap = w.pq_cap;
+    W.counts = (uint32_t *)w.counts.p; W.pixel_list = (uint32_t *)w.pixel_list.p;
     W.stats = (unsigned long long *)D->stats.p;
     return W;
 }
@@ -947,7 +975,7 @@ static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const 
 
 struct Timing { std::vector<hipEvent_t> ev; std::vector<int> cls; };
 
-static rt_status run_pipeline(DeviceState *D, hipStream_t st, const DevWork &W, const rt_params &P, Timing *tm,
+static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const DevWork &W, const rt_params &P, Timing *tm,
                               const DevCamera &dc, const DevTiles &dt, uint32_t q0, uint32_t npix, int j0, int ns,
                               int max_sample, int mode, const float *rays_dev)
 {
@@ -973,7 +1001,7 @@ static rt_status run_pipeline(DeviceState *D, hipStream_t st, const DevWork &W, 
     if ((s = mark(0))) return s;
     if (D->scene.pm.n_leaves) {
         rtk_launch_gather(st, D->scene.pm, W.pq.qa, W.pq.qb, W.pq.qc, W.counts + CNT_PHOTONQ, W.pq.cap, P.knn_k, P.knn_radius,
-                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, (uint16_t *)D->spill.p,
+                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, (uint16_t *)D->ws[slot].spill.p,
                           W.counts + CNT_GATHER_NEXT);
         if ((s = mark(1))) return s;
     }
@@ -1010,63 +1038,120 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
     // P12: a diffuse hit spawns hemisphere rays on top of the reflection/refraction pair; in practice one
     // of the three classes dominates per material, so the queues are sized for a fan-out of 2 and an
     // overflow is reported as an error rather than silently dropped
-    if ((st = ensure_workspace(D, (size_t)ppc * p->max_sample, p->bounce, (size_t)ppc,
-                               p->shade_model == RT_SHADE_P12 && p->hemisphere_sample > 1 ? 1 + p->hemisphere_sample : 2))) return st;
-    const DevWork W = make_work(D);
+    const uint64_t n_chunks = total_px ? (total_px + ppc - 1) / ppc : 0;
+    int n_slots = (int)std::min<uint64_t>(std::max<uint64_t>(n_chunks, 1), (uint64_t)render_streams());
+    DevWork Ws[RT_STREAMS];
+    int n_ready = 0;
+    for (int i = 0; i < n_slots; i++) {
+        if (i > 0 && D->ws[i].samples < (size_t)ppc * p->max_sample) {
+            // an extra working set is an optimisation: take it only while a comfortable share of the HBM stays
+            // free (other ranks rehearsing on the same device, the caller's own tensors)
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+            const size_t first = D->ws[0].sample_rgb.bytes + D->ws[0].sample_z.bytes + D->ws[0].sample_hit.bytes + 10 * D->ws[0].rq[0][0].bytes +
+                                 3 * D->ws[0].pq[0].bytes + D->ws[0].spill.bytes;
+            if (free_b < first + first / 4 + (total_b >> 3)) break;
+        }
+        if ((st = ensure_workspace(D, i, (size_t)ppc * p->max_sample, p->bounce, (size_t)ppc,
+                                   p->shade_model == RT_SHADE_P12 && p->hemisphere_sample > 1 ? 1 + p->hemisphere_sample : 2))) return st;
+        Ws[i] = make_work(D, i);
+        n_ready++;
+    }
+    n_slots = n_ready;
     const bool want_stats = stats_out != nullptr || job != nullptr;
-    Timing tm;
+    Timing tm[RT_STREAMS];
     hipEvent_t e_begin = nullptr, e_end = nullptr;
     if (want_stats) {
-        HIP_TRY(hipMemsetAsync(W.stats, 0, ST_COUNT * 8, stream));
+        HIP_TRY(hipMemsetAsync(Ws[0].stats, 0, ST_COUNT * 8, stream));
         HIP_TRY(hipEventCreate(&e_begin)); HIP_TRY(hipEventCreate(&e_end));
         HIP_TRY(hipEventRecord(e_begin, stream));
+    }
+    // slot 0 runs on `stream` itself; the other slots' streams start after everything already queued on
+    // `stream` (fork) and `stream` waits for them at the end (join), so the call keeps stream-order semantics
+    auto slot_stream = [&](int slot) { return slot == 0 ? stream : D->ws[slot].stream; };
+    if (n_slots > 1) {
+        hipEvent_t e_fork;
+        HIP_TRY(hipEventCreateWithFlags(&e_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(e_fork, stream));
+        for (int i = 1; i < n_slots; i++) HIP_TRY(hipStreamWaitEvent(slot_stream(i), e_fork, 0));
+        (void)hipEventDestroy(e_fork);
     }
     const float inv_gamma = (float)(1.0 / p->gamma);        // powf(x, 1.0/gamma): double quotient narrowed to float
     double ms_resolve = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> resolve_ev;
-    for (uint64_t q0 = 0; q0 < total_px; q0 += ppc) {
+    // chunks in flight (job mode): finished oldest-first for progress and the band copy
+    struct InFlight { uint64_t q0; uint32_t npix; hipEvent_t done; };
+    std::vector<InFlight> flight;
+    auto finish_oldest = [&]() -> rt_status {
+        const InFlight f = flight.front();
+        flight.erase(flight.begin());
+        HIP_TRY(hipEventSynchronize(f.done));
+        (void)hipEventDestroy(f.done);
+        // pixels of this chunk that lie inside the image
+        int done = 0;
+        for (uint64_t q = f.q0; q < f.q0 + f.npix; q += tile_px) {
+            const int t = dt.first + (int)(q / tile_px) * dt.stride;
+            const int tx = t % dt.tiles_x, ty = t / dt.tiles_x;
+            const int w = std::min(dt.tile_w, cam->width - tx * dt.tile_w), h = std::min(dt.tile_h, cam->height - ty * dt.tile_h);
+            if (w > 0 && h > 0) done += w * h;
+        }
+        if (job->host_rgb) {
+            // rows spanned by this chunk's tiles (tile-major order: a contiguous band of tile rows; a row shared
+            // with a chunk still in flight may arrive torn and is copied again when that chunk finishes)
+            const uint64_t k0 = f.q0 / tile_px, k1 = (f.q0 + f.npix - 1) / tile_px;
+            const int ty0 = (dt.first + (int)k0 * dt.stride) / dt.tiles_x, ty1 = (dt.first + (int)k1 * dt.stride) / dt.tiles_x;
+            const size_t y0 = (size_t)ty0 * dt.tile_h, y1 = std::min<size_t>((size_t)cam->height, (size_t)(ty1 + 1) * dt.tile_h);
+            if (y1 > y0) {
+                const size_t o = y0 * cam->width, n = (y1 - y0) * cam->width;
+                HIP_TRY(hipMemcpy(job->host_rgb + 3 * o, rgb8_dev + 3 * o, 3 * n, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(job->host_z + o, z_dev + o, 4 * n, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(job->host_count + o, count_dev + o, n, hipMemcpyDeviceToHost));
+            }
+        }
+        job->progress.fetch_add(done);
+        return RT_OK;
+    };
+    uint64_t chunk_index = 0;
+    for (uint64_t q0 = 0; q0 < total_px; q0 += ppc, chunk_index++) {
         if (job && job->stop.load()) break;
+        const int slot = (int)(chunk_index % (uint64_t)n_slots);
+        const hipStream_t cs = slot_stream(slot);
+        const DevWork &W = Ws[slot];
+        Timing *tmp = want_stats ? &tm[slot] : nullptr;
         const uint32_t npix = (uint32_t)std::min<uint64_t>(ppc, total_px - q0);
-        HIP_TRY(hipMemsetAsync(W.counts + CNT_PIXLIST, 0, 4, stream));
-        if ((st = run_pipeline(D, stream, W, *p, want_stats ? &tm : nullptr, dc, dt, (uint32_t)q0, npix, 0, p->min_sample, p->max_sample, 0, nullptr))) return st;
+        HIP_TRY(hipMemsetAsync(W.counts + CNT_PIXLIST, 0, 4, cs));
+        if ((st = run_pipeline(D, slot, cs, W, *p, tmp, dc, dt, (uint32_t)q0, npix, 0, p->min_sample, p->max_sample, 0, nullptr))) return st;
         auto timed_resolve = [&](int phase) -> rt_status {
             hipEvent_t r0 = nullptr, r1 = nullptr;
-            if (want_stats) { HIP_TRY(hipEventCreate(&r0)); HIP_TRY(hipEventCreate(&r1)); HIP_TRY(hipEventRecord(r0, stream)); }
-            rtk_launch_resolve(stream, D->scene, W, dc, dt, (uint32_t)q0, npix, p->min_sample, p->max_sample, p->threshold, inv_gamma, phase,
+            if (want_stats) { HIP_TRY(hipEventCreate(&r0)); HIP_TRY(hipEventCreate(&r1)); HIP_TRY(hipEventRecord(r0, cs)); }
+            rtk_launch_resolve(cs, D->scene, W, dc, dt, (uint32_t)q0, npix, p->min_sample, p->max_sample, p->threshold, inv_gamma, phase,
                                D->scene.bg, rgb8_dev, z_dev, count_dev, 2048);
-            if (want_stats) { HIP_TRY(hipEventRecord(r1, stream)); resolve_ev.emplace_back(r0, r1); }
+            if (want_stats) { HIP_TRY(hipEventRecord(r1, cs)); resolve_ev.emplace_back(r0, r1); }
             return RT_OK;
         };
         if ((st = timed_resolve(0))) return st;
         if (p->max_sample > p->min_sample) {
-            if ((st = run_pipeline(D, stream, W, *p, want_stats ? &tm : nullptr, dc, dt, (uint32_t)q0, npix, p->min_sample,
+            if ((st = run_pipeline(D, slot, cs, W, *p, tmp, dc, dt, (uint32_t)q0, npix, p->min_sample,
                                    p->max_sample - p->min_sample, p->max_sample, 1, nullptr))) return st;
             if ((st = timed_resolve(1))) return st;
         }
         HIP_TRY(hipGetLastError());
         if (job) {
-            HIP_TRY(hipStreamSynchronize(stream));
-            // pixels of this chunk that lie inside the image
-            int done = 0;
-            for (uint64_t q = q0; q < q0 + npix; q += tile_px) {
-                const int t = dt.first + (int)(q / tile_px) * dt.stride;
-                const int tx = t % dt.tiles_x, ty = t / dt.tiles_x;
-                const int w = std::min(dt.tile_w, cam->width - tx * dt.tile_w), h = std::min(dt.tile_h, cam->height - ty * dt.tile_h);
-                if (w > 0 && h > 0) done += w * h;
-            }
-            if (job->host_rgb) {
-                // rows spanned by this chunk's tiles (tile-major order: a contiguous band of tile rows)
-                const uint64_t k0 = q0 / tile_px, k1 = (q0 + npix - 1) / tile_px;
-                const int ty0 = (dt.first + (int)k0 * dt.stride) / dt.tiles_x, ty1 = (dt.first + (int)k1 * dt.stride) / dt.tiles_x;
-                const size_t y0 = (size_t)ty0 * dt.tile_h, y1 = std::min<size_t>((size_t)cam->height, (size_t)(ty1 + 1) * dt.tile_h);
-                if (y1 > y0) {
-                    const size_t o = y0 * cam->width, n = (y1 - y0) * cam->width;
-                    HIP_TRY(hipMemcpy(job->host_rgb + 3 * o, rgb8_dev + 3 * o, 3 * n, hipMemcpyDeviceToHost));
-                    HIP_TRY(hipMemcpy(job->host_z + o, z_dev + o, 4 * n, hipMemcpyDeviceToHost));
-                    HIP_TRY(hipMemcpy(job->host_count + o, count_dev + o, n, hipMemcpyDeviceToHost));
-                }
-            }
-            job->progress.fetch_add(done);
+            InFlight f; f.q0 = q0; f.npix = npix;
+            HIP_TRY(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(f.done, cs));
+            flight.push_back(f);
+            while ((int)flight.size() >= n_slots) if ((st = finish_oldest())) return st;
+        }
+    }
+    while (job && !flight.empty()) if ((st = finish_oldest())) return st;
+    if (n_slots > 1) {
+        for (int i = 1; i < n_slots; i++) {
+            hipEvent_t e_join;
+            HIP_TRY(hipEventCreateWithFlags(&e_join, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(e_join, slot_stream(i)));
+            HIP_TRY(hipStreamWaitEvent(stream, e_join, 0));
+            (void)hipEventDestroy(e_join);
         }
     }
     if (want_stats) HIP_TRY(hipEventRecord(e_end, stream));
@@ -1075,18 +1160,21 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
         rt_stats R;
         memset(&R, 0, sizeof R);
         unsigned long long hs[ST_COUNT];
-        HIP_TRY(hipMemcpy(hs, W.stats, sizeof hs, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hs, Ws[0].stats, sizeof hs, hipMemcpyDeviceToHost));
         R.rays_primary = hs[ST_RAYS_PRIMARY]; R.rays_shadow = hs[ST_RAYS_SHADOW]; R.rays_reflect = hs[ST_RAYS_REFLECT];
         R.rays_refract = hs[ST_RAYS_REFRACT]; R.instance_visits = hs[ST_INSTANCE_VISITS]; R.bvh_nodes_visited = hs[ST_BVH_NODES];
         R.tris_tested = hs[ST_TRIS]; R.photon_queries = hs[ST_PHOTON_QUERIES]; R.photons_visited = hs[ST_PHOTONS_VISITED];
         R.pixels = 0; R.samples = hs[ST_RAYS_PRIMARY];
         R.gather_rounds = hs[ST_GATHER_ROUNDS]; R.gather_slow = hs[ST_GATHER_SLOW]; R.gather_leaf_reads = hs[ST_GATHER_LEAF_READS];
-        for (size_t i = 1; i < tm.ev.size(); i++) {
-            if (tm.cls[i] < 0) continue;
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, tm.ev[i - 1], tm.ev[i]));
-            if (tm.cls[i] == 0) { R.ms_trace += ms; R.launches_trace++; } else { R.ms_gather += ms; R.launches_gather++; }
-        }
+        // per-stream intervals between consecutive marks: with two chunks in flight a kernel shares the GPU
+        // with the other stream's kernels, so these are durations under overlap (the same thing rocprofv3 reports)
+        for (int sl = 0; sl < n_slots; sl++)
+            for (size_t i = 1; i < tm[sl].ev.size(); i++) {
+                if (tm[sl].cls[i] < 0) continue;
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, tm[sl].ev[i - 1], tm[sl].ev[i]));
+                if (tm[sl].cls[i] == 0) { R.ms_trace += ms; R.launches_trace++; } else { R.ms_gather += ms; R.launches_gather++; }
+            }
         for (auto &pr : resolve_ev) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
@@ -1097,7 +1185,7 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, e_begin, e_end));
         R.ms_total = ms;
-        for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
+        for (int sl = 0; sl < RT_STREAMS; sl++) for (hipEvent_t e : tm[sl].ev) (void)hipEventDestroy(e);
         (void)hipEventDestroy(e_begin); (void)hipEventDestroy(e_end);
         for (uint64_t k = 0; k < (uint64_t)dt.n_tiles; k++) {
             const int t = dt.first + (int)k * dt.stride;
@@ -1233,9 +1321,10 @@ extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, 
     if ((st = D->t_out[3].ensure((size_t)n * 12))) return st;
     if ((st = D->t_out[4].ensure((size_t)n * 12))) return st;
     if ((st = D->t_in.upload(cnt, 8))) return st;
+    if ((st = D->ws[0].spill.ensure((size_t)GATHER_BLOCKS * RT_GATHER_WAVES * D->scene.pm.n_leaves * sizeof(uint16_t)))) return st;
     rtk_launch_gather(D->stream, D->scene.pm, (const float4 *)D->t_out[0].p, (const float4 *)D->t_out[1].p, (const float4 *)D->t_out[2].p,
                       (const uint32_t *)D->t_in.p, cnt[0], k, radius, nullptr, (float *)D->t_out[3].p, (float *)D->t_out[4].p, 1, nullptr, GATHER_BLOCKS,
-                      (uint16_t *)D->spill.p, (uint32_t *)D->t_in.p + 1);
+                      (uint16_t *)D->ws[0].spill.p, (uint32_t *)D->t_in.p + 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(D->stream));
     HIP_TRY(hipMemcpy(irr, D->t_out[3].p, (size_t)n * 12, hipMemcpyDeviceToHost));
@@ -1260,8 +1349,8 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
     if (n == 0) return RT_OK;
     const size_t limit = chunk_samples_limit();
     const size_t chunk = (size_t)std::min<int64_t>(n, (int64_t)limit);
-    if ((st = ensure_workspace(D, chunk, pv.bounce, 1))) return st;
-    const DevWork W = make_work(D);
+    if ((st = ensure_workspace(D, 0, chunk, pv.bounce, 1))) return st;
+    const DevWork W = make_work(D, 0);
     DevCamera dc; camera_setup(cam, dc);
     DevTiles dt; memset(&dt, 0, sizeof dt);
     HIP_TRY(hipMemsetAsync(W.stats, 0, ST_COUNT * 8, D->stream));
@@ -1270,7 +1359,7 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
         if ((st = D->t_in.upload(rays + 6 * off, (size_t)m * 24))) return st;
         HIP_TRY(hipMemsetAsync(W.sample_hit, 0, m, D->stream));
         HIP_TRY(hipMemsetAsync(W.sample_rgb, 0, (size_t)m * 12, D->stream));
-        if ((st = run_pipeline(D, D->stream, W, pv, nullptr, dc, dt, (uint32_t)off, m, 0, 1, 1, 2, (const float *)D->t_in.p))) return st;
+        if ((st = run_pipeline(D, 0, D->stream, W, pv, nullptr, dc, dt, (uint32_t)off, m, 0, 1, 1, 2, (const float *)D->t_in.p))) return st;
         HIP_TRY(hipStreamSynchronize(D->stream));
         HIP_TRY(hipMemcpy(hit + off, W.sample_hit, m, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(rgb + 3 * off, W.sample_rgb, (size_t)m * 12, hipMemcpyDeviceToHost));
