@@ -215,7 +215,11 @@ def main():
         my_rays = my["rays_primary"] + my["rays_shadow"] + my["rays_reflect"] + my["rays_refract"]
         t_bytes = my_rays * 48.0 + my["instance_visits"] * 84.0 + my["bvh_nodes_visited"] * 28.0 + my["tris_tested"] * 48.0
         t_gbs = t_bytes / (ms["ms_trace"] * 1e-3) / 1e9 if ms["ms_trace"] > 0 else 0.0
-        gather_dominant = ms["ms_gather"] >= ms["ms_trace"]
+        # Up to three chunks of a frame are in flight at once, so the per-stream event intervals of different
+        # kernels overlap in time and their sums no longer partition the frame; the roofline is quoted for the
+        # kernel class that moves the most algorithmic bytes (with RT_STREAMS=1, where intervals are exclusive,
+        # that is also the one taking the most time: profiles/r01d)
+        gather_dominant = g_bytes >= t_bytes
         default_workload = (a.workload, a.width, a.height, a.spp, a.photons, a.synthetic_photons, world) == ("cornell", 1920, 1080, 64, 1000000, False, 1)
         traffic, traffic_src = measured_traffic("k_gather", default_workload and gather_dominant)
         roof = {"bound": "hbm", "kernel": "k_gather" if gather_dominant else "k_primary+k_bounce",
