@@ -308,7 +308,10 @@ rt_status rt_photon_pass(rt_scene *s, int device, uint32_t max_photons, int phot
  * at any time: finished bands of rows are copied into them chunk by chunk while the job runs
  * (the reference's viewport shows renderImage.GetPixels() as it fills, viewport.cpp:367), and
  * rt_render_progress counts only pixels that have already arrived.  Pixels of tiles this call
- * does not own, and of chunks not reached before rt_render_stop, keep the caller's values. */
+ * does not own, and of chunks not reached before rt_render_stop, keep the caller's values.
+ * One render at a time per (scene, device): a second one started while the first still runs
+ * fails with RT_ERR_STATE (reported by rt_render_wait for jobs); different devices may render
+ * the same scene concurrently. */
 rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt_params *p,
                           const rt_tile_range *tiles, int device,
                           uint8_t *rgb8, float *z, uint8_t *count, rt_job **out);

@@ -143,6 +143,7 @@ struct DeviceState {
     DevScene scene{};
     Workspace ws[RT_STREAMS];
     DevBuf stats;
+    std::atomic<int> busy{0};           // a render is using the working sets of this device
     // scratch for the single-stage entry points
     DevBuf t_in, t_out[6];
     hipStream_t stream = nullptr;
@@ -1018,6 +1019,9 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
     if (!rgb8_dev || !z_dev || !count_dev) return fail(RT_ERR_ARG, "render: output buffers are required");
     DeviceState *D = nullptr;
     if ((st = prepare_device(s, device, &D))) return st;
+    // one render at a time per (scene, device): the working sets are not shared between concurrent calls
+    if (D->busy.exchange(1)) return fail(RT_ERR_STATE, "render: another render of this scene is running on device %d", device);
+    struct BusyGuard { std::atomic<int> &b; ~BusyGuard() { b.store(0); } } busy_guard{D->busy};
     hipStream_t stream = use_user_stream ? user_stream : D->stream;
 
     DevCamera dc;
