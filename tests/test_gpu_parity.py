@@ -642,6 +642,33 @@ def test_job_progress_stop_and_partial_image(cornell, monkeypatch):
     s.set_lights(s.export()["lights"])                        # unlocked again
 
 
+def test_async_device_renders_keep_stream_order(cornell, monkeypatch):
+    """rt_render_tiles_device without sync on a caller's stream: the library forks onto its own streams for
+    the chunks in flight and joins back, so work queued behind the call on that stream sees the finished
+    image, and two calls back to back (different tile sets, same buffers) do not disturb each other"""
+    import torch
+    monkeypatch.setenv("RT_CHUNK_SAMPLES", "16384")           # several chunks -> several streams
+    s, cam = scenes.load_cornell(160, 120)
+    s.set_photons(photons.synth_cornell_photon_map(20000, seed=3))
+    p = capi.default_params(min_sample=4, max_sample=4, threshold=-1.0)
+    ref, zref, _, _, _ = s.render(cam, p)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    rgb = torch.zeros((120, 160, 3), dtype=torch.uint8, device=dev)
+    z = torch.zeros((120, 160), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((120, 160), dtype=torch.uint8, device=dev)
+    with torch.cuda.stream(side):
+        for rank in range(2):                                 # two async calls, interleaved tile sets
+            s.render_tiles_device(cam, p, capi.TileRange(32, 8, rank, 2), 0, rgb.data_ptr(), z.data_ptr(), cnt.data_ptr(),
+                                  stream=side.cuda_stream, sync=False, want_stats=False)
+        zsum = (z != 0).sum()                                 # queued behind both renders on the same stream
+        rgb_copy = rgb.clone()
+    side.synchronize()
+    assert int(zsum) == 160 * 120
+    assert (z.cpu().numpy() == zref).all()
+    assert (np.abs(rgb_copy.cpu().numpy().astype(int) - ref.astype(int)) <= 1).all()
+
+
 def test_full_size_frame_properties():
     """BASELINE size (1920 x 1080) with 2 fixed samples: size-independent properties"""
     s, cam = scenes.load_cornell(1920, 1080)
