@@ -33,8 +33,11 @@
 #ifndef RT_GATHER_GUESS
 #define RT_GATHER_GUESS 1.3f   // photons expected inside the first trial radius, in units of k (1.2-1.6 measured flat)
 #endif
+#ifndef RT_GATHER_RING
+#define RT_GATHER_RING 160     // LDS entries for the photons around the predicted k-th distance (0: always re-read in pass 2)
+#endif
 #ifndef RT_GATHER_BATCH
-#define RT_GATHER_BATCH 32     // queries a wave lists per phase A (32 halves the LDS leaf lists: 5 waves/SIMD instead of 4)
+#define RT_GATHER_BATCH 16     // queries a wave lists per phase A (sized so that lists + ring keep 5 waves/SIMD)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1470,6 +1473,12 @@ struct GatherLds {
     float    sel_d[64];
     uint32_t sel_i[64];
     uint32_t sel_n;
+#if RT_GATHER_RING
+    // everything pass 1 read about a photon whose distance lies in the band around the predicted k-th one,
+    // so that the exact selection does not have to read the leaves a second time
+    float4   ring_a[RT_GATHER_RING];      // d2, dir.x, dir.y, dir.z
+    float2   ring_b[RT_GATHER_RING];      // max power, colour bytes
+#endif
 };
 
 // Color24 -> Color (cyColor.h): byte / 255.0f, correctly rounded, without the ~10-instruction IEEE
@@ -1568,6 +1577,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     unsigned long long visited = 0;
     uint32_t n_rounds = 0, n_slow = 0, n_reads = 0;       // wave-uniform tallies
+    float pred_rk2 = 0.0f;                                // k-th squared distance of this wave's previous query (a hint only)
 
     // 64-query batches are handed out dynamically (one atomic per batch): query cost varies by two
     // orders of magnitude with the local photon density, so a static split leaves a long tail
@@ -1656,25 +1666,52 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // pass 1: sums over ALL candidates
                 // sum of power (GetPower = Color24 -> Color times power) and of dir * maxPower for one photon
                 // (branch-free variant: take == false adds exact zeros; measured slower than the branch)
-                auto accumulate = [&](const float4 &pa, const float4 &pb, bool take) {
+                auto accumulate5 = [&](float dirx, float diry, float dirz, float maxp, uint32_t cbits, bool take) {
 #if RT_GATHER_BRANCHY
                     if (!take) return;
 #endif
-                    const uint32_t cbits = __float_as_uint(pb.w);
-                    const float mp = take ? pb.z : 0.0f;
+                    const float mp = take ? maxp : 0.0f;
                     s_pr += BYTE_OVER_255(cbits & 255u) * mp; s_pg += BYTE_OVER_255((cbits >> 8) & 255u) * mp; s_pb += BYTE_OVER_255((cbits >> 16) & 255u) * mp;
-                    s_dx += pa.w * mp; s_dy += pb.x * mp; s_dz += pb.y * mp;
+                    s_dx += dirx * mp; s_dy += diry * mp; s_dz += dirz * mp;
                 };
+                auto accumulate = [&](const float4 &pa, const float4 &pb, bool take) { accumulate5(pa.w, pb.x, pb.y, pb.z, __float_as_uint(pb.w), take); };
 
                 uint32_t M = 0;                            // accepted photons (wave-uniform: popcount of the ballots)
                 for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                 wave_sync();
-                // pass 1
+                // pass 1: count + histogram of every accepted photon.  Photons closer than t_lo (safely inside the
+                // k nearest if the prediction holds) are summed right away; those between t_lo and t_hi, the band
+                // the k-th distance is expected in, are parked in the LDS ring with all their data.
+#if RT_GATHER_RING
+                const float pk = (pred_rk2 > 0.0f && pred_rk2 < rq2) ? pred_rk2 : rq2 * (1.0f / RT_GATHER_GUESS);
+                const float t_lo = 0.85f * pk;
+                const float t_hi = final_round ? rq2 : fminf(1.18f * pk, rq2);
+                uint32_t n_ring = 0;                       // wave-uniform (ballot popcounts)
+                for_each([&](const Cand &cd, size_t) {
+                    const bool lo = cd.ok && cd.d2 < t_lo;
+                    const bool rg = cd.ok && !lo && cd.d2 < t_hi;
+                    M += (uint32_t)__popcll(__ballot(cd.ok));
+                    if (cd.ok) atomicAdd(&L.hist[cd.key >> 16], 1u);
+                    accumulate(cd.pa, cd.pb, lo);
+                    const unsigned long long mr = __ballot(rg);
+                    if (mr) {
+                        if (rg) {
+                            const uint32_t at = n_ring + (uint32_t)__popcll(mr & ((1ull << lane) - 1ull));
+                            if (at < (uint32_t)RT_GATHER_RING) {
+                                L.ring_a[at] = make_float4(cd.d2, cd.pa.w, cd.pb.x, cd.pb.y);
+                                L.ring_b[at] = make_float2(cd.pb.z, cd.pb.w);
+                            }
+                        }
+                        n_ring += (uint32_t)__popcll(mr);
+                    }
+                });
+#else
                 for_each([&](const Cand &cd, size_t) {
                     accumulate(cd.pa, cd.pb, cd.ok);
                     M += (uint32_t)__popcll(__ballot(cd.ok));
                     if (cd.ok) atomicAdd(&L.hist[cd.key >> 16], 1u);
                 });
+#endif
                 visited += n_iter;
                 if (!final_round && M <= K) {
                     // not enough inside the trial radius: grow it (count ~ r^2 on a surface) and retry
@@ -1721,14 +1758,50 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                             if (cd.ok && (cd.key & hi_mask) == prefix) atomicAdd(&L.hist[(cd.key >> shift) & 255u], 1u);
                         });
                     }
-                    n_reads += n_iter;
-                    // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
                     const uint32_t bin_mask = ~((1u << shift) - 1u) & 0xFFFFFFu;
-                    s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
                     if (lane == 0) L.sel_n = 0;
                     wave_sync();
                     uint32_t tie_taken = 0;                // only used when in_bin > 64 (identical keys)
                     float tmax = 0.0f;
+                    bool from_ring = false;
+#if RT_GATHER_RING
+                    {
+                        // The ring serves the selection when (1) it did not overflow, (2) the k-th photon's bin was
+                        // resolved at the first level, (3) every photon below t_lo lies in an earlier bin (so all of
+                        // them count) and (4) every photon of the k-th bin or earlier lies below t_hi (so it is either
+                        // summed already or in the ring).  Keys are monotone in d2, which makes (3) and (4) exact.
+                        const uint32_t bin_lo = (uint32_t)(t_lo * Q.kscale) >> 16, bin_hi = (uint32_t)(t_hi * Q.kscale) >> 16;
+                        const uint32_t kbin = prefix >> 16;
+                        from_ring = shift == 16 && in_bin <= 64u && n_ring <= (uint32_t)RT_GATHER_RING && bin_lo < kbin && (t_hi >= rq2 || kbin < bin_hi);
+                    }
+                    if (from_ring) {
+                        for (uint32_t base = 0; base < n_ring; base += 64u) {
+                            const uint32_t idx = base + (uint32_t)lane;
+                            const bool have = idx < n_ring;
+                            const float4 ra = have ? L.ring_a[idx] : make_float4(3.0e38f, 0, 0, 0);
+                            const float2 rb = have ? L.ring_b[idx] : make_float2(0, 0);
+                            const uint32_t kb = (uint32_t)(ra.x * Q.kscale) & bin_mask;
+                            const bool take = have && kb < prefix;
+                            const bool inb = have && kb == prefix;
+                            const unsigned long long mb = __ballot(inb);
+                            if (mb) {
+                                const uint32_t sbase = lane_u(L.sel_n, 0);
+                                if (inb) {
+                                    const uint32_t at = sbase + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                                    if (at < 64u) { L.sel_d[at] = ra.x; L.sel_i[at] = idx; }
+                                }
+                                wave_sync();
+                                if (lane == 0) L.sel_n = sbase + (uint32_t)__popcll(mb);
+                                wave_sync();
+                            }
+                            accumulate5(ra.y, ra.z, ra.w, rb.x, __float_as_uint(rb.y), take);
+                        }
+                    }
+#endif
+                    if (!from_ring) {
+                    n_reads += n_iter;
+                    // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
+                    s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
                     for_each([&](const Cand &cd, size_t s) {
                         const uint32_t kb = cd.key & bin_mask;
                         bool take = cd.ok && kb < prefix;
@@ -1753,6 +1826,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         }
                         accumulate(cd.pa, cd.pb, take);
                     });
+                    }
                     wave_sync();
                     if (in_bin <= 64u) {
                         // exact selection: rank by (d2, list position); take ranks < need
@@ -1765,13 +1839,41 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                             rank += (od < md || (od == md && j < (uint32_t)lane)) ? 1u : 0u;
                         }
                         if (mine && rank < need) {
-                            const size_t s = L.sel_i[lane];
-                            accumulate(G.pm.pa[s], G.pm.pb[s], true);
+                            const uint32_t si = L.sel_i[lane];
+#if RT_GATHER_RING
+                            if (from_ring) {
+                                const float4 ra = L.ring_a[si];
+                                const float2 rb = L.ring_b[si];
+                                accumulate5(ra.y, ra.z, ra.w, rb.x, __float_as_uint(rb.y), true);
+                            } else
+#endif
+                                accumulate(G.pm.pa[si], G.pm.pb[si], true);
                             tmax = md;
                         }
                     }
                     area_d2 = wave_max0(tmax);                        // np.dist2[0] = largest kept distance
+                    pred_rk2 = area_d2;
                 }
+#if RT_GATHER_RING
+                else if (M > 0) {
+                    // at most k inside the full radius: all of them count.  Pass 1 summed those below t_lo and, in the
+                    // final round, parked every other one in the ring; if that overflowed, sum them with one more pass
+                    if (n_ring <= (uint32_t)RT_GATHER_RING) {
+                        for (uint32_t base = 0; base < n_ring; base += 64u) {
+                            const uint32_t idx = base + (uint32_t)lane;
+                            if (idx < n_ring) {
+                                const float4 ra = L.ring_a[idx];
+                                const float2 rb = L.ring_b[idx];
+                                accumulate5(ra.y, ra.z, ra.w, rb.x, __float_as_uint(rb.y), true);
+                            }
+                        }
+                    } else {
+                        n_reads += n_iter;
+                        s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
+                        for_each([&](const Cand &cd, size_t) { accumulate(cd.pa, cd.pb, cd.ok); });
+                    }
+                }
+#endif
                 float irr_r = wave_sum(s_pr), irr_g = wave_sum(s_pg), irr_b = wave_sum(s_pb);
                 float dx = wave_sum(s_dx), dy = wave_sum(s_dy), dz = wave_sum(s_dz);
                 if (M > 0) {
