@@ -22,7 +22,7 @@
 #define LEAF_BIT 0x80000000u
 // k_gather tuning knobs (the defaults are the measured best on MI355X)
 #ifndef RT_GATHER_AHEAD
-#define RT_GATHER_AHEAD 1      // 1: the next leaf is fetched while the current one is processed (0: -27 % on MI355X)
+#define RT_GATHER_AHEAD 1      // 1: the next leaf is fetched while the current one is processed (0: 27 % slower on MI355X)
 #endif
 #ifndef RT_GATHER_BRANCHY
 #define RT_GATHER_BRANCHY 1    // 1: accepted lanes accumulate under a branch; 0: predicated, branch-free
