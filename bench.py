@@ -229,11 +229,11 @@ def main():
                 "algorithmic_bytes_per_launch": round(g_bytes / max(launches_g, 1)) if gather_dominant else None,
                 "avg_launch_ms": round(ms["ms_gather"] / max(launches_g, 1), 4) if gather_dominant else None,
                 "launches": int(launches_g) if gather_dominant else int(sum(x["launches_trace"] for x in stats)),
-                # frac > 1 is not an accounting slip: the formula prices every photon examined at the
-                # reference's 24 B against the HBM peak, but the 34 MB photon structure is served from
-                # L2 / Infinity Cache (`traffic` = the HBM bytes actually moved per launch) and the kernel
-                # is bound by VALU issue (profiles/r01c_bench_sq_counters.json: 94 % VALU busy)
-                "note": ("photon structure is L2/MALL resident: see traffic; kernel is VALU-issue bound" if gather_dominant else
+                # frac near or above 1 is not an accounting slip: the formula prices every photon examined at
+                # the reference's 24 B against the HBM peak, but the 34 MB photon structure is served from
+                # L2 / Infinity Cache (`traffic` = the HBM bytes actually moved per launch); the kernel is
+                # bound by the latency of the dependent chain inside a query
+                "note": ("photon structure is L2/MALL resident: see traffic; kernel is latency bound, not HBM bound" if gather_dominant else
                          "scene (BVH, triangles, transforms) is L2 resident; achieved = algorithmic bytes of traversal / kernel time"),
                 "other": {"k_gather_GBps": round(g_gbs, 2), "trace_shade_GBps": round(t_gbs, 2),
                           "ms_gather": round(ms["ms_gather"], 2), "ms_trace_shade": round(ms["ms_trace"], 2),
