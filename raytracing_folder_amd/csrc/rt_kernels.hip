@@ -1571,6 +1571,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
 #endif
     uint32_t nq = *G.count_ptr;
     if (nq > G.count_cap) nq = G.count_cap;
+    if (nq == 0) return;                                 // most chunks of a frame see no photon query at all
     const uint32_t n_leaves = G.pm.n_leaves;
     const float r2 = G.radius * G.radius;
     const uint32_t K = (uint32_t)G.k;
