@@ -164,6 +164,23 @@ def test_irradiance_on_the_reference_photon_dump(gold):
         assert tight.mean() > 0.9, (tag, rel)
         assert (rel[~tight] < 2.5 / k + 1e-4).all(), (tag, rel[~tight])
         assert (np.abs(d - ref[:, 3:]).max(axis=1)[tight] < 2e-5).all()
+    # volume: thousands of queries all over the map (and off it) against the oracle, several k and radii --
+    # exercises the trial-radius retries, the LDS ring, its fall-back to the second pass and the sparse case
+    rng = np.random.default_rng(77)
+    raw = bal[1:]
+    for k, radius, n in ((400, 1.0, 3000), (50, 0.4, 2000), (400, 6.0, 600), (1000, 2.5, 600)):
+        qi = rng.integers(0, len(raw), n)
+        pos = raw["position"][qi] + rng.normal(0, radius * 0.3, (n, 3)).astype(np.float32)
+        nrm = rng.normal(size=(n, 3)).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        irr, d = s.estimate_irradiance(k, radius, pos, nrm)
+        oirr, od = orc.estimate_irradiance(bal, k, radius, pos, nrm)
+        scale = np.abs(oirr).max(axis=1, keepdims=True) + 1e-30
+        rel = (np.abs(irr - oirr) / scale).max(axis=1)
+        lit = oirr.max(axis=1) > 0
+        assert lit.mean() > 0.5 and ((oirr.max(axis=1) > 0) == (irr.max(axis=1) > 0)).all(), (k, radius)
+        assert (rel < 2.5 / k + 2e-5).all(), (k, radius, rel.max())
+        assert (rel < 2e-5).mean() > 0.9, (k, radius)
 
 
 def test_irradiance_single_photon_colour_bytes():
