@@ -89,10 +89,15 @@ bool Renderer::BeginRender()
         st = rt_scene_set_mesh(handle, (int32_t)m, md.v.data(), (int32_t)(md.v.size() / 3), md.f.data(), (int32_t)(md.f.size() / 3),
                                md.vn.data(), (int32_t)(md.vn.size() / 3), md.fn.data(), md.nodes.data(), (int32_t)md.nodes.size(),
                                md.elements.data());
+        if (st == RT_OK && !md.vt.empty())
+            st = rt_scene_set_mesh_texcoords(handle, (int32_t)m, md.vt.data(), (int32_t)(md.vt.size() / 3), md.ft.data());
     }
     if (st == RT_OK) st = rt_scene_set_materials(handle, d.materials.data(), (int32_t)d.materials.size());
     if (st == RT_OK) st = rt_scene_set_lights(handle, d.lights.data(), (int32_t)d.lights.size());
     if (st == RT_OK) st = rt_scene_set_environment(handle, d.env, d.bg);
+    if (st == RT_OK) st = rt_scene_set_textures(handle, d.textures.data(), (int32_t)d.textures.size(), d.texels.data(), (uint64_t)d.texels.size());
+    if (st == RT_OK) st = rt_scene_set_material_maps(handle, d.material_maps.data(), d.material_maps.empty() ? 0 : (int32_t)d.materials.size());
+    if (st == RT_OK) st = rt_scene_set_environment_maps(handle, &d.env_map, &d.bg_map);
     if (st != RT_OK) { error = rt_last_error(); return false; }
     if (renderImage.GetWidth() != d.camera.width || renderImage.GetHeight() != d.camera.height)
         renderImage.Init(d.camera.width, d.camera.height);

@@ -70,3 +70,15 @@ def rebuild(export, materials=None, lights=None):
     s.set_materials(export["materials"] if materials is None else materials)
     s.set_lights(export["lights"] if lights is None else lights)
     return s
+
+
+def build_shim_driver(tmp_path):
+    """g++ build of tests/shim_driver.cpp (the reference's BeginRender / StopRender / saveImage contract in
+    C++, on top of the product library); returns the executable's path"""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "shim_driver")
+    lib = os.path.join(ROOT, "raytracing_folder_amd", "lib")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "shim_driver.cpp"), "-L" + lib, "-lrt_mi355x", "-Wl,-rpath," + lib, "-lpthread"],
+                   check=True, capture_output=True)
+    return exe

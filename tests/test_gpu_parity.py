@@ -4,6 +4,7 @@ seeded inputs (and against the reference's own outputs where golden vectors exis
 Bars: closest-hit records (hit flag, node, front, z, p, N) bit-exact; photon irradiance within
 2e-5 relative (summation order), except the reference's heap quirk (see test); linear colours
 within 2e-5 relative + 1e-6 absolute; RGB8 frames: >= 99.5 % of pixels within 1 level, z exact."""
+import os
 import numpy as np
 import pytest
 
@@ -684,6 +685,40 @@ def test_async_device_renders_keep_stream_order(cornell, monkeypatch):
     assert int(zsum) == 160 * 120
     assert (z.cpu().numpy() == zref).all()
     assert (np.abs(rgb_copy.cpu().numpy().astype(int) - ref.astype(int)) <= 1).all()
+
+
+def test_cpp_beginrender_shim_end_to_end(tmp_path):
+    """tests/shim_driver.cpp drives rt::Renderer like the reference's viewport: BeginRender returns at once,
+    IsRenderDone is polled while the image fills, saveImage writes the three PNGs -- which must hold what a
+    render through the C ABI gives (textured scene: the shim lowers textures, maps and texture vertices too)"""
+    import subprocess
+    exe = scenes.build_shim_driver(tmp_path)
+    xml = os.path.join(scenes.GOLD, "cornell_textured.xml")
+    out = [str(tmp_path / n) for n in ("image.png", "samples.png", "z.png")]
+    r = subprocess.run([exe, xml] + out, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    info = dict(zip(r.stdout.split()[0::2], r.stdout.split()[1::2]))
+    assert float(info["begin_ms"]) < 2000 and int(info["pixels"]) == 160 * 120 and int(info["rays"]) > 160 * 120
+    s = capi.Scene()
+    s.load_xml(xml)
+    cam = s.camera()
+    rgb, z, cnt, _, _ = s.render(cam, capi.default_params())
+    img = capi.image_read_rgb(out[0])
+    assert img.shape == rgb.shape and (np.abs(img.astype(int) - rgb.astype(int)) <= 1).mean() > 0.999
+    # ComputeZBufferImage / ComputeSampleCountImage (scene.h:591-637) on the same buffers
+    hit = z != np.float32(1e30)
+    zmin, zmax = z[hit].min(), z[hit].max()
+    zi = np.where(hit, np.clip(((zmax - np.where(hit, z, zmax)) / (zmax - zmin) * 255).astype(np.int64), 0, 255), 0)
+    zpng = capi.image_read_rgb(out[2])[..., 0]
+    assert (np.abs(zpng.astype(int) - zi) <= 1).mean() > 0.999
+    spng = capi.image_read_rgb(out[1])[..., 0]
+    smin, smax = int(cnt.min()), int(cnt.max())
+    assert smax > smin and (np.abs(spng.astype(int) - (255 * (cnt.astype(int) - smin)) // (smax - smin)) <= 1).mean() > 0.995
+    # StopRender after the first progress: fewer pixels, no error
+    r = subprocess.run([exe, xml] + out + ["stop"], capture_output=True, text=True, env=dict(os.environ, RT_CHUNK_SAMPLES="4096"))
+    assert r.returncode == 0, r.stderr
+    info = dict(zip(r.stdout.split()[0::2], r.stdout.split()[1::2]))
+    assert 0 < int(info["pixels"]) <= 160 * 120
 
 
 def test_full_size_frame_properties():

@@ -180,6 +180,21 @@ def test_render_fails_loudly_without_a_gpu():
         s.trace_rays(np.zeros((1, 6), np.float32))
 
 
+def test_cpp_driver_of_the_beginrender_shim_fails_loudly_without_a_gpu(tmp_path):
+    """the reference-side contract in C++ (rt::Renderer: LoadScene / BeginRender / IsRenderDone / saveImage)
+    links against the product library with plain g++; without a device BeginRender reports the error"""
+    import subprocess
+    exe = scenes.build_shim_driver(tmp_path)
+    r = subprocess.run([exe, os.path.join(scenes.GOLD, "cornell_textured.xml"), str(tmp_path / "a.png"), str(tmp_path / "b.png"),
+                        str(tmp_path / "c.png")], capture_output=True, text=True)
+    if capi.device_count() == 0:
+        assert r.returncode == 4 and "no CPU path" in r.stderr and not (tmp_path / "a.png").exists()
+    else:
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, str(tmp_path / "missing.xml"), "a", "b", "c"], capture_output=True, text=True)
+    assert r.returncode == 3 and "LoadScene failed" in r.stderr
+
+
 def test_synthetic_photon_map_is_well_formed():
     bal = photons.synth_cornell_photon_map(5000, seed=3)
     assert len(bal) == 5001
