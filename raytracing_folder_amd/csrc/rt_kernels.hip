@@ -1945,13 +1945,27 @@ __device__ __forceinline__ uint8_t float_to_byte(float r)
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+#define RT_RESOLVE_TILE 8            // samples per pixel staged through LDS at a time
 __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
 {
+    // A pixel's samples are contiguous (max_sample slots of 12 B), so a thread walking its own pixel reads 12 B
+    // at a 768-B stride from its neighbours: measured 6.6x the useful bytes from HBM.  In phase 0 the 64 pixels of
+    // a wave are consecutive, so the wave stages RT_RESOLVE_TILE samples of each of them through LDS with
+    // coalesced reads (one 96-B run per pixel) and every lane then reads its own pixel's samples from LDS
+    // (row stride 25 words: conflict-free).  The sums are taken in sample order, as before.
+    __shared__ float s_tile[4][64 * (3 * RT_RESOLVE_TILE + 1)];
+    float *tile = s_tile[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
     const uint32_t npix = A.phase == 1 ? W.counts[CNT_PIXLIST] : A.npix;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-        const uint32_t ql = A.phase == 1 ? W.pixel_list[i] : i;
-        int x, y;
-        if (!pixel_of(A.tiles, A.cam, A.q0 + ql, x, y)) continue;
+    const uint32_t npix_round = (npix + 63u) & ~63u;            // whole waves take part in the staging
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix_round; i += gridDim.x * blockDim.x) {
+        const uint32_t i0 = i - (uint32_t)lane;                  // first pixel of this wave
+        const bool staged = A.phase == 0 && i0 + 64u <= npix;    // wave-uniform
+        const bool in_range = i < npix;
+        const uint32_t ql = in_range ? (A.phase == 1 ? W.pixel_list[i] : i) : 0u;
+        int x = 0, y = 0;
+        const bool valid = in_range && pixel_of(A.tiles, A.cam, A.q0 + ql, x, y);
+        if (!staged && !valid) continue;
         const size_t index = (size_t)y * A.cam.width + x;
         const float *rgb = W.sample_rgb + 3 * (size_t)ql * A.max_sample;
         const uint8_t *hitf = W.sample_hit + (size_t)ql * A.max_sample;
@@ -1959,30 +1973,57 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
         const int ns = A.phase == 1 ? A.max_sample : A.min_sample;
         int n = 0;
         float hitz = 0;
-        for (int j = 0; j < ns; j++) if (hitf[j]) { n++; hitz = zs[j]; }
-        if (A.phase == 0 && n > 0 && A.min_sample != A.max_sample) {
-            // VariantOverThreshold over the hit colours of the first batch
-            const float ninverse = (float)(1.0 / n);
-            float sum[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
-            for (int j = 0; j < ns; j++) if (hitf[j])
-                for (int c = 0; c < 3; c++) {
-                    const float t = rgb[3 * j + c];
-                    sum[c] += t;
-                    sq[c] = (float)((double)sq[c] + (double)t * (double)t);       // pow(float,int) -> double
+        { int last = -1; for (int j = 0; j < ns; j++) if (hitf[j]) { n++; last = j; } if (last >= 0) hitz = zs[last]; }
+        // visit(j, r, g, b) for the hit samples in order, from LDS tiles (staged) or straight from memory
+        auto for_hit_samples = [&](auto &&visit) {
+            if (staged) {
+                const float *wave_rgb = W.sample_rgb + 3 * (size_t)i0 * A.max_sample;
+                for (int t0 = 0; t0 < ns; t0 += RT_RESOLVE_TILE) {
+                    const int tn = min(RT_RESOLVE_TILE, ns - t0);              // samples in this tile
+                    const int run = 3 * tn;                                     // floats per pixel
+                    __builtin_amdgcn_wave_barrier();
+                    for (int k = lane; k < 64 * run; k += 64) {
+                        const int pix = k / run, off = k - pix * run;
+                        tile[pix * (3 * RT_RESOLVE_TILE + 1) + off] = wave_rgb[(size_t)pix * 3 * A.max_sample + 3 * t0 + off];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const float *mine = tile + lane * (3 * RT_RESOLVE_TILE + 1);
+                    for (int j = 0; j < tn; j++) if (hitf[t0 + j]) visit(mine[3 * j], mine[3 * j + 1], mine[3 * j + 2]);
                 }
-            bool over = false;
+            } else {
+                for (int j = 0; j < ns; j++) if (hitf[j]) visit(rgb[3 * j], rgb[3 * j + 1], rgb[3 * j + 2]);
+            }
+        };
+        bool over = false;
+        if (A.phase == 0 && A.min_sample != A.max_sample && (staged || n > 0)) {
+            // VariantOverThreshold over the hit colours of the first batch
+            const float ninverse = (float)(1.0 / (n > 0 ? n : 1));
+            float sum[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
+            for_hit_samples([&](float r, float g, float b) {
+                const float t3[3] = {r, g, b};
+                for (int c = 0; c < 3; c++) {
+                    sum[c] += t3[c];
+                    sq[c] = (float)((double)sq[c] + (double)t3[c] * (double)t3[c]);       // pow(float,int) -> double
+                }
+            });
             for (int c = 0; c < 3; c++) {
                 const float avg = ninverse * sum[c];
                 const float var = (float)((double)(sq[c] * ninverse) + (double)avg * (double)avg - (double)(2 * avg * ninverse * sum[c]));
                 if (var > A.threshold) over = true;
             }
-            if (over) { W.pixel_list[atomicAdd(&W.counts[CNT_PIXLIST], 1u)] = ql; continue; }
+            over = over && n > 0 && valid;
+            if (over) W.pixel_list[atomicAdd(&W.counts[CNT_PIXLIST], 1u)] = ql;
         }
+        float c0 = 0, c1 = 0, c2 = 0;
+        if (staged || n > 0) {
+            const float inv = 1 / (float)(n > 0 ? n : 1);
+            for_hit_samples([&](float r, float g, float b) { c0 += r * inv; c1 += g * inv; c2 += b * inv; });
+        }
+        if (!valid || over) continue;
         float g[3];
         if (n > 0) {
-            const float inv = 1 / (float)n;
-            float c0 = 0, c1 = 0, c2 = 0;
-            for (int j = 0; j < ns; j++) if (hitf[j]) { c0 += rgb[3 * j] * inv; c1 += rgb[3 * j + 1] * inv; c2 += rgb[3 * j + 2] * inv; }
             g[0] = powf(c0, A.inv_gamma); g[1] = powf(c1, A.inv_gamma); g[2] = powf(c2, A.inv_gamma);
             A.count[index] = (n <= A.min_sample) ? 0 : 255;
             A.z[index] = hitz;

@@ -746,3 +746,9 @@ def test_full_size_frame_properties():
         for a, b in zip(ty[mine], tx[mine]):
             cover[a * 8:(a + 1) * 8, b * 32:(b + 1) * 32] += 1
     assert (cover == 1).all()
+    # four times the pixels (3840 x 2160, one sample): every pixel is written once, the quarter-resolution
+    # image is what the full-resolution one shows at the pixels whose first-sample rays coincide
+    s4, cam4 = scenes.load_cornell(3840, 2160)
+    p1 = capi.default_params(min_sample=1, max_sample=1, threshold=-1.0)
+    rgb4, z4, _, st4, prog4 = s4.render(cam4, p1)
+    assert prog4 == 3840 * 2160 and st4.rays_primary == 3840 * 2160 and (z4 != 0).all() and (z4 < 1e29).mean() > 0.99
