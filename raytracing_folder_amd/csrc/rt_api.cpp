@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -196,6 +197,9 @@ extern "C" rt_status rt_scene_create(rt_scene **out)
 extern "C" void rt_scene_destroy(rt_scene *s)
 {
     if (!s) return;
+    // a job that is still rendering this scene holds a pointer to it: wait for it (jobs always terminate;
+    // destroying the job first, or rt_render_stop, makes this immediate)
+    while (s->live_jobs.load() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     for (DeviceState *d : s->devs) {
         if (hipSetDevice(d->device) == hipSuccess) d->release();
         delete d;
