@@ -1170,13 +1170,19 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
         in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0;
         in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
         if (active) {
-            const float4 a = qin.a[gid], b = qin.b[gid], c = qin.c[gid];
-            const uint4 dd = qin.d[gid];
+#ifdef RT_BOUNCE_SCRAMBLE          /* experiment: destroy the queue's coherence inside 64 Ki-ray windows */
+            uint32_t src = gid;
+            if ((gid | 65535u) < total) src = (gid & ~65535u) | ((gid * 40503u) & 65535u);
+#else
+            const uint32_t src = gid;
+#endif
+            const float4 a = qin.a[src], b = qin.b[src], c = qin.c[src];
+            const uint4 dd = qin.d[src];
             in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
             in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
             in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.node = dd.z; in.sample = dd.w;
             if (MODEL == RT_SHADE_P6 && in.kind == KIND_REFRACT) {
-                const float4 e = qin.e[gid];
+                const float4 e = qin.e[src];
                 in.side_dir = mk(e.x, e.y, e.z); in.side_K = mk(e.w, c.z, c.w);
                 in.absorb = mk(c.y, 0, 0);
             }
