@@ -123,6 +123,9 @@ def measured_traffic(kernel, default_workload):
 
 def main():
     a = parse()
+    if not os.path.exists(os.path.join(ROOT, "raytracing_folder_amd", "lib", "librt_mi355x.so")) and int(os.environ.get("RANK", "0")) == 0:
+        import __graft_entry__                    # fresh checkout: built artefacts are git-ignored
+        __graft_entry__.build()
     import torch
     import torch.distributed as dist
     from raytracing_folder_amd import capi, photons
