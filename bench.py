@@ -123,9 +123,17 @@ def measured_traffic(kernel, default_workload):
 
 def main():
     a = parse()
-    if not os.path.exists(os.path.join(ROOT, "raytracing_folder_amd", "lib", "librt_mi355x.so")) and int(os.environ.get("RANK", "0")) == 0:
-        import __graft_entry__                    # fresh checkout: built artefacts are git-ignored
-        __graft_entry__.build()
+    lib_path = os.path.join(ROOT, "raytracing_folder_amd", "lib", "librt_mi355x.so")
+    if not os.path.exists(lib_path):              # fresh checkout: built artefacts are git-ignored
+        if int(os.environ.get("RANK", "0")) == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            for _ in range(600):                  # rank 0 is building
+                if os.path.exists(lib_path):
+                    break
+                time.sleep(1.0)
+            time.sleep(2.0)
     import torch
     import torch.distributed as dist
     from raytracing_folder_amd import capi, photons
