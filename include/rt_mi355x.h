@@ -269,6 +269,12 @@ rt_status rt_scene_get_mesh_texcoords(const rt_scene *s, int32_t mesh, int32_t *
  * rt_image_read_rgb with rgb == NULL only reports the size. comps: 1 = grey, 3 = RGB. */
 rt_status rt_image_read_rgb(const char *path, int32_t *w, int32_t *h, uint8_t *rgb, uint64_t cap);
 rt_status rt_image_write_png(const char *path, const uint8_t *data, int32_t w, int32_t h, int32_t comps);
+/* The two derived images of RenderImage (FIN/include/scene.h:591-613 ComputeZBufferImage: 255*(zmax-z)/
+ * (zmax-zmin) truncated, BIGFLOAT pixels 0 and ignored by the extrema; :615-637 ComputeSampleCountImage:
+ * integer 255*(c-smin)/(smax-smin), all zero when smax == smin).  Bit-exact integer maps; *smax (may be
+ * NULL) receives ComputeSampleCountImage's return value.  Host code, no GPU involved. */
+rt_status rt_image_zbuffer(const float *zbuffer, int32_t w, int32_t h, uint8_t *zbuffer_img);
+rt_status rt_image_sample_count(const uint8_t *sample_count, int32_t w, int32_t h, uint8_t *sample_count_img, int32_t *smax);
 
 /* ---- host helpers that mirror reference host code --------------------------------------- */
 /* cyBVH build with MeanSplit (FIN/include/cyBVH.h:122-142,295-328) as TriObj::Load calls it

@@ -398,6 +398,119 @@ def gen_texture():
     print("texture: 52x37 PNG,", n, "samples")
 
 
+def gen_zimage():
+    """RenderImage::ComputeZBufferImage / ComputeSampleCountImage (scene.h:591-637) on seeded buffers."""
+    rng = np.random.default_rng(401)
+    res = {}
+    for tag, (w, h) in (("a", (53, 31)), ("b", (16, 9)), ("c", (40, 25))):
+        z = rng.uniform(5.0, 90.0, (h, w)).astype(np.float32)
+        z[rng.random((h, w)) < 0.2] = np.float32(1.0e30)            # BIGFLOAT = missed pixels
+        cnt = np.where(rng.random((h, w)) < 0.3, 255, 0).astype(np.uint8)
+        if tag == "b":
+            cnt[:] = 255                                             # smax == smin -> all zeros
+        if tag == "c":
+            cnt = rng.integers(0, 256, (h, w)).astype(np.uint8)      # the general formula
+            z[0, 0] = np.float32(1.0e30); z[1, 1] = np.float32(5.0); z[2, 2] = np.float32(90.0)
+        out = run("fin", "zimg", struct.pack("<2i", w, h) + z.tobytes() + cnt.tobytes())
+        n = w * h
+        res.update({f"z_{tag}": z, f"cnt_{tag}": cnt, f"zimg_{tag}": np.frombuffer(out, "u1", n, 0).reshape(h, w),
+                    f"scimg_{tag}": np.frombuffer(out, "u1", n, n).reshape(h, w),
+                    f"smax_{tag}": struct.unpack_from("<i", out, 2 * n)[0]})
+        out13 = run("p13", "zimg", struct.pack("<2i", w, h) + z.tobytes() + cnt.tobytes())
+        assert out13 == out                                          # both snapshots carry the same code
+    np.savez_compressed(os.path.join(GOLD, "zimage.npz"), **res)
+    print("zimage: 3 cases")
+
+
+ILLUM_IN = np.dtype([("intensity", "<f4", 3), ("position", "<f4", 3), ("size", "<f4"), ("p", "<f4", 3),
+                     ("seed", "<u4"), ("nscript", "<i4"), ("script", "<f4", 8)])
+ILLUM_OUT = np.dtype([("result", "<f4", 3), ("ncalls", "<i4"), ("log", "<f4", (20, 7)), ("rand", "<i4", 64)])
+
+
+def gen_illum():
+    """PointLight::Illuminate of both snapshots (FIN/include/lights.h:67-131, P13/include/lights.h:65-91)
+    with the harness's recording Shadow double and a captured rand() stream."""
+    rng = np.random.default_rng(402)
+    n = 384
+    a = np.zeros(n, ILLUM_IN)
+    a["intensity"] = rng.uniform(0.2, 120.0, (n, 3))
+    a["position"] = rng.uniform(-10, 10, (n, 3)) + np.array([0, 0, 20])
+    a["size"] = rng.choice([0.0, 0.5, 2.0, 5.0], n)
+    a["p"] = rng.uniform(-15, 15, (n, 3))
+    a["p"][:32, 0] = a["position"][:32, 0] - rng.uniform(1, 30, 32)       # dir.x > 0.8: the other basis branch
+    a["seed"] = rng.integers(1, 2 ** 31, n)
+    kinds = rng.integers(0, 4, n)
+    for i in range(n):
+        if kinds[i] == 0: sc = [1.0]                                        # fully lit: no escalation
+        elif kinds[i] == 1: sc = [0.0]                                      # fully shadowed
+        elif kinds[i] == 2: sc = list(rng.integers(0, 2, 8).astype(float))  # mixed -> FIN escalates to 16
+        else: sc = [1.0, 1.0, 1.0, 0.0, 1.0, 0.0, 0.0, 1.0]
+        a["nscript"][i] = len(sc)
+        a["script"][i, :len(sc)] = sc
+    res = {"cases": a}
+    for model in ("fin", "p13"):
+        out = np.frombuffer(run(model, "illum", struct.pack("<i", n) + a.tobytes()), ILLUM_OUT)
+        assert len(out) == n
+        res[f"out_{model}"] = out
+        print(f"illum[{model}]: shadow calls per case: {sorted(set(out['ncalls'].tolist()))}")
+    np.savez_compressed(os.path.join(GOLD, "illum.npz"), **res)
+
+
+PB_IN = np.dtype([("diffuse", "<f4", 3), ("specular", "<f4", 3), ("reflection", "<f4", 3), ("refraction", "<f4", 3),
+                  ("absorption", "<f4", 3), ("glossiness", "<f4"), ("ior", "<f4"), ("ray", "<f4", 6),
+                  ("hit_p", "<f4", 3), ("hit_N", "<f4", 3), ("hit_z", "<f4"), ("front", "<i4"), ("c", "<f4", 3),
+                  ("seed", "<u4")])
+PB_OUT = np.dtype([("ret", "<i4"), ("ray", "<f4", 6), ("c", "<f4", 3), ("rand", "<i4", 8)])
+
+
+def gen_pbounce():
+    """MtlBlinn::RandomPhotonBounce, Attenuation, createCoordinateSystem (FIN/include/materials.h:50-256)."""
+    rng = np.random.default_rng(403)
+    n = 4096
+    a = np.zeros(n, PB_IN)
+    kind = rng.integers(0, 5, n)
+    a["diffuse"] = rng.uniform(0.05, 0.9, (n, 3)); a["specular"] = rng.uniform(0, 0.8, (n, 3))
+    a["glossiness"] = rng.choice([1.0, 20.0, 50.0], n); a["ior"] = 1.0
+    mirror, glass, tinted, black = kind == 1, kind == 2, kind == 3, kind == 4
+    a["diffuse"][mirror | glass] = 0; a["specular"][mirror | glass] = 0.8
+    a["reflection"][mirror] = 0.8
+    a["refraction"][glass | tinted] = rng.uniform(0.5, 0.9, ((glass | tinted).sum(), 3))
+    a["ior"][glass | tinted] = rng.choice([1.52, 1.33, 2.4], (glass | tinted).sum())
+    a["absorption"][tinted] = rng.uniform(0.0, 0.3, (tinted.sum(), 3))
+    a["reflection"][tinted] = rng.uniform(0, 0.3, (tinted.sum(), 3))
+    a["diffuse"][black] = 0; a["absorption"][black] = 0.2                     # nothing but absorption
+    N = rng.normal(size=(n, 3)); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a["front"] = (rng.random(n) < 0.7).astype(np.int32)
+    facing = (d * N).sum(1) < 0                                                  # front hits: the ray runs against N
+    flip = facing != (a["front"] == 1)
+    d[flip] *= -1
+    a["ray"][:, :3] = rng.uniform(-10, 10, (n, 3)); a["ray"][:, 3:] = d
+    a["hit_p"] = rng.uniform(-10, 10, (n, 3)); a["hit_N"] = N
+    a["hit_z"] = rng.uniform(0.1, 40, n)
+    a["c"] = rng.uniform(0.1, 100, (n, 3))
+    a["seed"] = rng.integers(1, 2 ** 31, n)
+    out = run("fin", "pbounce", struct.pack("<i", n) + a.tobytes())
+    recs = np.frombuffer(out, PB_OUT, n, 0)
+    off = n * PB_OUT.itemsize
+    att = np.frombuffer(out, "<f4", 3 * n, off).reshape(n, 3); off += att.nbytes
+    cs = np.frombuffer(out, "<f4", 6 * n, off).reshape(n, 6)
+    np.savez_compressed(os.path.join(GOLD, "pbounce.npz"), cases=a, out=recs, attenuation=att, coord=cs)
+    print(f"pbounce: {int(recs['ret'].sum())}/{n} bounced")
+
+
+def gen_refimages():
+    """Images the reference itself holds, copied as DATA fixtures (reference-held outputs, not source):
+    RayTracingProj13/prj13_boxzbuff.png -- the z image (RenderImage::SaveZImage) of the P13 Cornell scene,
+    RayTracingProj5/RayTracingProj5/prj5_zbuff.png -- the z image of the scene RayTracingProj6/scene.xml describes."""
+    import shutil
+    for src, dst in ((("RayTracingProj13", "prj13_boxzbuff.png"), "ref_prj13_boxzbuff.png"),
+                     (("RayTracingProj5", "RayTracingProj5", "prj5_zbuff.png"), "ref_prj5_zbuff.png")):
+        shutil.copyfile(os.path.join(REF, *src), os.path.join(GOLD, dst))
+        os.chmod(os.path.join(GOLD, dst), 0o644)
+    print("reference-held z images copied")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     for m in ("fin", "p13"):
@@ -416,6 +529,10 @@ def main():
     gen_photon("k50", 3001, 50, 1.5, 256, 107)
     gen_photon("k8", 64, 8, 4.0, 64, 108)
     gen_photon_dat()
+    gen_zimage()
+    gen_illum()
+    gen_pbounce()
+    gen_refimages()
     print("fixtures written to", GOLD)
 
 

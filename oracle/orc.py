@@ -351,3 +351,63 @@ def counters():
     c = Counters()
     lib().orc_counters_get(C.byref(c))
     return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+
+# ---- scripted randomness / Shadow (test hooks of rt_oracle.c) and the small image helpers -------------
+def illuminate_scripted(model, intensity, position, size, p, raw_rand, script, shadow_samples=4):
+    """PointLight::Illuminate with the raw rand() values and the Shadow return values of a reference run.
+    Returns (result[3], shadow-call log (n,7) = ray.p, ray.dir, t_max, rand values used)."""
+    light = np.zeros(1, LIGHT)
+    light["type"], light["intensity"], light["position"], light["size"] = 2, intensity, position, size
+    scene = Scene(np.zeros(0, NODE), lights=light)
+    params = default_params(shade_model=int(model), shadow_samples=int(shadow_samples))
+    raw = _c(raw_rand, np.int32)
+    sc = _c(script, np.float32)
+    log = np.zeros((32, 7), np.float32)
+    out = np.zeros(3, np.float32)
+    pp, nn = _c(p, np.float32), np.array([0, 0, 1], np.float32)
+    lib().orc_script_begin(_p(raw), len(raw), _p(sc), len(sc), _p(log), len(log))
+    lib().orc_illuminate(C.byref(scene.c), C.byref(params), _p(scene.lights), _p(pp), _p(nn), _p(out))
+    used = C.c_int()
+    n = lib().orc_script_end(C.byref(used))
+    return out, log[:n], used.value
+
+
+def random_photon_bounce_scripted(material, ray, hit_p, hit_N, hit_z, front, c, raw_rand):
+    m = _c(material, BLINN).reshape(1)
+    h = np.zeros(1, HIT)
+    h["p"], h["N"], h["z"], h["front"] = hit_p, hit_N, hit_z, front
+    r = _c(ray, np.float32).copy()
+    cc = _c(c, np.float32).copy()
+    raw = _c(raw_rand, np.int32)
+    lib().orc_script_begin(_p(raw), len(raw), None, 0, None, 0)
+    ret = lib().orc_random_photon_bounce(_p(m), _p(h), _p(r), _p(cc))
+    used = C.c_int()
+    lib().orc_script_end(C.byref(used))
+    return ret, r, cc, used.value
+
+
+def attenuation(absorption, l):
+    out = np.zeros(3, np.float32)
+    lib().orc_attenuation(_p(_c(absorption, np.float32)), C.c_float(l), _p(out))
+    return out
+
+
+def coordinate_system(N):
+    nt, nb = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().orc_coordinate_system(_p(_c(N, np.float32)), _p(nt), _p(nb))
+    return nt, nb
+
+
+def zbuffer_image(z):
+    z = _c(z, np.float32)
+    out = np.zeros(z.shape, np.uint8)
+    lib().orc_zbuffer_image(_p(z), z.shape[1], z.shape[0], _p(out))
+    return out
+
+
+def sample_count_image(cnt):
+    cnt = _c(cnt, np.uint8)
+    out = np.zeros(cnt.shape, np.uint8)
+    smax = lib().orc_sample_count_image(_p(cnt), cnt.shape[1], cnt.shape[0], _p(out))
+    return out, smax

@@ -4,11 +4,23 @@
 // /root/reference (nothing is copied) -- to produce golden vectors that pin oracle/rt_oracle.c.
 // Built by oracle/Makefile into oracle/_ref/ (git-ignored).  Runs only in the build container.
 //
-// What can be built: scene.h, scene.cpp (Box::IntersectRay), objects.h (Sphere, Plane, TriObj +
-// cyTriMesh OBJ loader + cyBVH), cyPhotonMap.h, cyColor.h/cyPoint.h/cyMatrix.h.
+// What can be built: scene.h (incl. RenderImage::ComputeZBufferImage/ComputeSampleCountImage),
+// scene.cpp (Box::IntersectRay), objects.h (Sphere, Plane, TriObj + cyTriMesh OBJ loader + cyBVH),
+// cyPhotonMap.h, cyColor.h/cyPoint.h/cyMatrix.h, lights.h (the inline PointLight::Illuminate of
+// either snapshot) and materials.h (the inline MtlBlinn::RandomPhotonBounce, Attenuation,
+// createCoordinateSystem of RayTracingFinal).
 // What cannot: main.cpp (TraceNode, Shade, RenderPixel, GenLight::Shadow) -- it textually
 // includes viewport.cpp, which needs <GL/glut.h>, absent from this image.  No stand-in header is
 // written for it; those functions stay "parity unpinned" (DESIGN.md).
+//
+// GenLight::Shadow is only DECLARED by lights.h (its body, FIN/main.cpp:499-513, is in the
+// unbuildable translation unit).  PointLight::Illuminate calls it once per shadow sample, so to
+// exercise Illuminate this file defines GenLight::Shadow as a RECORDING TEST DOUBLE: it logs the
+// ray it is handed and returns the next value of a script supplied by the caller.  What the
+// `illum` vectors pin is therefore Illuminate's own arithmetic (sample placement, rand()
+// consumption, the 4 -> 16 escalation rule, the fall-off) -- NOT Shadow, which stays unpinned.
+// libc rand() is made reproducible the plain way: srand(seed), draw and store the raw values,
+// srand(seed) again, call the reference; the stored values are what the oracle is fed.
 //
 // The three Object subclasses declare a GLUT-drawing virtual (ViewportDisplay) that only
 // viewport.cpp defines, so their vtables are never emitted.  The harness is therefore linked as
@@ -32,6 +44,8 @@
 #include "objects.h"
 #include "cyPhotonMap.h"
 #include "texture.h"
+#include "lights.h"
+#include "materials.h"
 
 // the reference declares these as globals in main.cpp; objects.h has `extern` declarations only
 Sphere theSphere;
@@ -400,6 +414,130 @@ static int cmd_tex(const char *in, const char *out, const char *image)
     return 0;
 }
 
+
+// ---- RenderImage side products (scene.h:591-637) ----------------------------------------------
+// zimg <in.bin> <out.bin>
+// in: int32 w, h; float z[w*h]; uint8 sampleCount[w*h]
+// out: uint8 zbufferImg[w*h]; uint8 sampleCountImg[w*h]; int32 smax (return value of ComputeSampleCountImage)
+static int cmd_zimg(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    const char *c = b.data();
+    int32_t w = *(int32_t *)c; c += 4;
+    int32_t h = *(int32_t *)c; c += 4;
+    const size_t n = (size_t)w * h;
+    RenderImage img;
+    img.Init(w, h);
+    memcpy(img.GetZBuffer(), c, n * 4); c += n * 4;
+    memcpy(img.GetSampleCount(), c, n);
+    img.ComputeZBufferImage();
+    int32_t smax = img.ComputeSampleCountImage();
+    Out o(out);
+    o.bytes(img.GetZBufferImage(), n);
+    o.bytes(img.GetSampleCountImage(), n);
+    o.put(smax);
+    return 0;
+}
+
+// ---- the recording double for GenLight::Shadow (see the file header) ---------------------------
+static std::vector<float> g_shadow_log;       // 7 floats per call: ray.p, ray.dir, t_max
+static std::vector<float> g_shadow_script;    // values returned, in call order (cycled)
+static size_t g_shadow_calls = 0;
+float GenLight::Shadow(Ray ray, float t_max)
+{
+    const float v[7] = {ray.p.x, ray.p.y, ray.p.z, ray.dir.x, ray.dir.y, ray.dir.z, t_max};
+    g_shadow_log.insert(g_shadow_log.end(), v, v + 7);
+    const float r = g_shadow_script.empty() ? 1.0f : g_shadow_script[g_shadow_calls % g_shadow_script.size()];
+    g_shadow_calls++;
+    return r;
+}
+
+#define RAND_CAPTURE 64
+// illum <in.bin> <out.bin>
+// in: int32 n; n x {float intensity[3], position[3], size, p[3]; uint32 seed; int32 nscript; float script[8]}
+// out: n x {float result[3]; int32 ncalls; float log[20][7] (first ncalls rows used); int32 rand[RAND_CAPTURE]}
+static int cmd_illum(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    const char *c = b.data();
+    int32_t n = *(int32_t *)c; c += 4;
+    Out o(out);
+    for (int i = 0; i < n; i++) {
+        const float *f = (const float *)c; c += 40;
+        uint32_t seed = *(uint32_t *)c; c += 4;
+        int32_t nscript = *(int32_t *)c; c += 4;
+        const float *script = (const float *)c; c += 32;
+        PointLight pl;
+        pl.SetIntensity(Color(f[0], f[1], f[2]));
+        pl.SetPosition(Point3(f[3], f[4], f[5]));
+        pl.SetSize(f[6]);
+        int32_t raw[RAND_CAPTURE];
+        srand(seed);
+        for (int k = 0; k < RAND_CAPTURE; k++) raw[k] = rand();
+        srand(seed);
+        g_shadow_log.clear(); g_shadow_calls = 0;
+        g_shadow_script.assign(script, script + nscript);
+        Color r = pl.PointLight::Illuminate(Point3(f[7], f[8], f[9]), Point3(0, 0, 1));
+        o.put(r.r); o.put(r.g); o.put(r.b);
+        int32_t nc = (int32_t)g_shadow_calls; o.put(nc);
+        g_shadow_log.resize(20 * 7, 0.0f);
+        o.bytes(g_shadow_log.data(), 20 * 7 * 4);
+        o.bytes(raw, sizeof raw);
+    }
+    return 0;
+}
+
+#ifdef REF_FIN
+// pbounce <in.bin> <out.bin>   (RayTracingFinal only: P13's materials.h has no body for it)
+// in: int32 n; n x {float diffuse[3], specular[3], reflection[3], refraction[3], absorption[3], glossiness, ior;
+//                   float ray_p[3], ray_dir[3]; float hit_p[3], hit_N[3], hit_z; int32 front; float c[3]; uint32 seed}
+// out: n x {int32 ret; float ray_p[3], ray_dir[3], c[3]; int32 rand[8]}; then n x float atten[3] =
+//      Attenuation(absorption, hit_z); then n x float Nt[3], Nb[3] = createCoordinateSystem(hit_N)
+static int cmd_pbounce(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    const char *c0 = b.data();
+    int32_t n = *(int32_t *)c0;
+    const size_t rec = 17 * 4 + 6 * 4 + 7 * 4 + 4 + 3 * 4 + 4;
+    Out o(out);
+    std::vector<float> att, cs;
+    for (int i = 0; i < n; i++) {
+        const char *c = c0 + 4 + rec * i;
+        const float *m = (const float *)c; c += 17 * 4;
+        const float *ry = (const float *)c; c += 24;
+        const float *ht = (const float *)c; c += 28;
+        int32_t front = *(int32_t *)c; c += 4;
+        const float *col = (const float *)c; c += 12;
+        uint32_t seed = *(uint32_t *)c;
+        MtlBlinn mtl;
+        mtl.SetDiffuse(Color(m[0], m[1], m[2])); mtl.SetSpecular(Color(m[3], m[4], m[5]));
+        mtl.SetReflection(Color(m[6], m[7], m[8])); mtl.SetRefraction(Color(m[9], m[10], m[11]));
+        mtl.SetAbsorption(Color(m[12], m[13], m[14])); mtl.SetGlossiness(m[15]); mtl.SetRefractionIndex(m[16]);
+        Ray r(Point3(ry[0], ry[1], ry[2]), Point3(ry[3], ry[4], ry[5]));
+        HitInfo hi; hi.Init();
+        hi.p = Point3(ht[0], ht[1], ht[2]); hi.N = Point3(ht[3], ht[4], ht[5]); hi.z = ht[6]; hi.front = front != 0;
+        Color cc(col[0], col[1], col[2]);
+        int32_t raw[8];
+        srand(seed);
+        for (int k = 0; k < 8; k++) raw[k] = rand();
+        srand(seed);
+        int32_t ret = mtl.MtlBlinn::RandomPhotonBounce(r, cc, hi) ? 1 : 0;
+        o.put(ret);
+        o.put(r.p.x); o.put(r.p.y); o.put(r.p.z); o.put(r.dir.x); o.put(r.dir.y); o.put(r.dir.z);
+        o.put(cc.r); o.put(cc.g); o.put(cc.b);
+        o.bytes(raw, sizeof raw);
+        Color a = Attenuation(Color(m[12], m[13], m[14]), ht[6]);
+        att.push_back(a.r); att.push_back(a.g); att.push_back(a.b);
+        Point3 Nt, Nb;
+        createCoordinateSystem(hi.N, Nt, Nb);
+        const float q[6] = {Nt.x, Nt.y, Nt.z, Nb.x, Nb.y, Nb.z};
+        cs.insert(cs.end(), q, q + 6);
+    }
+    if (n) { o.bytes(att.data(), att.size() * 4); o.bytes(cs.data(), cs.size() * 4); }
+    return 0;
+}
+#endif
+
 // time <in.bin> <out.bin>: same input as `photon`; prints seconds spent in the nq queries (k=400)
 static int cmd_time(const char *in, const char *out)
 {
@@ -420,6 +558,11 @@ int main(int argc, char **argv)
     if (cmd == "photon") return cmd_photon(argv[2], argv[3]);
     if (cmd == "photondat") { if (argc < 5) return 1; return cmd_photondat(argv[2], argv[3], argv[4]); }
     if (cmd == "tex") { if (argc < 5) return 1; return cmd_tex(argv[2], argv[3], argv[4]); }
+    if (cmd == "zimg") return cmd_zimg(argv[2], argv[3]);
+    if (cmd == "illum") return cmd_illum(argv[2], argv[3]);
+#ifdef REF_FIN
+    if (cmd == "pbounce") return cmd_pbounce(argv[2], argv[3]);
+#endif
     if (cmd == "time") return cmd_time(argv[2], argv[3]);
     fprintf(stderr, "unknown command %s\n", cmd.c_str());
     return 1;

@@ -54,7 +54,47 @@ static void rng2_at(uint32_t seed, uint32_t sample, uint32_t node, uint32_t purp
     *u0 = (float)(o[0] >> 8) * (1.0f / 16777216.0f);
     *u1 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
 }
-static void rng2(uint32_t purpose, uint32_t index, float *u0, float *u1) { rng2_at(g_rng.seed, g_rng.sample, g_rng.node, purpose, index, u0, u1); }
+
+/* ---- test hooks: a scripted rand() stream and a scripted Shadow --------------------------------
+ * The reference draws from libc rand() and calls GenLight::Shadow; to compare this restatement with
+ * the reference's own PointLight::Illuminate / MtlBlinn::RandomPhotonBounce (compiled in
+ * oracle/ref_harness.cpp) draw for draw, a test hands over the RAW rand() values the reference
+ * consumed and the values its Shadow double returned; while a script is active every random draw
+ * takes the next raw value exactly the way the reference's expression does
+ * (`rand() / (float) RAND_MAX`, or the double forms of P13/include/lights.h:73-74) and orc_shadow
+ * logs its ray and returns the next scripted value instead of tracing. */
+static struct { const int32_t *raw; int n, i; const float *sh; int nsh, ish; float *log; int log_cap, nlog; int on; } g_script;
+void orc_script_begin(const int32_t *raw_rand, int n_rand, const float *shadow_values, int n_shadow, float *shadow_log, int log_cap)
+{
+    g_script.raw = raw_rand; g_script.n = n_rand; g_script.i = 0;
+    g_script.sh = shadow_values; g_script.nsh = n_shadow; g_script.ish = 0;
+    g_script.log = shadow_log; g_script.log_cap = log_cap; g_script.nlog = 0; g_script.on = 1;
+}
+int orc_script_end(int *rand_used)
+{
+    if (rand_used) *rand_used = g_script.i;
+    g_script.on = 0;
+    return g_script.nlog;
+}
+#define REF_RAND_MAX 2147483647            /* glibc RAND_MAX, the value the harness ran with */
+static int32_t script_raw(void) { return (g_script.i < g_script.n) ? g_script.raw[g_script.i++] : (g_script.i++, 0); }
+static float script_uniform(void) { return script_raw() / (float)REF_RAND_MAX; }    /* rand() / (float) RAND_MAX */
+
+static void rng2(uint32_t purpose, uint32_t index, float *u0, float *u1)
+{
+    if (g_script.on) { *u0 = script_uniform(); *u1 = script_uniform(); return; }
+    rng2_at(g_rng.seed, g_rng.sample, g_rng.node, purpose, index, u0, u1);
+}
+/* the same two draws as numerator/denominator pairs for expressions of the form
+ * `M_PI * 2.0 * rand() / (float) RAND_MAX` (evaluated in double, left to right): with the counter
+ * generator the numerator is the uniform itself and the denominator 1.0 (an exact division) */
+static void rng2_ratio(uint32_t purpose, uint32_t index, double *r0, double *r1, double *den)
+{
+    if (g_script.on) { *r0 = (double)script_raw(); *r1 = (double)script_raw(); *den = (double)(float)REF_RAND_MAX; return; }
+    float u0, u1;
+    rng2_at(g_rng.seed, g_rng.sample, g_rng.node, purpose, index, &u0, &u1);
+    *r0 = (double)u0; *r1 = (double)u1; *den = 1.0;
+}
 static uint32_t child_node(uint32_t node, uint32_t kind) { return node * 0x9E3779B1u + kind * 0x85EBCA6Bu + 0x27D4EB2Fu; }
 
 /* ---- cyPoint3f subset (FIN/include/cyPoint.h:259-350) ---------------------------------- */
@@ -447,6 +487,11 @@ float orc_shadow(const orc_scene *s, int model, const float ray[6], float t_max)
 {
     float bias = 1e-14f;
     orc_hit h;
+    if (g_script.on) {                                      /* test hook, see orc_script_begin */
+        if (g_script.log && g_script.nlog < g_script.log_cap) { memcpy(g_script.log + 7 * g_script.nlog, ray, 24); g_script.log[7 * g_script.nlog + 6] = t_max; }
+        g_script.nlog++;
+        return g_script.nsh > 0 ? g_script.sh[(g_script.ish++) % g_script.nsh] : 1.0f;
+    }
     g_cnt.rays_shadow++;
     if (orc_trace(s, model, ray, &h)) {
         if (h.z > bias && h.z < t_max) return 0.0f;
@@ -500,11 +545,12 @@ void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
     if (model != RT_SHADE_FIN) {
         float shadow_coef = 0.0f;
         for (int i = 0; i < ns; i++) {
-            rng2(RNG_SHADOW, li * 64 + (uint32_t)i, &u0, &u1);
+            double r0, r1, den;
+            rng2_ratio(RNG_SHADOW, li * 64 + (uint32_t)i, &r0, &r1, &den);
             float r = orc_halton(i, 2);
             r = sqrtf(r) * size;
-            float theta = (float)(M_PI * 2.0 * (double)u0);            /* M_PI*2.0*rand()/(float)RAND_MAX */
-            float gam = (float)(M_PI * (double)u1);
+            float theta = (float)(M_PI * 2.0 * r0 / den);              /* M_PI * 2.0 * rand()/ (float) RAND_MAX */
+            float gam = (float)(M_PI * r1 / den);                      /* M_PI * rand()/ (float) RAND_MAX */
             float dx = r * sinf(gam) * cosf(theta);
             float dy = r * sinf(gam) * sinf(theta);
             float dz = r * cosf(gam);
@@ -1576,6 +1622,7 @@ static void philox_refill(philox_t *g)
 }
 static float philox_next(philox_t *g)     /* stands in for rand() / (float) RAND_MAX */
 {
+    if (g_script.on) return script_uniform();               /* test hook, see orc_script_begin */
     if (g->used >= 4) philox_refill(g);
     return (float)(g->o[g->used++] >> 8) * (1.0f / 16777216.0f);
 }
@@ -1640,6 +1687,71 @@ static int random_photon_bounce(const rt_blinn *m, const orc_hit *h, float ray[6
     *c = vdivs(vmul(*c, BxDF), 1.f * scale);
     if (!h->front) *c = vmul(*c, attenuation(v3p(m->absorption), h->z));
     return 1;
+}
+
+/* public faces of the three materials.h helpers, for the tests that compare them with the reference's own
+ * (tests/golden/pbounce.npz): RandomPhotonBounce draws from the active script (orc_script_begin) */
+int orc_random_photon_bounce(const rt_blinn *m, const orc_hit *h, float ray[6], float c[3])
+{
+    philox_t rng;
+    memset(&rng, 0, sizeof rng);
+    rng.used = 4;
+    v3 cc = v3p(c);
+    const int r = random_photon_bounce(m, h, ray, &cc, &rng);
+    st3(c, cc);
+    return r;
+}
+void orc_attenuation(const float absorption[3], float l, float out[3]) { st3(out, attenuation(v3p(absorption), l)); }
+/* createCoordinateSystem, FIN/include/materials.h:50-59 */
+void orc_coordinate_system(const float N_[3], float Nt_[3], float Nb_[3])
+{
+    const v3 N = v3p(N_);
+    v3 Nt = vdot(N, V3(1, 0, 0)) < 0.4f ? vcross(N, V3(1, 0, 0)) : vcross(N, V3(0, 0, 1));
+    Nt = vnorm(Nt);
+    st3(Nt_, Nt); st3(Nb_, vcross(N, Nt));
+}
+
+/* RenderImage::ComputeZBufferImage, FIN/include/scene.h:591-613 */
+void orc_zbuffer_image(const float *zbuffer, int width, int height, uint8_t *zbufferImg)
+{
+    int size = width * height;
+    float zmin = BIGFLOAT, zmax = 0;
+    for (int i = 0; i < size; i++) {
+        if (zbuffer[i] == BIGFLOAT) continue;
+        if (zmin > zbuffer[i]) zmin = zbuffer[i];
+        if (zmax < zbuffer[i]) zmax = zbuffer[i];
+    }
+    for (int i = 0; i < size; i++) {
+        if (zbuffer[i] == BIGFLOAT) zbufferImg[i] = 0;
+        else {
+            float f = (zmax - zbuffer[i]) / (zmax - zmin);
+            int c = (int)(f * 255);
+            if (c < 0) c = 0;
+            if (c > 255) c = 255;
+            zbufferImg[i] = (uint8_t)c;
+        }
+    }
+}
+/* RenderImage::ComputeSampleCountImage, FIN/include/scene.h:615-637; returns smax */
+int orc_sample_count_image(const uint8_t *sampleCount, int width, int height, uint8_t *sampleCountImg)
+{
+    int size = width * height;
+    uint8_t smin = 255, smax = 0;
+    for (int i = 0; i < size; i++) {
+        if (smin > sampleCount[i]) smin = sampleCount[i];
+        if (smax < sampleCount[i]) smax = sampleCount[i];
+    }
+    if (smax == smin) {
+        for (int i = 0; i < size; i++) sampleCountImg[i] = 0;
+    } else {
+        for (int i = 0; i < size; i++) {
+            int c = (255 * (sampleCount[i] - smin)) / (smax - smin);
+            if (c < 0) c = 0;
+            if (c > 255) c = 255;
+            sampleCountImg[i] = (uint8_t)c;
+        }
+    }
+    return smax;
 }
 
 /* generatePhotonMap (FIN/main.cpp:350-396) + PhotonTracing (:439-459) + RandomPhoton (:489-497);

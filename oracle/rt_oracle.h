@@ -104,6 +104,18 @@ void  orc_estimate_irradiance(const rt_photon *photons, uint32_t n, int k, float
                               const float pos[3], const float normal[3],
                               float irr[3], float dir[3]);
 
+/* test hooks (see rt_oracle.c): while a script is active, random draws consume raw rand() values
+ * captured from the reference run and orc_shadow logs {p, dir, t_max} and returns scripted values */
+void  orc_script_begin(const int32_t *raw_rand, int n_rand, const float *shadow_values, int n_shadow,
+                       float *shadow_log, int log_cap);
+int   orc_script_end(int *rand_used);
+int   orc_random_photon_bounce(const rt_blinn *m, const orc_hit *h, float ray[6], float c[3]);
+void  orc_attenuation(const float absorption[3], float l, float out[3]);
+void  orc_coordinate_system(const float N[3], float Nt[3], float Nb[3]);
+/* RenderImage::ComputeZBufferImage / ComputeSampleCountImage (scene.h:591-637) */
+void  orc_zbuffer_image(const float *zbuffer, int width, int height, uint8_t *zbufferImg);
+int   orc_sample_count_image(const uint8_t *sampleCount, int width, int height, uint8_t *sampleCountImg);
+
 /* generatePhotonMap with the build's counter RNG (Philox); out is 1-based with room for
  * max_photons + 9 records; returns the photon count */
 uint32_t orc_photon_pass(const orc_scene *s, uint32_t seed, uint32_t max_photons, int max_bounce,

@@ -74,7 +74,7 @@ SYMBOLS = [
     "rt_scene_set_mesh_texcoords", "rt_scene_get_mesh_texcoords",
     "rt_scene_set_materials", "rt_scene_set_lights", "rt_scene_set_environment",
     "rt_scene_set_photons", "rt_scene_set_textures", "rt_scene_set_material_maps", "rt_scene_set_environment_maps",
-    "rt_scene_get_textures", "rt_scene_get_maps", "rt_image_read_rgb", "rt_image_write_png", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
+    "rt_scene_get_textures", "rt_scene_get_maps", "rt_image_read_rgb", "rt_image_write_png", "rt_image_zbuffer", "rt_image_sample_count", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
     "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
     "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photons_write_dat", "rt_photons_read_dat", "rt_photon_pass", "rt_render_begin",
     "rt_render_tiles_device", "rt_render_progress", "rt_render_stop", "rt_render_wait",
@@ -157,6 +157,23 @@ def image_write_png(path, data):
     data = np.ascontiguousarray(data, np.uint8)
     comps = 1 if data.ndim == 2 else data.shape[2]
     _check(lib().rt_image_write_png(os.fsencode(path), _p(data), data.shape[1], data.shape[0], comps))
+
+
+def zbuffer_image(z):
+    """RenderImage::ComputeZBufferImage (scene.h:591-613) of a float z buffer (h, w)."""
+    z = np.ascontiguousarray(z, np.float32)
+    out = np.zeros(z.shape, np.uint8)
+    _check(lib().rt_image_zbuffer(_p(z), z.shape[1], z.shape[0], _p(out)))
+    return out
+
+
+def sample_count_image(cnt):
+    """RenderImage::ComputeSampleCountImage (scene.h:615-637): (image, smax)."""
+    cnt = np.ascontiguousarray(cnt, np.uint8)
+    out = np.zeros(cnt.shape, np.uint8)
+    smax = C.c_int32()
+    _check(lib().rt_image_sample_count(_p(cnt), cnt.shape[1], cnt.shape[0], _p(out), C.byref(smax)))
+    return out, smax.value
 
 
 def identity_map(texture=MAP_NONE):

@@ -2,8 +2,10 @@
 // FIN = /root/reference/RayTracingFinal/RayTracingFinal) gets from the vendored lodepng
 // (`lodepng::decode(d, w, h, name, LCT_RGB)`: any PNG colour type converted to 8-bit RGB) and from
 // its own LoadPPM (:33-53).  Own implementation: zlib inflate (stored / fixed / dynamic Huffman),
-// PNG scanline filters, non-interlaced images of bit depth 8 or 16 (16 keeps the high byte),
-// colour types grey, RGB, palette, grey+alpha, RGBA (alpha dropped, as LCT_RGB does).
+// PNG scanline filters, non-interlaced images of every legal bit depth (1/2/4-bit grey and palette
+// samples unpacked and scaled like lodepng does, 16 keeps the high byte), colour types grey, RGB,
+// palette, grey+alpha, RGBA (alpha dropped, as LCT_RGB does).  Also the two derived images of
+// RenderImage (scene.h:591-637).
 #include "rt_scene.h"
 
 #include <cctype>
@@ -152,12 +154,16 @@ bool load_png(const std::vector<uint8_t> &f, int &w, int &h, std::vector<uint8_t
         else if (!memcmp(tag, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
-    if (w <= 0 || h <= 0 || (depth != 8 && depth != 16) || interlace != 0) { if (err) *err = "unsupported PNG (need non-interlaced, 8/16 bit)"; return false; }
+    if (w <= 0 || h <= 0 || interlace != 0) { if (err) *err = "unsupported PNG (need a non-interlaced image)"; return false; }
+    // IHDR is untrusted input: bound the pixel count before any size arithmetic (2^28 pixels = the render limit)
+    if ((unsigned long long)w * (unsigned long long)h > (1ull << 28)) { if (err) *err = "PNG too large (more than 2^28 pixels)"; return false; }
     int ch;
     switch (ctype) { case 0: ch = 1; break; case 2: ch = 3; break; case 3: ch = 1; break; case 4: ch = 2; break; case 6: ch = 4; break; default: if (err) *err = "bad PNG colour type"; return false; }
-    if (ctype == 3 && depth != 8) { if (err) *err = "unsupported palette depth"; return false; }
-    const int bpp = ch * depth / 8;
-    const size_t stride = (size_t)w * bpp;
+    // legal depths per colour type (PNG 1.2, table 11.1): grey 1/2/4/8/16, palette 1/2/4/8, the rest 8/16
+    const bool sub_byte = depth == 1 || depth == 2 || depth == 4;
+    if (!((depth == 8) || (depth == 16 && ctype != 3) || (sub_byte && (ctype == 0 || ctype == 3)))) { if (err) *err = "unsupported PNG bit depth"; return false; }
+    const int bpp = sub_byte ? 1 : ch * depth / 8;           // filter distance in bytes (1 for packed samples)
+    const size_t stride = sub_byte ? ((size_t)w * depth + 7) / 8 : (size_t)w * bpp;
     std::vector<uint8_t> raw;
     raw.reserve((stride + 1) * h);
     if (!inflate(idat.data(), idat.size(), raw) || raw.size() < (stride + 1) * (size_t)h) { if (err) *err = "PNG data does not inflate"; return false; }
@@ -181,6 +187,22 @@ bool load_png(const std::vector<uint8_t> &f, int &w, int &h, std::vector<uint8_t
         }
     }
     rgb.resize((size_t)w * h * 3);
+    if (sub_byte) {
+        // packed 1/2/4-bit samples, leftmost pixel in the high-order bits; grey levels scale to 0..255
+        // (lodepng's conversion to 8 bit: value * 255 / (2^depth - 1))
+        const int maxv = (1 << depth) - 1;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const size_t bit = (size_t)x * depth;
+                const int v = (img[stride * y + bit / 8] >> (8 - depth - (int)(bit % 8))) & maxv;
+                uint8_t r, g, b;
+                if (ctype == 3) { const size_t k = (size_t)v * 3; if (k + 2 < plte.size()) { r = plte[k]; g = plte[k + 1]; b = plte[k + 2]; } else r = g = b = 0; }
+                else r = g = b = (uint8_t)(v * 255 / maxv);
+                uint8_t *o = &rgb[3 * ((size_t)y * w + x)];
+                o[0] = r; o[1] = g; o[2] = b;
+            }
+        return true;
+    }
     const int bs = depth / 8;                  // bytes per sample (16 bit: high byte first)
     for (size_t i = 0; i < (size_t)w * h; i++) {
         const uint8_t *px = &img[i * bpp];
@@ -203,10 +225,10 @@ bool load_ppm(const std::vector<uint8_t> &f, int &w, int &h, std::vector<uint8_t
     };
     std::string s;
     line(s);
-    if (s.size() < 2 || (s[0] != 'P' && s[1] != '6')) { if (err) *err = "not a P6 PPM"; return false; }
+    if (s.size() < 2 || s[0] != 'P' || s[1] != '6') { if (err) *err = "not a P6 PPM"; return false; }
     line(s);
     while (!s.empty() && s[0] == '#') line(s);
-    if (sscanf(s.c_str(), "%d %d", &w, &h) != 2 || w <= 0 || h <= 0) { if (err) *err = "bad PPM size"; return false; }
+    if (sscanf(s.c_str(), "%d %d", &w, &h) != 2 || w <= 0 || h <= 0 || (unsigned long long)w * (unsigned long long)h > (1ull << 28)) { if (err) *err = "bad PPM size"; return false; }
     line(s);
     while (!s.empty() && s[0] == '#') line(s);
     rgb.assign((size_t)w * h * 3, 0);
@@ -216,6 +238,42 @@ bool load_ppm(const std::vector<uint8_t> &f, int &w, int &h, std::vector<uint8_t
 }
 
 }  // namespace
+
+// RenderImage::ComputeZBufferImage, FIN/include/scene.h:591-613
+void ZBufferImage(const float *zbuffer, size_t size, uint8_t *zbufferImg)
+{
+    const float BIG = 1.0e30f;
+    float zmin = BIG, zmax = 0;
+    for (size_t i = 0; i < size; i++) {
+        if (zbuffer[i] == BIG) continue;
+        if (zmin > zbuffer[i]) zmin = zbuffer[i];
+        if (zmax < zbuffer[i]) zmax = zbuffer[i];
+    }
+    for (size_t i = 0; i < size; i++) {
+        if (zbuffer[i] == BIG) { zbufferImg[i] = 0; continue; }
+        const float f = (zmax - zbuffer[i]) / (zmax - zmin);
+        // int(f * 255) is undefined for NaN (zmax == zmin: 0/0) in the reference; here NaN -> 0
+        int c = (f == f) ? int(f * 255) : 0;
+        if (c < 0) c = 0;
+        if (c > 255) c = 255;
+        zbufferImg[i] = (uint8_t)c;
+    }
+}
+
+// RenderImage::ComputeSampleCountImage, FIN/include/scene.h:615-637
+int SampleCountImage(const uint8_t *sampleCount, size_t size, uint8_t *sampleCountImg)
+{
+    uint8_t smin = 255, smax = 0;
+    for (size_t i = 0; i < size; i++) { if (smin > sampleCount[i]) smin = sampleCount[i]; if (smax < sampleCount[i]) smax = sampleCount[i]; }
+    if (smax == smin) { for (size_t i = 0; i < size; i++) sampleCountImg[i] = 0; return smax; }
+    for (size_t i = 0; i < size; i++) {
+        int c = (255 * (sampleCount[i] - smin)) / (smax - smin);
+        if (c < 0) c = 0;
+        if (c > 255) c = 255;
+        sampleCountImg[i] = (uint8_t)c;
+    }
+    return smax;
+}
 
 bool ReadImageRGB(const char *filename, int &w, int &h, std::vector<uint8_t> &rgb, std::string *err)
 {
@@ -230,8 +288,16 @@ bool ReadImageRGB(const char *filename, int &w, int &h, std::vector<uint8_t> &rg
     size_t n;
     while ((n = fread(buf, 1, sizeof buf, fp)) > 0) f.insert(f.end(), buf, buf + n);
     fclose(fp);
-    if (!strcmp(ext, "png")) return load_png(f, w, h, rgb, err);
-    if (!strcmp(ext, "ppm")) return load_ppm(f, w, h, rgb, err);
+    // nothing may be thrown across the C ABI (rt_image_read_rgb, rt_scene_load_xml): a truncated or hostile
+    // file can still run an allocation out of memory
+    try {
+        if (!strcmp(ext, "png")) return load_png(f, w, h, rgb, err);
+        if (!strcmp(ext, "ppm")) return load_ppm(f, w, h, rgb, err);
+    } catch (const std::exception &e) {
+        if (err) *err = std::string("image decode failed: ") + e.what();
+        w = h = 0;
+        return false;
+    }
     if (err) *err = "unsupported image type (png and ppm only, like the reference)";
     return false;
 }

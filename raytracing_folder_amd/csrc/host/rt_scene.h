@@ -335,7 +335,10 @@ void BuildMeanSplitBVH(const float *v, const uint32_t *f, unsigned nf, unsigned 
 // PhotonMap::PrepareForIrradianceEstimation (FIN/include/cyPhotonMap.h:196-284)
 void BalancePhotons(rt_photon *in, uint32_t n, rt_photon *out);
 
-// PNG (non-interlaced, 8/16 bit) and binary PPM reader -> RGB8, as TextureFile::Load needs
+// RenderImage::ComputeZBufferImage / ComputeSampleCountImage (FIN/include/scene.h:591-637) on plain arrays
+void ZBufferImage(const float *zbuffer, size_t size, uint8_t *zbufferImg);
+int SampleCountImage(const uint8_t *sampleCount, size_t size, uint8_t *sampleCountImg);
+// PNG (non-interlaced, any legal bit depth) and binary PPM reader -> RGB8, as TextureFile::Load needs
 bool ReadImageRGB(const char *filename, int &w, int &h, std::vector<uint8_t> &rgb, std::string *err);
 // minimal PNG writer (8-bit grey or RGB, stored deflate blocks) for RenderImage::SavePNG
 bool WritePNG(const char *filename, const uint8_t *data, int width, int height, int comps);

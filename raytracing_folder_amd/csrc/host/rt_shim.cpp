@@ -17,43 +17,17 @@ void RenderImage::Init(int w, int h)
 
 int RenderImage::GetNumRenderedPixels() const { return job ? rt_render_progress(job) : finalPixels; }
 
-// RenderImage::ComputeZBufferImage, FIN/include/scene.h:591-613
+// RenderImage::ComputeZBufferImage / ComputeSampleCountImage, FIN/include/scene.h:591-637 (rt_image.cpp)
 void RenderImage::ComputeZBufferImage()
 {
-    const size_t size = (size_t)width * height;
-    zbufferImg.assign(size, 0);
-    const float BIG = 1.0e30f;
-    float zmin = BIG, zmax = 0;
-    for (size_t i = 0; i < size; i++) {
-        if (zbuffer[i] == BIG) continue;
-        if (zmin > zbuffer[i]) zmin = zbuffer[i];
-        if (zmax < zbuffer[i]) zmax = zbuffer[i];
-    }
-    for (size_t i = 0; i < size; i++) {
-        if (zbuffer[i] == BIG) { zbufferImg[i] = 0; continue; }
-        const float f = (zmax - zbuffer[i]) / (zmax - zmin);
-        int c = int(f * 255);
-        if (c < 0) c = 0;
-        if (c > 255) c = 255;
-        zbufferImg[i] = (uint8_t)c;
-    }
+    zbufferImg.assign((size_t)width * height, 0);
+    ZBufferImage(zbuffer.data(), zbufferImg.size(), zbufferImg.data());
 }
 
-// RenderImage::ComputeSampleCountImage, FIN/include/scene.h:615-637
 int RenderImage::ComputeSampleCountImage()
 {
-    const size_t size = (size_t)width * height;
-    sampleCountImg.assign(size, 0);
-    uint8_t smin = 255, smax = 0;
-    for (size_t i = 0; i < size; i++) { if (smin > sampleCount[i]) smin = sampleCount[i]; if (smax < sampleCount[i]) smax = sampleCount[i]; }
-    if (smax != smin)
-        for (size_t i = 0; i < size; i++) {
-            int c = (255 * (sampleCount[i] - smin)) / (smax - smin);
-            if (c < 0) c = 0;
-            if (c > 255) c = 255;
-            sampleCountImg[i] = (uint8_t)c;
-        }
-    return smax;
+    sampleCountImg.assign((size_t)width * height, 0);
+    return SampleCountImage(sampleCount.data(), sampleCountImg.size(), sampleCountImg.data());
 }
 
 Renderer::Renderer() { rt_params_default(&params); rt_scene_create(&handle); }

@@ -405,6 +405,21 @@ extern "C" rt_status rt_image_write_png(const char *path, const uint8_t *data, i
     return RT_OK;
 }
 
+extern "C" rt_status rt_image_zbuffer(const float *zbuffer, int32_t w, int32_t h, uint8_t *zbuffer_img)
+{
+    if (!zbuffer || !zbuffer_img || w <= 0 || h <= 0) return fail(RT_ERR_ARG, "rt_image_zbuffer: bad argument");
+    rt::ZBufferImage(zbuffer, (size_t)w * (size_t)h, zbuffer_img);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_image_sample_count(const uint8_t *sample_count, int32_t w, int32_t h, uint8_t *sample_count_img, int32_t *smax)
+{
+    if (!sample_count || !sample_count_img || w <= 0 || h <= 0) return fail(RT_ERR_ARG, "rt_image_sample_count: bad argument");
+    const int m = rt::SampleCountImage(sample_count, (size_t)w * (size_t)h, sample_count_img);
+    if (smax) *smax = m;
+    return RT_OK;
+}
+
 extern "C" rt_status rt_scene_set_photons(rt_scene *s, const rt_photon *photons, uint32_t n_stored)
 {
     rt_status st = check_idle(s, "rt_scene_set_photons");

@@ -705,15 +705,16 @@ def test_cpp_beginrender_shim_end_to_end(tmp_path):
     rgb, z, cnt, _, _ = s.render(cam, capi.default_params())
     img = capi.image_read_rgb(out[0])
     assert img.shape == rgb.shape and (np.abs(img.astype(int) - rgb.astype(int)) <= 1).mean() > 0.999
-    # ComputeZBufferImage / ComputeSampleCountImage (scene.h:591-637) on the same buffers
-    hit = z != np.float32(1e30)
-    zmin, zmax = z[hit].min(), z[hit].max()
-    zi = np.where(hit, np.clip(((zmax - np.where(hit, z, zmax)) / (zmax - zmin) * 255).astype(np.int64), 0, 255), 0)
+    # ComputeZBufferImage / ComputeSampleCountImage (scene.h:591-637): integer maps, BIT-EXACT.  The PNGs the
+    # C++ shim wrote must be what the same functions (pinned to the reference's own in tests/golden/zimage.npz)
+    # make of the z / count buffers of a render through the C ABI -- the z buffer itself is deterministic
     zpng = capi.image_read_rgb(out[2])[..., 0]
-    assert (np.abs(zpng.astype(int) - zi) <= 1).mean() > 0.999
+    assert np.array_equal(zpng, capi.zbuffer_image(z))
     spng = capi.image_read_rgb(out[1])[..., 0]
-    smin, smax = int(cnt.min()), int(cnt.max())
-    assert smax > smin and (np.abs(spng.astype(int) - (255 * (cnt.astype(int) - smin)) // (smax - smin)) <= 1).mean() > 0.995
+    sc, smax = capi.sample_count_image(cnt)
+    # the count byte hangs on the variance gate of colours whose last ulp is not deterministic (float atomics):
+    # a pixel exactly on the threshold may flip between two runs, everything else is exact
+    assert smax == 255 and (spng != sc).sum() <= 2
     # StopRender after the first progress: fewer pixels, no error
     r = subprocess.run([exe, xml] + out + ["stop"], capture_output=True, text=True, env=dict(os.environ, RT_CHUNK_SAMPLES="4096"))
     assert r.returncode == 0, r.stderr

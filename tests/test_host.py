@@ -242,3 +242,73 @@ def test_xml_textures_and_map_transforms(gold):
     assert orc.texmap_transform(maps[1, 0], g["uvw"]).tobytes() == g["map_transform"].tobytes()
     assert e["env_map"]["texture"][0] == 0 and e["bg_map"]["texture"][0] == 0
     assert np.allclose(e["materials"]["diffuse"][3], 0.8)
+
+
+def test_zbuffer_and_sample_count_images_match_reference(gold):
+    """rt_image_zbuffer / rt_image_sample_count (host code behind the C ABI, used by rt::RenderImage) against
+    RenderImage::ComputeZBufferImage / ComputeSampleCountImage of the reference itself: bit-exact integer maps"""
+    g = gold("zimage.npz")
+    for tag in "abc":
+        assert np.array_equal(capi.zbuffer_image(g[f"z_{tag}"]), g[f"zimg_{tag}"])
+        sc, smax = capi.sample_count_image(g[f"cnt_{tag}"])
+        assert np.array_equal(sc, g[f"scimg_{tag}"]) and smax == int(g[f"smax_{tag}"])
+    # degenerate frames: nothing hit (all BIGFLOAT) -> zeros; a single depth -> 0/0, NaN -> 0 (UB in the reference)
+    assert (capi.zbuffer_image(np.full((3, 4), 1.0e30, np.float32)) == 0).all()
+    assert (capi.zbuffer_image(np.full((3, 4), 7.0, np.float32)) == 0).all()
+
+
+def _png(path, w, h, depth, ctype, rows, plte=None):
+    """minimal PNG writer for the reader test: `rows` are the packed scanlines (bytes), filter type 0"""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    raw = b"".join(b"\0" + bytes(r) for r in rows)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if plte is not None:
+        png += chunk(b"PLTE", bytes(plte))
+    png += chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(png)
+
+
+def test_image_reader_low_bit_depths_and_hostile_headers(tmp_path):
+    """1/2/4-bit grey and palette PNGs (the reference's own sample-count images are 1-bit grey: lodepng picks
+    the smallest type) decode like lodepng's LCT_RGB conversion; absurd IHDR sizes and bad PPM magics are
+    refused with an error instead of an exception or an overflow"""
+    rng = np.random.default_rng(5)
+    w, h = 13, 5
+    for depth in (1, 2, 4):
+        vals = rng.integers(0, 1 << depth, (h, w))
+        per = 8 // depth
+        rows = []
+        for y in range(h):
+            row = bytearray((w + per - 1) // per)
+            for x in range(w):
+                row[x // per] |= int(vals[y, x]) << (8 - depth - depth * (x % per))
+            rows.append(row)
+        path = str(tmp_path / f"g{depth}.png")
+        _png(path, w, h, depth, 0, rows)
+        got = capi.image_read_rgb(path)
+        want = (vals * 255 // ((1 << depth) - 1)).astype(np.uint8)
+        assert np.array_equal(got, np.repeat(want[:, :, None], 3, 2))
+        plte = rng.integers(0, 256, (1 << depth, 3)).astype(np.uint8)
+        _png(path, w, h, depth, 3, rows, plte.tobytes())
+        assert np.array_equal(capi.image_read_rgb(path), plte[vals])
+    # the reference-held 8-bit grey z image decodes (it is a fixture of tests/test_reference_images.py)
+    assert capi.image_read_rgb(os.path.join(scenes.GOLD, "ref_prj13_boxzbuff.png")).shape == (600, 800, 3)
+    big = str(tmp_path / "big.png")
+    _png(big, 0x7FFFFFFF, 0x7FFFFFFF, 8, 2, [b"\0\0\0"])
+    with pytest.raises(capi.RtError):
+        capi.image_read_rgb(big)
+    for magic in (b"P5", b"X6", b"PX"):
+        ppm = str(tmp_path / "bad.ppm")
+        with open(ppm, "wb") as f:
+            f.write(magic + b"\n2 2\n255\n" + bytes(12))
+        with pytest.raises(capi.RtError):
+            capi.image_read_rgb(ppm)
+    ppm = str(tmp_path / "ok.ppm")
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n2 2\n255\n" + bytes(range(12)))
+    assert capi.image_read_rgb(ppm).ravel().tolist() == list(range(12))
