@@ -47,39 +47,12 @@ def parse():
     return ap.parse_args()
 
 
-def make_balls_scene(capi, width, height):
-    """SURVEY.md section 8 config C5 stand-in, written as OBJ + XML and loaded through the product's own loader."""
-    import tempfile
-    from tests import meshgen
-    d = tempfile.mkdtemp(prefix="rt_balls_")
-    va, fa = meshgen.balls_scene(n_balls=64, seed=1)              # 64 balls + the ground quad
-    vb, fb = meshgen.balls_scene(n_balls=64, seed=2)
-    vb, fb = vb[:-4], fb[:-2]                                     # the second group without a second ground
-    meshgen.write_obj(os.path.join(d, "balls_a.obj"), va, fa)
-    meshgen.write_obj(os.path.join(d, "balls_b.obj"), vb, fb)
-    with open(os.path.join(d, "scene.xml"), "w") as f:
-        f.write(f"""<xml><scene>
-  <background r="0.55" g="0.7" b="0.95"/><environment r="0.55" g="0.7" b="0.95"/>
-  <object type="obj" name="balls_a.obj" material="matte"/>
-  <object type="obj" name="balls_b.obj" material="mirror"/>
-  <material type="blinn" name="matte"><diffuse r="0.8" g="0.5" b="0.3"/><specular value="0.4"/><glossiness value="30"/></material>
-  <material type="blinn" name="mirror"><diffuse value="0.1"/><specular value="0.9"/><glossiness value="80"/><reflection value="0.8"/></material>
-  <light type="ambient" name="amb"><intensity value="0.2"/></light>
-  <light type="point" name="sun"><intensity value="1800"/><position x="10" y="-30" z="40"/></light>
-</scene><camera><position x="0" y="-52" z="20"/><target x="0" y="-4" z="3"/><up x="0" y="0" z="1"/>
-  <fov value="35"/><width value="{width}"/><height value="{height}"/></camera></xml>""")
-    s = capi.Scene()
-    s.load_xml(os.path.join(d, "scene.xml"))
-    return s, s.camera()
-
-
 def cpu_baseline(scene_export, balanced, cam, params, budget_s):
     """The oracle (single-threaded plain-C restatement of the reference's RenderPixel) on a seeded
     sample of 8x8-pixel blocks of the SAME workload, for about budget_s seconds."""
     from oracle import orc
-    from tests import scenes
-    osc = scenes.oracle_scene(scene_export, balanced)
-    ocam, op = scenes.oracle_camera(cam), scenes.oracle_params(params)
+    osc = orc.scene_from_export(scene_export, balanced)
+    ocam, op = orc.camera_from(cam), orc.params_from(params)
     rng = np.random.default_rng(7)
     bx, by = cam.width // 8, cam.height // 8
     order = rng.permutation(bx * by)
@@ -136,9 +109,8 @@ def main():
             time.sleep(2.0)
     import torch
     import torch.distributed as dist
-    from raytracing_folder_amd import capi, photons
+    from raytracing_folder_amd import capi, photons, workloads
     from raytracing_folder_amd.dist import ShardedRenderer
-    from tests import scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -164,9 +136,9 @@ def main():
     # ---- synthetic inputs, resident in HBM before anything is timed -------------------------
     balanced = None
     if a.workload == "balls":
-        s, cam = make_balls_scene(capi, a.width, a.height)
+        s, cam = workloads.make_balls_scene(a.width, a.height)
     else:
-        s, cam = scenes.load_cornell(a.width, a.height)
+        s, cam = workloads.load_cornell(a.width, a.height)
     if a.workload == "balls":
         pass
     elif a.synthetic_photons:

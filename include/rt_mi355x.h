@@ -228,6 +228,7 @@ rt_status rt_scene_set_materials(rt_scene *s, const rt_blinn *m, int32_t n);
 rt_status rt_scene_set_lights(rt_scene *s, const rt_light *l, int32_t n);
 /* environment / background colour (FIN/include/scene.h:406-434; textures: not yet) */
 rt_status rt_scene_set_environment(rt_scene *s, const float env_rgb[3], const float bg_rgb[3]);
+rt_status rt_scene_get_environment(const rt_scene *s, float env_rgb[3], float bg_rgb[3]);
 /* Texture store (replaces the TextureList global, FIN/main.cpp:46) and the maps of the colours the
  * render path samples: per material its diffuse and specular maps (MtlBlinn::Shade samples only
  * those two, FIN/main.cpp:531-532), the environment (SampleEnvironment, :635) and the background
@@ -322,13 +323,21 @@ rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt_params *p,
                           const rt_tile_range *tiles, int device,
                           uint8_t *rgb8, float *z, uint8_t *count, rt_job **out);
 /* Same, but the outputs are DEVICE pointers on `device` and the work is enqueued on
- * `hip_stream` (a hipStream_t, NULL = the library's own stream); only this call's tiles are
- * written.  Synchronous with respect to enqueueing; completion follows stream order unless
- * `sync` is non-zero. */
+ * `hip_stream` (a hipStream_t; NULL = the library's own non-blocking stream; to render in the order
+ * of the caller's legacy default stream pass hipStreamLegacy, i.e. (void *)1 -- NOT 0); only this
+ * call's tiles are written.  Synchronous with respect to enqueueing; completion follows stream
+ * order unless `sync` is non-zero.  A ray or photon query dropped by a full queue makes the image
+ * wrong: with `sync` != 0 the call then returns RT_ERR_LIMIT (with or without stats_out); after
+ * `sync` == 0 calls the verdict is collected by rt_render_check.  While an asynchronous render is
+ * still in flight the next call on the same (scene, device) -- on whatever stream -- is ordered
+ * behind it on the GPU. */
 rt_status rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_params *p,
                                  const rt_tile_range *tiles, int device, void *hip_stream,
                                  uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
                                  int sync, rt_stats *stats_out);
+/* Waits for the asynchronous renders (sync == 0) issued so far on (scene, device) and returns
+ * RT_ERR_LIMIT if any of them dropped rays or photon queries, RT_OK otherwise. */
+rt_status rt_render_check(rt_scene *s, int device);
 int       rt_render_progress(rt_job *j);      /* pixels finished so far (monotonic)       */
 rt_status rt_render_stop(rt_job *j);          /* cooperative cancel (StopRender)          */
 rt_status rt_render_wait(rt_job *j);          /* join; returns the job's final status     */

@@ -19,6 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("RT_REFERENCE", "/root/reference")
 GOLD = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "raytracing_folder_amd", "data")     # workload inputs the product ships (bench.py, smoke())
 HARNESS = {m: os.path.join(ROOT, "oracle", "_ref", f"ref_harness_{m}") for m in ("fin", "p13")}
 TEAPOT = os.path.join(REF, "RayTracingFinal", "RayTracingFinal", "data", "teapot.obj")
 
@@ -139,9 +140,9 @@ def gen_mesh(model):
                         **({"v": v, "f": f, "vn": vn, "fn": fn, "nodes": nodes, "elements": elements}
                            if model == "fin" else {}))
     if model == "fin":
-        write_tri_obj(os.path.join(GOLD, "teapot_tri.obj"), v, f, vn, fn)
+        write_tri_obj(os.path.join(DATA, "teapot_tri.obj"), v, f, vn, fn)
         # the triangulated export must load back to identical arrays through the reference loader
-        out2 = run(model, "mesh", struct.pack("<i", 0), os.path.join(GOLD, "teapot_tri.obj"))
+        out2 = run(model, "mesh", struct.pack("<i", 0), os.path.join(DATA, "teapot_tri.obj"))
         v2, f2, vn2, fn2, nodes2, el2, _ = parse_mesh(out2)
         assert (v2 == v).all() and (f2 == f).all() and (vn2 == vn).all() and (fn2 == fn).all()
         assert nodes2.tobytes() == nodes.tobytes() and (el2 == elements).all()

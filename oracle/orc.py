@@ -411,3 +411,30 @@ def sample_count_image(cnt):
     out = np.zeros(cnt.shape, np.uint8)
     smax = lib().orc_sample_count_image(_p(cnt), cnt.shape[1], cnt.shape[0], _p(out))
     return out, smax
+
+
+# ---- the product's exported arrays as oracle inputs (same bytes on both sides) -----------------------
+def scene_from_export(export, photons=None, env=None, bg=None):
+    """orc.Scene over the very arrays raytracing_folder_amd.capi.Scene.export() returns (environment and
+    background colours come from the export unless given)."""
+    env = tuple(export.get("env", (0, 0, 0))) if env is None else env
+    bg = tuple(export.get("bg", (0, 0, 0))) if bg is None else bg
+    meshes = [Mesh(m["v"], m["f"], m["vn"], m["fn"], m["nodes"], m["elements"], m.get("vt"), m.get("ft")) for m in export["meshes"]]
+    return Scene(export["nodes"], meshes, export["materials"], export["lights"], photons, env, bg,
+                 textures=export.get("textures"), texels=export.get("texels"),
+                 material_maps=export.get("material_maps"), env_map=export.get("env_map"),
+                 bg_map=export.get("bg_map"))
+
+
+def camera_from(cam):
+    oc = Camera()
+    for f, _ in Camera._fields_:
+        setattr(oc, f, getattr(cam, f))
+    return oc
+
+
+def params_from(p):
+    op = Params()
+    for f, _ in Params._fields_:
+        setattr(op, f, getattr(p, f))
+    return op

@@ -32,6 +32,7 @@ assert (NODE.itemsize, BVHNODE.itemsize, BLINN.itemsize, LIGHT.itemsize, PHOTON.
         TEXTURE.itemsize, TEXMAP.itemsize) == (100, 28, 88, 44, 24, 40, 88)
 TEX_FILE, TEX_CHECKER, MAP_NONE, MAP_EMPTY = 1, 2, -1, -2
 
+HIP_STREAM_LEGACY = 1          # hipStreamLegacy, hip_runtime_api.h
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3
 LIGHT_AMBIENT, LIGHT_DIRECT, LIGHT_POINT = 0, 1, 2
 SHADE_FIN, SHADE_P13, SHADE_P12, SHADE_P6, SHADE_P3 = 0, 1, 2, 3, 4
@@ -72,12 +73,12 @@ SYMBOLS = [
     "rt_abi_version", "rt_last_error", "rt_device_count", "rt_params_default",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_set_nodes", "rt_scene_set_mesh",
     "rt_scene_set_mesh_texcoords", "rt_scene_get_mesh_texcoords",
-    "rt_scene_set_materials", "rt_scene_set_lights", "rt_scene_set_environment",
+    "rt_scene_set_materials", "rt_scene_set_lights", "rt_scene_set_environment", "rt_scene_get_environment",
     "rt_scene_set_photons", "rt_scene_set_textures", "rt_scene_set_material_maps", "rt_scene_set_environment_maps",
     "rt_scene_get_textures", "rt_scene_get_maps", "rt_image_read_rgb", "rt_image_write_png", "rt_image_zbuffer", "rt_image_sample_count", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
     "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
     "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photons_write_dat", "rt_photons_read_dat", "rt_photon_pass", "rt_render_begin",
-    "rt_render_tiles_device", "rt_render_progress", "rt_render_stop", "rt_render_wait",
+    "rt_render_tiles_device", "rt_render_check", "rt_render_progress", "rt_render_stop", "rt_render_wait",
     "rt_job_stats", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
 ]
 
@@ -326,8 +327,10 @@ class Scene:
         maps, env_map, bg_map = np.zeros(2 * len(mats), TEXMAP), np.zeros(1, TEXMAP), np.zeros(1, TEXMAP)
         _check(lib().rt_scene_get_maps(self._h, _p(maps), len(maps), _p(env_map), _p(bg_map)))
         has_maps = bool(len(maps)) and bool((maps["tm"] != 0).any() or (maps["texture"] != 0).any())
+        env, bg = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        _check(lib().rt_scene_get_environment(self._h, _p(env), _p(bg)))
         return dict(nodes=nodes, materials=mats, lights=lights, meshes=meshes, textures=textures, texels=texels,
-                    material_maps=maps if has_maps else None, env_map=env_map, bg_map=bg_map)
+                    material_maps=maps if has_maps else None, env_map=env_map, bg_map=bg_map, env=env, bg=bg)
 
     # -- GPU work -------------------------------------------------------------------------------
     def trace_rays(self, rays, shade_model=SHADE_FIN, device=0):
@@ -378,12 +381,19 @@ class Scene:
             lib().rt_job_destroy(job)
         return rgb, z, cnt, st, progress
 
+    def render_check(self, device=0):
+        """Collect the verdict of the asynchronous renders issued so far (raises on dropped rays)."""
+        _check(lib().rt_render_check(self._h, int(device)))
+
     def render_tiles_device(self, cam, params, tiles, device, rgb_ptr, z_ptr, cnt_ptr, stream=None, sync=True,
                             want_stats=True):
-        """Render this call's tiles into DEVICE buffers (e.g. torch tensors' data_ptr())."""
+        """Render this call's tiles into DEVICE buffers (e.g. torch tensors' data_ptr()).
+        stream: None = the library's own stream; a hipStream_t handle otherwise -- 0 (what torch reports for
+        its default stream) means the legacy default stream and is passed as hipStreamLegacy."""
         st = Stats()
+        handle = None if stream is None else C.c_void_p(stream if stream else HIP_STREAM_LEGACY)
         _check(lib().rt_render_tiles_device(self._h, C.byref(cam), C.byref(params), C.byref(tiles), int(device),
-                                            C.c_void_p(stream) if stream else None, C.c_void_p(rgb_ptr),
+                                            handle, C.c_void_p(rgb_ptr),
                                             C.c_void_p(z_ptr), C.c_void_p(cnt_ptr), 1 if sync else 0,
                                             C.byref(st) if want_stats else None))
         return st

@@ -144,7 +144,11 @@ struct DeviceState {
     DevScene scene{};
     Workspace ws[RT_STREAMS];
     DevBuf stats;
-    std::atomic<int> busy{0};           // a render is using the working sets of this device
+    std::atomic<int> busy{0};           // a host call is using the working sets of this device
+    // an asynchronous render (sync == 0) returns while the GPU still uses the working sets, counters and
+    // stats: `last_done` is recorded at its join and every later call orders its own stream behind it
+    hipEvent_t last_done = nullptr;
+    bool last_pending = false;
     // scratch for the single-stage entry points
     DevBuf t_in, t_out[6];
     hipStream_t stream = nullptr;
@@ -157,7 +161,20 @@ struct DeviceState {
         for (int k = 0; k < 6; k++) t_out[k].release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
+        if (last_done) (void)hipEventDestroy(last_done);
+        last_done = nullptr; last_pending = false;
     }
+};
+
+// One host call at a time may use a device's working sets, scratch buffers, counters and stats: the render
+// entry points AND the single-stage ones (rt_trace_rays, rt_shade_rays, rt_estimate_irradiance, rt_photon_pass)
+// claim the device for their duration and fail with RT_ERR_STATE while another call (or a live job) holds it.
+struct DeviceClaim {
+    DeviceState *D; bool ok;
+    explicit DeviceClaim(DeviceState *d) : D(d), ok(d->busy.exchange(1) == 0) {}
+    ~DeviceClaim() { if (ok) D->busy.store(0); }
+    DeviceClaim(const DeviceClaim &) = delete;
+    DeviceClaim &operator=(const DeviceClaim &) = delete;
 };
 
 struct rt_scene {
@@ -315,6 +332,14 @@ extern "C" rt_status rt_scene_set_environment(rt_scene *s, const float env[3], c
     if (env) memcpy(s->data.env, env, 12);
     if (bg) memcpy(s->data.bg, bg, 12);
     s->invalidate(true, false);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_get_environment(const rt_scene *s, float env[3], float bg[3])
+{
+    if (!s) return fail(RT_ERR_ARG, "rt_scene_get_environment: scene is NULL");
+    if (env) memcpy(env, s->data.env, 12);
+    if (bg) memcpy(bg, s->data.bg, 12);
     return RT_OK;
 }
 
@@ -917,6 +942,10 @@ static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int 
     const unsigned long long lim = 1ull << 28;
     if (rq_cap > lim) rq_cap = lim;
     if (pq_cap > lim) pq_cap = lim;
+    if (const char *e = getenv("RT_QUEUE_CAP")) {          // tests only: force a small queue to exercise the overflow report
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 64) { rq_cap = std::min(rq_cap, v); pq_cap = std::min(pq_cap, v); }
+    }
     if (rq_cap < 64) rq_cap = 64;
     if (pq_cap < 64) pq_cap = 64;
     if ((st = w.sample_rgb.ensure(samples * 12))) return st;
@@ -947,6 +976,21 @@ static DevWork make_work(DeviceState *D, int slot)
     W.counts = (uint32_t *)w.counts.p; W.pixel_list = (uint32_t *)w.pixel_list.p;
     W.stats = (unsigned long long *)D->stats.p;
     return W;
+}
+
+// Work queued by an earlier asynchronous render still owns the working sets: order `st` behind it.
+static rt_status order_after_pending(DeviceState *D, hipStream_t st)
+{
+    if (D->last_pending && D->last_done) HIP_TRY(hipStreamWaitEvent(st, D->last_done, 0));
+    return RT_OK;
+}
+// Dropped rays / photon queries of the renders since the counter was last cleared (host-synchronous read).
+static rt_status read_overflow(DeviceState *D, unsigned long long *drops)
+{
+    *drops = 0;
+    if (!D->stats.p) return RT_OK;
+    HIP_TRY(hipMemcpy(drops, (unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 8, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 // camera set-up of RenderPixel, FIN/main.cpp:205-224 (tan in double, everything else float)
@@ -1038,10 +1082,12 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
     if (!rgb8_dev || !z_dev || !count_dev) return fail(RT_ERR_ARG, "render: output buffers are required");
     DeviceState *D = nullptr;
     if ((st = prepare_device(s, device, &D))) return st;
-    // one render at a time per (scene, device): the working sets are not shared between concurrent calls
-    if (D->busy.exchange(1)) return fail(RT_ERR_STATE, "render: another render of this scene is running on device %d", device);
-    struct BusyGuard { std::atomic<int> &b; ~BusyGuard() { b.store(0); } } busy_guard{D->busy};
+    // one host call at a time per (scene, device): the working sets are not shared between concurrent calls
+    DeviceClaim claim(D);
+    if (!claim.ok) return fail(RT_ERR_STATE, "render: another call on this scene is using device %d", device);
     hipStream_t stream = use_user_stream ? user_stream : D->stream;
+    if ((st = order_after_pending(D, stream))) return st;
+    if (!D->last_done) HIP_TRY(hipEventCreateWithFlags(&D->last_done, hipEventDisableTiming));
 
     DevCamera dc;
     camera_setup(*cam, dc);
@@ -1088,6 +1134,10 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
         HIP_TRY(hipMemsetAsync(Ws[0].stats, 0, ST_COUNT * 8, stream));
         HIP_TRY(hipEventCreate(&e_begin)); HIP_TRY(hipEventCreate(&e_end));
         HIP_TRY(hipEventRecord(e_begin, stream));
+    } else if (!D->last_pending) {
+        // the drop counter is read back after every synchronous render (below) and by rt_render_check after
+        // asynchronous ones; consecutive asynchronous renders accumulate into it until it is checked
+        HIP_TRY(hipMemsetAsync(Ws[0].stats + ST_QUEUE_OVERFLOW, 0, 8, stream));
     }
     // slot 0 runs on `stream` itself; the other slots' streams start after everything already queued on
     // `stream` (fork) and `stream` waits for them at the end (join), so the call keeps stream-order semantics
@@ -1178,7 +1228,19 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
         }
     }
     if (want_stats) HIP_TRY(hipEventRecord(e_end, stream));
-    if (sync || want_stats) HIP_TRY(hipStreamSynchronize(stream));
+    if (sync || want_stats) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        D->last_pending = false;
+        if (!want_stats) {
+            // a dropped ray or photon query means a wrong image: never RT_OK, whether or not statistics were asked for
+            unsigned long long drops = 0;
+            if ((st = read_overflow(D, &drops))) return st;
+            if (drops) return fail(RT_ERR_LIMIT, "render: a ray/photon queue overflowed (%llu drops); lower RT_CHUNK_SAMPLES or the bounce limit", drops);
+        }
+    } else {
+        HIP_TRY(hipEventRecord(D->last_done, stream));
+        D->last_pending = true;
+    }
     if (want_stats) {
         rt_stats R;
         memset(&R, 0, sizeof R);
@@ -1230,6 +1292,30 @@ extern "C" rt_status rt_render_tiles_device(rt_scene *s, const rt_camera *cam, c
     if (!s) return fail(RT_ERR_ARG, "rt_render_tiles_device: scene is NULL");
     return render_tiles(s, cam, p, tiles, device, (hipStream_t)hip_stream, hip_stream != nullptr, rgb8_dev, z_dev, count_dev,
                         sync != 0, stats_out, nullptr);
+}
+
+extern "C" rt_status rt_render_check(rt_scene *s, int device)
+{
+    if (!s) return fail(RT_ERR_ARG, "rt_render_check: scene is NULL");
+    DeviceState *D = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        for (DeviceState *d : s->devs) if (d->device == device) D = d;
+    }
+    if (!D) return RT_OK;                                    // nothing was ever rendered there
+    HIP_TRY(hipSetDevice(device));
+    DeviceClaim claim(D);
+    if (!claim.ok) return fail(RT_ERR_STATE, "rt_render_check: another call on this scene is using device %d", device);
+    if (D->last_pending && D->last_done) HIP_TRY(hipEventSynchronize(D->last_done));
+    D->last_pending = false;
+    unsigned long long drops = 0;
+    rt_status st = read_overflow(D, &drops);
+    if (st) return st;
+    if (drops) {
+        HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 0, 8));
+        return fail(RT_ERR_LIMIT, "rt_render_check: a ray/photon queue overflowed (%llu drops) in an asynchronous render", drops);
+    }
+    return RT_OK;
 }
 
 extern "C" rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles, int device,
@@ -1307,6 +1393,9 @@ extern "C" rt_status rt_trace_rays(rt_scene *s, int shade_model, int device, con
     rt_status st = prepare_device(s, device, &D);
     if (st) return st;
     if (n == 0) return RT_OK;
+    DeviceClaim claim(D);
+    if (!claim.ok) return fail(RT_ERR_STATE, "rt_trace_rays: another call on this scene is using device %d", device);
+    if ((st = order_after_pending(D, D->stream))) return st;
     const size_t sizes[6] = {(size_t)n, (size_t)n * 4, (size_t)n * 12, (size_t)n * 12, (size_t)n * 4, (size_t)n};
     if ((st = D->t_in.upload(rays, (size_t)n * 24))) return st;
     for (int k = 0; k < 6; k++) if ((st = D->t_out[k].ensure(sizes[k]))) return st;
@@ -1330,6 +1419,9 @@ extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, 
     if (st) return st;
     if (n == 0) return RT_OK;
     if (n > (1LL << 28)) return fail(RT_ERR_LIMIT, "rt_estimate_irradiance: too many queries");
+    DeviceClaim claim(D);
+    if (!claim.ok) return fail(RT_ERR_STATE, "rt_estimate_irradiance: another call on this scene is using device %d", device);
+    if ((st = order_after_pending(D, D->stream))) return st;
     if (!D->scene.pm.n_leaves) { memset(irr, 0, (size_t)n * 12); memset(dir, 0, (size_t)n * 12); return RT_OK; }
     std::vector<float4> qa((size_t)n), qb((size_t)n), qc((size_t)n);
     for (int64_t i = 0; i < n; i++) {
@@ -1370,6 +1462,9 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
     DeviceState *D = nullptr;
     if ((st = prepare_device(s, device, &D))) return st;
     if (n == 0) return RT_OK;
+    DeviceClaim claim(D);
+    if (!claim.ok) return fail(RT_ERR_STATE, "rt_shade_rays: another call on this scene is using device %d", device);
+    if ((st = order_after_pending(D, D->stream))) return st;
     const size_t limit = chunk_samples_limit();
     const size_t chunk = (size_t)std::min<int64_t>(n, (int64_t)limit);
     if ((st = ensure_workspace(D, 0, chunk, pv.bounce, 1))) return st;
@@ -1427,6 +1522,9 @@ extern "C" rt_status rt_photon_pass(rt_scene *s, int device, uint32_t max_photon
     bool have_source = false;
     for (const rt_light &l : s->data.lights) if (l.type == RT_LIGHT_POINT) have_source = true;
     if (!have_source) return fail(RT_ERR_STATE, "rt_photon_pass: the scene has no photon source (point light)");
+    DeviceClaim claim(D);
+    if (!claim.ok) return fail(RT_ERR_STATE, "rt_photon_pass: another call on this scene is using device %d", device);
+    if ((st = order_after_pending(D, D->stream))) return st;
     const uint32_t batch = 1u << 18;
     if ((st = D->t_out[0].ensure((size_t)batch * 8 * 9 * 4))) return st;
     if ((st = D->t_out[1].ensure((size_t)batch * 4))) return st;

@@ -4,43 +4,17 @@ import os
 import numpy as np
 
 from oracle import orc
-from raytracing_folder_amd import capi
+from raytracing_folder_amd import capi, workloads
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-CORNELL = os.path.join(GOLD, "cornell.xml")
+CORNELL = workloads.CORNELL_XML
 
 
-def load_cornell(width=None, height=None):
-    s = capi.Scene()
-    s.load_xml(CORNELL)
-    cam = s.camera()
-    if width:
-        cam.width, cam.height = int(width), int(height)
-    return s, cam
-
-
-def oracle_scene(export, photons=None, env=(0, 0, 0), bg=(0, 0, 0)):
-    """orc.Scene over the very arrays the product exports."""
-    meshes = [orc.Mesh(m["v"], m["f"], m["vn"], m["fn"], m["nodes"], m["elements"], m.get("vt"), m.get("ft")) for m in export["meshes"]]
-    return orc.Scene(export["nodes"], meshes, export["materials"], export["lights"], photons, env, bg,
-                     textures=export.get("textures"), texels=export.get("texels"),
-                     material_maps=export.get("material_maps"), env_map=export.get("env_map"),
-                     bg_map=export.get("bg_map"))
-
-
-def oracle_camera(cam):
-    oc = orc.Camera()
-    for f, _ in orc.Camera._fields_:
-        setattr(oc, f, getattr(cam, f))
-    return oc
-
-
-def oracle_params(p):
-    op = orc.Params()
-    for f, _ in orc.Params._fields_:
-        setattr(op, f, getattr(p, f))
-    return op
+load_cornell = workloads.load_cornell
+oracle_scene = orc.scene_from_export        # orc.Scene over the very arrays the product exports
+oracle_camera = orc.camera_from
+oracle_params = orc.params_from
 
 
 def identity_node(parent=-1, obj=capi.OBJ_NONE, material=-1, mesh=-1, scale=1.0, pos=(0, 0, 0)):
