@@ -10,8 +10,14 @@ box (FIN shading: direct light + reflection/refraction tree + k=400 photon gathe
 One step = one whole frame: every rank renders its interleaved 32x8 tiles (rank t mod N) with the
 scene and photon map already resident in HBM, then ONE all-gather (RCCL over xGMI) assembles the
 RenderImage on every rank.  value = rays actually traced by all ranks / max-over-ranks time.
-Prints one JSON line on rank 0 (see the task contract): roofline = the dominant kernel (photon
-gather), cpu_baseline = the plain-C oracle timed on a bounded tile sample (rank 0, N=1 only).
+Prints one JSON line on rank 0 (see the task contract).
+
+roofline: after the timed region the same frame is rendered --profile-frames more times with ONE chunk
+in flight (RT_STREAMS=1), so that the HIP-event intervals around each kernel class are exclusive kernel
+times; the line is quoted for the kernel that takes the most of them and says which of three ceilings
+that kernel sits closest to -- HBM bytes (PMC counters, profiles/), L2-side bytes (what the kernel asks
+its caches for), VALU issue slots (SQ counters, profiles/) -- see DESIGN.md section 6.
+cpu_baseline: the plain-C oracle timed on a bounded tile sample (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -26,6 +32,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+L2_PEAK_GBS = 34500.0        # aggregate L2 rate of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
+VALU_PEAK_GINST = 1024 * 2.4 / 2      # wave64 VALU instructions per ns: 256 CUs x 4 SIMD-32 at 2.4 GHz, 2 cycles each
+PARITY_NOTE = ("geometry half of RenderPixel pinned to the reference's own z images and compiled headers; "
+               "MtlBlinn::Shade, GenLight::Shadow, TraceNode and RenderPixel's loop are restated from main.cpp "
+               "(unbuildable here: needs GL/glut.h): Shade parity UNPINNED, GPU == oracle only")
 
 
 def parse():
@@ -40,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--synthetic-photons", action="store_true", help="wall-sprinkled photons instead of the GPU photon pass")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--profile-frames", type=int, default=2, help="frames of the RT_STREAMS=1 pass behind the timed region (0: no roofline)")
     ap.add_argument("--workload", choices=["cornell", "balls"], default="cornell",
                     help="cornell = the headline (BASELINE C4); balls = stand-in for the absent christmas_balls scene (C5): "
                          "128 tessellated spheres, 102 402 triangles, half of them mirrors, no photon map -- a BVH-bound "
@@ -48,50 +60,74 @@ def parse():
 
 
 def cpu_baseline(scene_export, balanced, cam, params, budget_s):
-    """The oracle (single-threaded plain-C restatement of the reference's RenderPixel) on a seeded
-    sample of 8x8-pixel blocks of the SAME workload, for about budget_s seconds."""
+    """The oracle (single-threaded plain-C restatement of the reference's RenderPixel) on a seeded sample of 8x8-pixel
+    blocks of the SAME workload.  Two legs: `value` = the work the reference really does (its 30 hemisphere rays per
+    primary hit are traced, shaded and thrown away, FIN/main.cpp:642-693); `pruned` = the same pixels without that
+    dead loop (what the GPU path computes)."""
     from oracle import orc
     osc = orc.scene_from_export(scene_export, balanced)
     ocam, op = orc.camera_from(cam), orc.params_from(params)
-    rng = np.random.default_rng(7)
     bx, by = cam.width // 8, cam.height // 8
-    order = rng.permutation(bx * by)
-    orc.counters_reset()
-    t0 = time.perf_counter()
-    blocks = 0
-    for b in order:
-        x0, y0 = (b % bx) * 8, (b // bx) * 8
-        orc.render(osc, ocam, op, x0, y0, x0 + 8, y0 + 8)
-        blocks += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    c = orc.counters()
-    rays = c["rays_primary"] + c["rays_shadow"] + c["rays_reflect"] + c["rays_refract"]
-    px = blocks * 64
-    return {"value": round(rays / dt / 1e6, 4), "unit": "Mray/s", "cores": 1, "kind": "port",
-            "sample": f"{blocks} seeded 8x8-pixel blocks ({px} px) of the same {cam.width}x{cam.height}x{params.max_sample}spp frame, "
-                      f"{dt:.1f} s, {rays} rays (the CPU path traces 4 identical shadow rays per light, the GPU 1)",
-            "px_per_s": round(px / dt, 2),
-            "frame_s_extrapolated": round(cam.width * cam.height / (px / dt), 1)}
+
+    def leg(discarded, budget):
+        rng = np.random.default_rng(7)
+        order = rng.permutation(bx * by)
+        orc.set_trace_discarded(discarded)
+        orc.counters_reset()
+        t0 = time.perf_counter()
+        blocks = 0
+        for b in order:
+            x0, y0 = (b % bx) * 8, (b // bx) * 8
+            orc.render(osc, ocam, op, x0, y0, x0 + 8, y0 + 8)
+            blocks += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        dt = time.perf_counter() - t0
+        c = orc.counters()
+        rays = c["rays_primary"] + c["rays_shadow"] + c["rays_reflect"] + c["rays_refract"] + orc.discarded_rays()
+        orc.set_trace_discarded(False)
+        px = blocks * 64
+        return {"Mray_s": round(rays / dt / 1e6, 4), "px_per_s": round(px / dt, 2), "blocks": blocks, "seconds": round(dt, 1),
+                "rays": int(rays), "frame_s_extrapolated": round(cam.width * cam.height / (px / dt), 1)}
+    full = leg(True, budget_s * 0.6)
+    pruned = leg(False, budget_s * 0.4)
+    return {"value": full["Mray_s"], "unit": "Mray/s", "cores": 1, "kind": "port",
+            "port_of": "RenderPixel as the reference executes it: incl. FIN's discarded 30-ray hemisphere loop at every primary hit "
+                       "(traced, shaded, dropped: FIN/main.cpp:642-693); same pixels as the GPU path",
+            "sample": f"{full['blocks']} seeded 8x8-pixel blocks of the same {cam.width}x{cam.height}x{params.max_sample}spp frame, "
+                      f"{full['seconds']} s, {full['rays']} rays (the CPU path traces 4 identical shadow rays per light, the GPU 1)",
+            "px_per_s": full["px_per_s"], "frame_s_extrapolated": full["frame_s_extrapolated"],
+            "pruned": {**pruned, "note": "the same port with the dead hemisphere loop skipped (what round 1 reported as the baseline)"},
+            "reference_measured": {"px_per_s": 159, "Mray_s": 0.135, "threads": 1,
+                                   "note": "the reference's own RenderPixel, FIN scene, 1 M photons, adaptive 4->8 spp, rows 400-407, "
+                                           "build container (BASELINE.md section 2) -- other sampling, other host: context only"}}
 
 
-def measured_traffic(kernel, default_workload):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_bench_pmc_hbm.json,
-    made by tools_profile_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-    command, with the gfx950 x2 fetch correction).  PMC counters cannot be read from inside bench.py, so the
-    figure is only quoted for the default workload it was measured on; otherwise null."""
+def profile_figures(default_workload):
+    """What cannot be read from inside bench.py -- HBM bytes (FETCH_SIZE / WRITE_SIZE) and VALU instructions (SQ_INSTS_VALU)
+    per launch -- from the newest committed counter summaries (profiles/*_bench_pmc_hbm.json, *_bench_sq_counters.json:
+    separate rocprofv3 --pmc passes of this very command, condensed by tools_profile_summary.py, gfx950 x2 fetch
+    correction applied).  Only quoted for the default workload they were measured on."""
     import glob
+    out = {"hbm": {}, "valu": {}, "hbm_source": None, "valu_source": None}
     if not default_workload:
-        return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_hbm.json")))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        return float(d["kernels"][kernel]["hbm_bytes_per_launch"]), os.path.basename(files[-1])
-    except Exception:
-        return None, None
+        return out
+    for key, pat in (("hbm", "*_bench_pmc_hbm.json"), ("valu", "*_bench_sq_counters.json")):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02" + pat)))
+        if not files:
+            continue
+        try:
+            d = json.load(open(files[-1]))
+            for k, v in d["kernels"].items():
+                name = k.split("<")[0]
+                if key == "hbm":
+                    out["hbm"][name] = float(v["hbm_bytes_per_launch"])
+                elif "SQ_INSTS_VALU" in v and v.get("avg_launch_us"):
+                    out["valu"][name] = float(v["SQ_INSTS_VALU"]) / (float(v["avg_launch_us"]) * 1e3) / VALU_PEAK_GINST
+            out[key + "_source"] = os.path.basename(files[-1])
+        except Exception:
+            pass
+    return out
 
 
 def main():
@@ -173,65 +209,113 @@ def main():
     keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "photon_queries", "photons_visited",
             "bvh_nodes_visited", "tris_tested", "instance_visits", "gather_rounds", "gather_slow", "gather_leaf_reads"]
     tot = {k: float(sum(x[k] for x in stats)) for k in keys}
-    ms = {k: float(sum(x[k] for x in stats)) for k in ("ms_trace", "ms_gather", "ms_resolve", "ms_total")}
-    launches_g = float(sum(x["launches_gather"] for x in stats))
-    vec = torch.tensor([dt] + [tot[k] for k in keys] + [ms["ms_gather"], ms["ms_trace"], launches_g], dtype=torch.float64,
-                       device="cpu" if rehearsal else "cuda")
+    gather_ms = float(sum(R.gather_ms)) / max(len(R.gather_ms), 1) if getattr(R, "gather_ms", None) else 0.0
+    vec = torch.tensor([dt, gather_ms] + [tot[k] for k in keys], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if world > 1:
         mx = vec.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        dt = float(mx[0])
+        dt, gather_ms = float(mx[0]), float(mx[1])
         for i, k in enumerate(keys):
-            tot[k] = float(vec[1 + i])
-        # roofline figures are quoted for rank 0's kernels
+            tot[k] = float(vec[2 + i])
     rays = tot["rays_primary"] + tot["rays_shadow"] + tot["rays_reflect"] + tot["rays_refract"]
 
+    # ---- roofline leg: the same frame with ONE chunk in flight, so that event intervals are exclusive kernel times.
+    # Every rank takes part (same number of renders everywhere); only rank 0's figures are quoted.
+    prof = []
+    if a.profile_frames > 0:
+        old_streams = os.environ.get("RT_STREAMS")
+        os.environ["RT_STREAMS"] = "1"
+        for _ in range(a.profile_frames):
+            prof.append(R.render_own_tiles(want_stats=True).as_dict())
+        if old_streams is None:
+            del os.environ["RT_STREAMS"]
+        else:
+            os.environ["RT_STREAMS"] = old_streams
+        barrier()
+
     if rank == 0:
-        my = {k: float(sum(x[k] for x in stats)) for k in keys}
-        # algorithmic bytes of the photon gather: 24 B query + 24 B result per query,
-        # 24 B (the reference's photon record) per photon examined
-        g_bytes = my["photon_queries"] * 48.0 + my["photons_visited"] * 24.0
-        g_gbs = g_bytes / (ms["ms_gather"] * 1e-3) / 1e9 if ms["ms_gather"] > 0 else 0.0
-        # algorithmic bytes of the trace+shade kernels: 48 B/ray + 84 B per object transform +
-        # 28 B per BVH node visit + 48 B per triangle test
-        my_rays = my["rays_primary"] + my["rays_shadow"] + my["rays_reflect"] + my["rays_refract"]
-        t_bytes = my_rays * 48.0 + my["instance_visits"] * 84.0 + my["bvh_nodes_visited"] * 28.0 + my["tris_tested"] * 48.0
-        t_gbs = t_bytes / (ms["ms_trace"] * 1e-3) / 1e9 if ms["ms_trace"] > 0 else 0.0
-        # Up to three chunks of a frame are in flight at once, so the per-stream event intervals of different
-        # kernels overlap in time and their sums no longer partition the frame; the roofline is quoted for the
-        # kernel class that moves the most algorithmic bytes (with RT_STREAMS=1, where intervals are exclusive,
-        # that is also the one taking the most time: profiles/r01d)
-        gather_dominant = g_bytes >= t_bytes
-        default_workload = (a.workload, a.width, a.height, a.spp, a.photons, a.synthetic_photons, world) == ("cornell", 1920, 1080, 64, 1000000, False, 1)
-        traffic, traffic_src = measured_traffic("k_gather", default_workload and gather_dominant)
-        roof = {"bound": "hbm", "kernel": "k_gather" if gather_dominant else "k_primary+k_bounce",
-                "achieved": round(g_gbs if gather_dominant else t_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round((g_gbs if gather_dominant else t_gbs) / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(g_bytes / max(launches_g, 1)) if gather_dominant else None,
-                "avg_launch_ms": round(ms["ms_gather"] / max(launches_g, 1), 4) if gather_dominant else None,
-                "launches": int(launches_g) if gather_dominant else int(sum(x["launches_trace"] for x in stats)),
-                # frac near or above 1 is not an accounting slip: the formula prices every photon examined at
-                # the reference's 24 B against the HBM peak, but the 34 MB photon structure is served from
-                # L2 / Infinity Cache (`traffic` = the HBM bytes actually moved per launch); the kernel is
-                # bound by the latency of the dependent chain inside a query
-                "note": ("photon structure is L2/MALL resident: see traffic; kernel is latency bound, not HBM bound" if gather_dominant else
-                         "scene (BVH, triangles, transforms) is L2 resident; achieved = algorithmic bytes of traversal / kernel time"),
-                "other": {"k_gather_GBps": round(g_gbs, 2), "trace_shade_GBps": round(t_gbs, 2),
-                          "ms_gather": round(ms["ms_gather"], 2), "ms_trace_shade": round(ms["ms_trace"], 2),
-                          "ms_resolve": round(ms["ms_resolve"], 3)}}
+        roof = None
+        if prof:
+            assert all(x["streams"] == 1 for x in prof)
+            n = float(len(prof))
+            P = {k: sum(float(x[k]) for x in prof) / n for k in prof[0]}          # per-frame averages of rank 0's share
+            figs = profile_figures((a.workload, a.width, a.height, a.spp, a.photons, a.synthetic_photons, world) ==
+                                   ("cornell", 1920, 1080, 64, 1000000, False, 1))
+            p_rays = P["rays_primary"] + P["rays_shadow"] + P["rays_reflect"] + P["rays_refract"]
+            classes = {
+                # algorithmic bytes: SURVEY.md section 8(d) / BASELINE.md section 3.4; l2 bytes: what the kernel asks its
+                # caches for in the DEVICE layout (rt_dev.h): 32-B photon slots, 64-B BVH nodes, 48-B triangles, 96-B node
+                # transforms, 64-B ray-queue records (written once, read once), 17 B/sample + 8 B/pixel in the resolve
+                "k_gather": {"ms": P["ms_gather"], "launches": P["launches_gather"],
+                             "alg": P["photon_queries"] * 48.0 + P["photons_visited"] * 24.0,
+                             "l2": P["photon_queries"] * 48.0 + P["gather_leaf_reads"] * 64.0 * 32.0},
+                "k_primary+k_bounce": {"ms": P["ms_primary"] + P["ms_bounce"], "launches": P["launches_primary"] + P["launches_bounce"],
+                                       "alg": p_rays * 48.0 + P["instance_visits"] * 84.0 + P["bvh_nodes_visited"] * 28.0 + P["tris_tested"] * 48.0,
+                                       "l2": (P["rays_reflect"] + P["rays_refract"]) * 128.0 + P["instance_visits"] * 96.0 +
+                                             P["bvh_nodes_visited"] * 64.0 + P["tris_tested"] * 48.0 + P["photon_queries"] * 48.0 + P["samples"] * 17.0},
+                "k_resolve": {"ms": P["ms_resolve"], "launches": P["launches_resolve"],
+                              "alg": P["pixels"] * 8.0, "l2": P["samples"] * 17.0 + P["pixels"] * 8.0},
+            }
+            exclusive_ms = sum(c["ms"] for c in classes.values())
+            table = {}
+            for name, c in classes.items():
+                sec = c["ms"] * 1e-3
+                row = {"ms_per_frame": round(c["ms"], 3), "launches_per_frame": round(c["launches"], 1),
+                       "share_of_kernel_time": round(c["ms"] / exclusive_ms, 3) if exclusive_ms > 0 else None,
+                       "algorithmic_GBps": round(c["alg"] / sec / 1e9, 1) if sec > 0 else None,
+                       "l2_GBps": round(c["l2"] / sec / 1e9, 1) if sec > 0 else None,
+                       "l2_frac": round(c["l2"] / sec / 1e9 / L2_PEAK_GBS, 4) if sec > 0 else None}
+                parts = name.split("+")
+                if all(q in figs["hbm"] for q in parts) and sec > 0:
+                    # PMC bytes are per launch of each kernel; launches per frame of each kernel from the stats
+                    per = {"k_gather": P["launches_gather"], "k_primary": P["launches_primary"], "k_bounce": P["launches_bounce"],
+                           "k_resolve": P["launches_resolve"]}
+                    hb = sum(figs["hbm"][q] * per[q] for q in parts)
+                    row["hbm_bytes_per_frame"] = int(hb)
+                    row["hbm_frac"] = round(hb / sec / 1e9 / HBM_PEAK_GBS, 4)
+                if all(q in figs["valu"] for q in parts):
+                    row["valu_frac"] = round(max(figs["valu"][q] for q in parts), 4)
+                table[name] = row
+            dom = max(classes, key=lambda k: classes[k]["ms"])
+            d, c = table[dom], classes[dom]
+            fr = {"hbm": d.get("hbm_frac"), "l2": d["l2_frac"], "valu": d.get("valu_frac")}
+            bound = max((k for k in fr if fr[k] is not None), key=lambda k: fr[k])
+            launches = max(c["launches"], 1.0)
+            sec_launch = c["ms"] * 1e-3 / launches
+            if bound == "hbm":
+                ach, peak, unit = d["hbm_bytes_per_frame"] / (c["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+            elif bound == "l2":
+                ach, peak, unit = d["l2_GBps"], L2_PEAK_GBS, "GB/s"
+            else:
+                ach, peak, unit = fr["valu"] * VALU_PEAK_GINST, VALU_PEAK_GINST, "Gwave-inst/s"
+            roof = {"kernel": dom, "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit, "frac": round(fr[bound], 4),
+                    "traffic": int(figs["hbm"][dom]) if dom in figs["hbm"] else None,
+                    "traffic_source": figs["hbm_source"], "valu_source": figs["valu_source"],
+                    "fractions": fr,
+                    "avg_launch_ms": round(sec_launch * 1e3, 4), "launches_per_frame": round(launches, 1),
+                    "timing": f"exclusive: {len(prof)} frame(s) with one chunk in flight (RT_STREAMS=1) after the timed region, HIP events on the "
+                              "launch stream; the timed region itself overlaps chunks on 3 streams",
+                    "exclusive_kernel_ms_per_frame": round(exclusive_ms, 2), "frame_ms_one_stream": round(P["ms_total"], 2),
+                    "algorithmic": {"bytes_per_launch": int(c["alg"] / launches), "GBps": d["algorithmic_GBps"],
+                                    "frac_of_hbm_peak": round(d["algorithmic_GBps"] / HBM_PEAK_GBS, 3),
+                                    "note": "SURVEY 8(d) formula (48 B/query + 24 B/photon examined; 48 B/ray + 84 B/instance + 28 B/node + 48 B/triangle): "
+                                            "it prices cache hits as bytes, so it is NOT an HBM rate -- the photon structure (34 MB) and the scene are "
+                                            "L2 / Infinity-Cache resident; see hbm_frac for what really crosses the fabric"},
+                    "kernels": table}
         out = {
             "metric": "Mray/s", "value": round(rays / dt / 1e6, 2), "unit": "Mray/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("C5 stand-in: 128 tessellated spheres (102 402 triangles, half mirrors) on a ground quad, FIN shading, "
-                                    f"{a.width}x{a.height}, {a.spp} spp fixed, no photon map, bounce 4") if a.workload == "balls" else
+            "config": {"workload": ("C5 stand-in: 128 tessellated spheres (102 402 triangles, half mirrors) on a ground quad under a PNG sky "
+                                    f"(environment + background), FIN shading, {a.width}x{a.height}, {a.spp} spp fixed, no photon map, bounce 4") if a.workload == "balls" else
                                    f"Cornell box, FIN shading, {a.width}x{a.height}, {a.spp} spp fixed, "
                                    f"{len(balanced) - 1}-photon map ({'sprinkled on the walls' if a.synthetic_photons else 'GPU photon pass, Philox seed 20171203, 8 bounces'}), "
                                    f"k=400 r=1, bounce 4",
                        "tiles": "32x8 interleaved, tile t -> rank t mod N", "exchange": "one all_gather of 8 B/pixel per frame"},
             "frame_ms": round(dt / a.steps * 1e3, 2),
+            "gather_ms": round(gather_ms, 3),
+            "parity_note": PARITY_NOTE,
             **({"rehearsal": "all ranks on device 0, gloo gather -- not a scaling measurement"} if rehearsal else {}),
             "rays_per_frame": {k: int(tot[k] / a.steps) for k in keys[:4]},
             "photon_queries_per_frame": int(tot["photon_queries"] / a.steps),
@@ -245,7 +329,6 @@ def main():
             # the gathered frame must equal what the tiles say: spot-check against rank 0's own tiles
             frgb, fz, fcnt = frame
             own = R.rgb.cpu() if rehearsal else R.rgb
-            t = 0                                    # tile 0 belongs to rank 0
             assert bool((frgb[:8, :32].cpu() == own[:8, :32].cpu()).all()), "gathered frame disagrees with rank 0's tile"
             out["gathered_frame_nonzero_fraction"] = round(float((fz.float() != 0).float().mean()), 4)
         print(json.dumps(out), flush=True)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef int rt_status;
 #define RT_OK               0
@@ -188,6 +188,15 @@ typedef struct rt_stats {
     uint64_t gather_rounds;         /* (query, trial radius) pairs processed by the gather          */
     uint64_t gather_slow;           /* of those, how many overflowed the LDS leaf list               */
     uint64_t gather_leaf_reads;     /* 64-photon leaf reads, all passes                              */
+    /* ABI 2: the trace+shade time by kernel (ms_trace = ms_primary + ms_bounce).  Every ms_* field is a sum
+     * of HIP-event intervals on the stream that ran the kernels.  With `streams` == 1 one chunk is in
+     * flight at a time and the intervals are EXCLUSIVE kernel times; with more, a kernel shares the GPU
+     * with the other chunks' kernels, the intervals overlap in time and their sum exceeds ms_total --
+     * do not divide bytes by them then (bench.py takes its roofline from a streams == 1 pass). */
+    double   ms_primary, ms_bounce;
+    uint64_t launches_primary, launches_bounce;
+    uint64_t streams;               /* chunks in flight at once during this call                     */
+    uint64_t peak_rays, peak_queries;   /* largest ray-queue level / photon-query count of any chunk */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;   /* opaque */
@@ -335,6 +344,21 @@ rt_status rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_par
                                  const rt_tile_range *tiles, int device, void *hip_stream,
                                  uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
                                  int sync, rt_stats *stats_out);
+/* Multi-GPU tile exchange (the reference shares one atomic pixel counter between its threads,
+ * FIN/main.cpp:71-78).  A rank renders its tiles first, first+stride, ... straight into the buffer it
+ * contributes to the all-gather: tile k of the call at packed_dev + k*tile_w*tile_h*8, pixels row-major
+ * inside the tile, one 8-byte record per pixel = {r, g, b, z as 4 little-endian bytes, count}; slots of a
+ * ragged tile that fall outside the image are zero.  rt_tiles_packed_size gives the bytes / tile count of
+ * a call.  rt_tiles_unpack_device turns the gathered buffer of `world` ranks (rank r's block of
+ * tiles_per_rank tiles at offset r, its tiles being r, r+world, ...) back into the three RenderImage
+ * planes with one small HIP kernel on `hip_stream` (stream-ordered, no host synchronisation). */
+rt_status rt_render_tiles_packed_device(rt_scene *s, const rt_camera *cam, const rt_params *p,
+                                        const rt_tile_range *tiles, int device, void *hip_stream,
+                                        void *packed_dev, uint64_t packed_bytes, int sync, rt_stats *stats_out);
+rt_status rt_tiles_packed_size(int32_t width, int32_t height, const rt_tile_range *tiles, uint64_t *bytes, int32_t *n_tiles);
+rt_status rt_tiles_unpack_device(int device, void *hip_stream, const void *gathered_dev, int32_t world, int32_t tiles_per_rank,
+                                 int32_t width, int32_t height, int32_t tile_w, int32_t tile_h,
+                                 uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev);
 /* Waits for the asynchronous renders (sync == 0) issued so far on (scene, device) and returns
  * RT_ERR_LIMIT if any of them dropped rays or photon queries, RT_OK otherwise. */
 rt_status rt_render_check(rt_scene *s, int device);

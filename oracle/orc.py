@@ -438,3 +438,13 @@ def params_from(p):
     for f, _ in Params._fields_:
         setattr(op, f, getattr(p, f))
     return op
+
+
+def set_trace_discarded(on):
+    """FIN's discarded hemisphere loop at primary hits: traced (and thrown away) like the reference, or skipped"""
+    lib().orc_set_trace_discarded(1 if on else 0)
+
+
+def discarded_rays():
+    lib().orc_discarded_rays.restype = C.c_uint64
+    return lib().orc_discarded_rays()

@@ -24,6 +24,11 @@
 #define RMAX(a,b) ((a)>(b)?(a):(b))
 
 static orc_counters g_cnt;
+/* FIN's discarded hemisphere loop (FIN/main.cpp:642-693): traced only on request, see shade_fin */
+static int g_trace_discarded = 0;
+static uint64_t g_discarded_rays = 0;
+void orc_set_trace_discarded(int on) { g_trace_discarded = on; g_discarded_rays = 0; }
+uint64_t orc_discarded_rays(void) { return g_discarded_rays; }
 void orc_counters_reset(void) { memset(&g_cnt, 0, sizeof g_cnt); }
 void orc_counters_get(orc_counters *out) { *out = g_cnt; }
 
@@ -818,7 +823,36 @@ static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6]
     if (bounceCount == P->bounce) {
         /* :642-693 -- HEMISPHERE_SAMPLE rays are traced and shaded, but the result is assigned
          * to a shadowing inner variable (:676) and the outer idrColor (:668) stays 0, so the
-         * block adds exactly 0.  Not traced here (SURVEY.md section 0 finding 2). */
+         * block adds exactly 0.  Not traced by default (SURVEY.md section 0 finding 2); with
+         * orc_set_trace_discarded(1) the rays ARE traced and shaded the way the reference spends
+         * its time on them (bench.py's cpu_baseline), and still thrown away. */
+        if (g_trace_discarded) {
+            v3 newz = v3p(hInfo->N);
+            v3 newx = vdot(newz, V3(1, 0, 0)) < 0.4 ? vcross(newz, V3(1, 0, 0)) : vcross(newz, V3(0, 0, 1));
+            newx = vnorm(newx);
+            v3 newy = vcross(newz, newx);
+            int Nofsample = P->hemisphere_sample;
+            const uint32_t me = g_rng.node;
+            for (int i = 0; i < Nofsample; i++) {
+                float u0, u1;
+                rng2(RNG_GI, (uint32_t)i, &u0, &u1);
+                float phi = (float)(2 * M_PI * (double)u0);
+                float cosphi = cosf(phi);
+                float ysquare = u1;
+                float sintheta = sqrtf(ysquare), costheta = sqrtf(1 - ysquare);
+                v3 hemis_dir = vnorm(vadd(vadd(vscale(newx, sintheta * cosphi), vscale(newy, sintheta * sinf(phi))), vscale(newz, costheta)));
+                if (vdot(hemis_dir, newz) < 0.0) continue;
+                float r[6], c[3];
+                orc_hit hh;
+                st3(r, p); st3(r + 3, vnorm(hemis_dir));
+                g_discarded_rays++;
+                if (orc_trace(s, P->shade_model, r, &hh)) {
+                    g_rng.node = child_node(me, 64u + (uint32_t)i);
+                    shade_fin(s, P, r, &hh, bounceCount - 1, c);         /* Shade(..., bounceCount-1, 1): result dropped */
+                    g_rng.node = me;
+                }
+            }
+        }
     } else {
         /* :695-705 */
         float irr[3], dir[3];

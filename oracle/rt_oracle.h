@@ -63,6 +63,10 @@ typedef struct orc_counters {
     uint64_t photon_queries, photons_visited;
 } orc_counters;
 
+/* 1: shade_fin traces and shades FIN's HEMISPHERE_SAMPLE rays at primary hits like the reference does, and
+ * discards them like the reference does (FIN/main.cpp:642-693) -- same pixels, the reference's cost */
+void  orc_set_trace_discarded(int on);
+uint64_t orc_discarded_rays(void);
 void  orc_counters_reset(void);
 void  orc_counters_get(orc_counters *out);
 

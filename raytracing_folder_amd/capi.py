@@ -62,7 +62,9 @@ class Stats(C.Structure):
                                            "photon_queries", "photons_visited", "pixels", "samples")] +
                 [(n, C.c_double) for n in ("ms_trace", "ms_gather", "ms_resolve", "ms_total")] +
                 [(n, C.c_uint64) for n in ("launches_trace", "launches_gather", "launches_resolve",
-                                           "gather_rounds", "gather_slow", "gather_leaf_reads")])
+                                           "gather_rounds", "gather_slow", "gather_leaf_reads")] +
+                [(n, C.c_double) for n in ("ms_primary", "ms_bounce")] +
+                [(n, C.c_uint64) for n in ("launches_primary", "launches_bounce", "streams", "peak_rays", "peak_queries")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -78,7 +80,7 @@ SYMBOLS = [
     "rt_scene_get_textures", "rt_scene_get_maps", "rt_image_read_rgb", "rt_image_write_png", "rt_image_zbuffer", "rt_image_sample_count", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
     "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
     "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photons_write_dat", "rt_photons_read_dat", "rt_photon_pass", "rt_render_begin",
-    "rt_render_tiles_device", "rt_render_check", "rt_render_progress", "rt_render_stop", "rt_render_wait",
+    "rt_render_tiles_device", "rt_render_tiles_packed_device", "rt_tiles_packed_size", "rt_tiles_unpack_device", "rt_render_check", "rt_render_progress", "rt_render_stop", "rt_render_wait",
     "rt_job_stats", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
 ]
 
@@ -175,6 +177,19 @@ def sample_count_image(cnt):
     smax = C.c_int32()
     _check(lib().rt_image_sample_count(_p(cnt), cnt.shape[1], cnt.shape[0], _p(out), C.byref(smax)))
     return out, smax.value
+
+
+def tiles_packed_size(width, height, tiles):
+    nbytes, n = C.c_uint64(), C.c_int32()
+    _check(lib().rt_tiles_packed_size(int(width), int(height), C.byref(tiles), C.byref(nbytes), C.byref(n)))
+    return nbytes.value, n.value
+
+
+def tiles_unpack_device(device, stream, gathered_ptr, world, tiles_per_rank, width, height, tile_w, tile_h, rgb_ptr, z_ptr, cnt_ptr):
+    """gathered packed tiles of `world` ranks -> RenderImage planes, one HIP kernel on `stream` (0 = legacy default)"""
+    handle = C.c_void_p(stream if stream else HIP_STREAM_LEGACY)
+    _check(lib().rt_tiles_unpack_device(int(device), handle, C.c_void_p(gathered_ptr), int(world), int(tiles_per_rank), int(width),
+                                        int(height), int(tile_w), int(tile_h), C.c_void_p(rgb_ptr), C.c_void_p(z_ptr), C.c_void_p(cnt_ptr)))
 
 
 def identity_map(texture=MAP_NONE):
@@ -380,6 +395,16 @@ class Scene:
         finally:
             lib().rt_job_destroy(job)
         return rgb, z, cnt, st, progress
+
+    def render_tiles_packed_device(self, cam, params, tiles, device, packed_ptr, packed_bytes, stream=None, sync=True,
+                                   want_stats=True):
+        """This call's tiles as packed 8-byte pixel records (the all-gather contribution of a rank), see the header."""
+        st = Stats()
+        handle = None if stream is None else C.c_void_p(stream if stream else HIP_STREAM_LEGACY)
+        _check(lib().rt_render_tiles_packed_device(self._h, C.byref(cam), C.byref(params), C.byref(tiles), int(device), handle,
+                                                   C.c_void_p(packed_ptr), C.c_uint64(int(packed_bytes)), 1 if sync else 0,
+                                                   C.byref(st) if want_stats else None))
+        return st
 
     def render_check(self, device=0):
         """Collect the verdict of the asynchronous renders issued so far (raises on dropped rays)."""

@@ -29,7 +29,8 @@ void rtk_launch_trace(hipStream_t, const DevScene &, int, const float *, long lo
 void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const float4 *, const float4 *, const uint32_t *,
                        uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint16_t *, uint32_t *);
 void rtk_launch_resolve(hipStream_t, const DevScene &, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
-                        float, float, int, const float *, uint8_t *, float *, uint8_t *, int);
+                        float, float, int, const float *, uint8_t *, float *, uint8_t *, void *, int);
+void rtk_launch_unpack_tiles(hipStream_t, const void *, int, int, int, int, int, int, uint8_t *, float *, uint8_t *);
 
 // k_gather is a persistent grid that pulls query batches from a counter: enough workgroups to fill
 // every CU at the kernel's occupancy (256 CUs x 5 resident workgroups of 4 waves)
@@ -1057,17 +1058,18 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
     HIP_TRY(hipMemsetAsync(W.counts, 0, (CNT_PHOTONQ + 1) * 4, st));
     if ((s = mark(-1))) return s;
     rtk_launch_primary(st, D->scene, W, P, W.rq[1], W.counts + 1, dc, dt, q0, npix, j0, ns, max_sample, mode, rays_dev, max_blocks);
+    if ((s = mark(0))) return s;
     // P6: a side ray is spawned when its refraction ray ARRIVES, one queue level later than a sibling
     // would be, so a path can take up to two levels per bounce
     const int max_level = P.shade_model == RT_SHADE_P6 ? 2 * P.bounce : P.bounce;
     for (int level = 1; level <= max_level && level < 15; level++)
         rtk_launch_bounce(st, D->scene, W, P, W.rq[level & 1], W.rq[(level + 1) & 1], W.counts + level + 1, level, max_blocks);
-    if ((s = mark(0))) return s;
+    if ((s = mark(1))) return s;
     if (D->scene.pm.n_leaves) {
         rtk_launch_gather(st, D->scene.pm, W.pq.qa, W.pq.qb, W.pq.qc, W.counts + CNT_PHOTONQ, W.pq.cap, P.knn_k, P.knn_radius,
                           W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, (uint16_t *)D->ws[slot].spill.p,
                           W.counts + CNT_GATHER_NEXT);
-        if ((s = mark(1))) return s;
+        if ((s = mark(2))) return s;
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1075,11 +1077,11 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
 
 static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles, int device,
                               hipStream_t user_stream, bool use_user_stream, uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
-                              bool sync, rt_stats *stats_out, rt_job *job)
+                              bool sync, rt_stats *stats_out, rt_job *job, void *packed_dev = nullptr)
 {
     rt_status st = validate_render(s, cam, p, tiles);
     if (st) return st;
-    if (!rgb8_dev || !z_dev || !count_dev) return fail(RT_ERR_ARG, "render: output buffers are required");
+    if (!packed_dev && (!rgb8_dev || !z_dev || !count_dev)) return fail(RT_ERR_ARG, "render: output buffers are required");
     DeviceState *D = nullptr;
     if ((st = prepare_device(s, device, &D))) return st;
     // one host call at a time per (scene, device): the working sets are not shared between concurrent calls
@@ -1198,7 +1200,7 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
             hipEvent_t r0 = nullptr, r1 = nullptr;
             if (want_stats) { HIP_TRY(hipEventCreate(&r0)); HIP_TRY(hipEventCreate(&r1)); HIP_TRY(hipEventRecord(r0, cs)); }
             rtk_launch_resolve(cs, D->scene, W, dc, dt, (uint32_t)q0, npix, p->min_sample, p->max_sample, p->threshold, inv_gamma, phase,
-                               D->scene.bg, rgb8_dev, z_dev, count_dev, 2048);
+                               D->scene.bg, rgb8_dev, z_dev, count_dev, packed_dev, 2048);
             if (want_stats) { HIP_TRY(hipEventRecord(r1, cs)); resolve_ev.emplace_back(r0, r1); }
             return RT_OK;
         };
@@ -1251,6 +1253,7 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
         R.tris_tested = hs[ST_TRIS]; R.photon_queries = hs[ST_PHOTON_QUERIES]; R.photons_visited = hs[ST_PHOTONS_VISITED];
         R.pixels = 0; R.samples = hs[ST_RAYS_PRIMARY];
         R.gather_rounds = hs[ST_GATHER_ROUNDS]; R.gather_slow = hs[ST_GATHER_SLOW]; R.gather_leaf_reads = hs[ST_GATHER_LEAF_READS];
+        R.peak_rays = hs[ST_PEAK_RAYS]; R.peak_queries = hs[ST_PEAK_QUERIES];
         // per-stream intervals between consecutive marks: with two chunks in flight a kernel shares the GPU
         // with the other stream's kernels, so these are durations under overlap (the same thing rocprofv3 reports)
         for (int sl = 0; sl < n_slots; sl++)
@@ -1258,8 +1261,13 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
                 if (tm[sl].cls[i] < 0) continue;
                 float ms = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, tm[sl].ev[i - 1], tm[sl].ev[i]));
-                if (tm[sl].cls[i] == 0) { R.ms_trace += ms; R.launches_trace++; } else { R.ms_gather += ms; R.launches_gather++; }
+                if (tm[sl].cls[i] == 0) { R.ms_primary += ms; R.launches_primary++; }
+                else if (tm[sl].cls[i] == 1) { R.ms_bounce += ms; R.launches_bounce += (uint64_t)std::max(0, std::min(p->shade_model == RT_SHADE_P6 ? 2 * p->bounce : p->bounce, 14)); }
+                else { R.ms_gather += ms; R.launches_gather++; }
             }
+        R.ms_trace = R.ms_primary + R.ms_bounce;
+        R.launches_trace = R.launches_primary + R.launches_bounce;
+        R.streams = (uint64_t)n_slots;
         for (auto &pr : resolve_ev) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
@@ -1292,6 +1300,50 @@ extern "C" rt_status rt_render_tiles_device(rt_scene *s, const rt_camera *cam, c
     if (!s) return fail(RT_ERR_ARG, "rt_render_tiles_device: scene is NULL");
     return render_tiles(s, cam, p, tiles, device, (hipStream_t)hip_stream, hip_stream != nullptr, rgb8_dev, z_dev, count_dev,
                         sync != 0, stats_out, nullptr);
+}
+
+extern "C" rt_status rt_render_tiles_packed_device(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles,
+                                                   int device, void *hip_stream, void *packed_dev, uint64_t packed_bytes,
+                                                   int sync, rt_stats *stats_out)
+{
+    if (!s) return fail(RT_ERR_ARG, "rt_render_tiles_packed_device: scene is NULL");
+    if (!packed_dev) return fail(RT_ERR_ARG, "rt_render_tiles_packed_device: the packed buffer is required");
+    rt_status st = validate_render(s, cam, p, tiles);
+    if (st) return st;
+    uint64_t need = 0;
+    if ((st = rt_tiles_packed_size(cam->width, cam->height, tiles, &need, nullptr))) return st;
+    if (packed_bytes < need) return fail(RT_ERR_ARG, "rt_render_tiles_packed_device: buffer of %llu bytes, this call's tiles need %llu",
+                                         (unsigned long long)packed_bytes, (unsigned long long)need);
+    return render_tiles(s, cam, p, tiles, device, (hipStream_t)hip_stream, hip_stream != nullptr, nullptr, nullptr, nullptr,
+                        sync != 0, stats_out, nullptr, packed_dev);
+}
+
+extern "C" rt_status rt_tiles_packed_size(int32_t width, int32_t height, const rt_tile_range *t, uint64_t *bytes, int32_t *n_tiles)
+{
+    if (!t || width <= 0 || height <= 0 || t->tile_w <= 0 || t->tile_h <= 0 || t->stride <= 0 || t->first < 0)
+        return fail(RT_ERR_ARG, "rt_tiles_packed_size: bad argument");
+    const int64_t tiles_x = (width + t->tile_w - 1) / t->tile_w, tiles_y = (height + t->tile_h - 1) / t->tile_h;
+    const int64_t total = tiles_x * tiles_y;
+    const int64_t n = t->first >= total ? 0 : (total - t->first + t->stride - 1) / t->stride;
+    if (bytes) *bytes = (uint64_t)n * (uint64_t)t->tile_w * (uint64_t)t->tile_h * 8ull;
+    if (n_tiles) *n_tiles = (int32_t)n;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_tiles_unpack_device(int device, void *hip_stream, const void *gathered_dev, int32_t world, int32_t tiles_per_rank,
+                                            int32_t width, int32_t height, int32_t tile_w, int32_t tile_h,
+                                            uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev)
+{
+    if (!gathered_dev || !rgb8_dev || !z_dev || !count_dev) return fail(RT_ERR_ARG, "rt_tiles_unpack_device: NULL buffer");
+    if (world <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0) return fail(RT_ERR_ARG, "rt_tiles_unpack_device: bad geometry");
+    const int64_t total = (int64_t)((width + tile_w - 1) / tile_w) * ((height + tile_h - 1) / tile_h);
+    if ((int64_t)tiles_per_rank * world < total || tiles_per_rank < (total + world - 1) / world)
+        return fail(RT_ERR_ARG, "rt_tiles_unpack_device: %d tiles per rank x %d ranks cannot hold %lld tiles", tiles_per_rank, world, (long long)total);
+    if (!device_is_gfx950(device)) return fail(RT_ERR_NO_DEVICE, "rt_tiles_unpack_device: device %d is not gfx950 (no CPU path)", device);
+    HIP_TRY(hipSetDevice(device));
+    rtk_launch_unpack_tiles((hipStream_t)hip_stream, gathered_dev, world, tiles_per_rank, width, height, tile_w, tile_h, rgb8_dev, z_dev, count_dev);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
 }
 
 extern "C" rt_status rt_render_check(rt_scene *s, int device)

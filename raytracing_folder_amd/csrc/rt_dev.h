@@ -152,7 +152,9 @@ static inline void tiles_prepare(DevTiles &t)
 enum {
     ST_RAYS_PRIMARY = 0, ST_RAYS_SHADOW, ST_RAYS_REFLECT, ST_RAYS_REFRACT,
     ST_INSTANCE_VISITS, ST_BVH_NODES, ST_TRIS, ST_PHOTON_QUERIES, ST_PHOTONS_VISITED,
-    ST_QUEUE_OVERFLOW, ST_GATHER_ROUNDS, ST_GATHER_SLOW, ST_GATHER_LEAF_READS, ST_COUNT
+    ST_QUEUE_OVERFLOW, ST_GATHER_ROUNDS, ST_GATHER_SLOW, ST_GATHER_LEAF_READS,
+    ST_PEAK_RAYS, ST_PEAK_QUERIES,      // largest ray-queue level / photon-query count any chunk produced (atomicMax)
+    ST_COUNT
 };
 
 // ray queue: structure of arrays of float4 (one 16-byte coalesced read per lane per array)

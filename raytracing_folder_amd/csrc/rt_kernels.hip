@@ -16,6 +16,7 @@
 // any-hit query; BVH boxes are culled against the closest hit so far.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include "rt_dev.h"
 
 #define BIGFLOAT 1.0e30f
@@ -1938,6 +1939,10 @@ struct ResolveArgs {
     float bg[3];
     DevScene S;                 // for the background map
     uint8_t *rgb8; float *z; uint8_t *count;
+    // packed output (multi-GPU tile exchange): pixel q of this call's tile walk (tile-major, row-major inside
+    // the tile) is ONE 8-byte record {r, g, b, z as 4 little-endian bytes, count} at packed + 8*q -- the very
+    // buffer a rank contributes to the all-gather, written here coalesced instead of being re-packed afterwards
+    uint2 *packed;
     int direct_mode;            // rt_shade_rays: no image, leave samples as they are
 };
 
@@ -1964,6 +1969,14 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
     const int lane = threadIdx.x & 63;
     const uint32_t npix = A.phase == 1 ? W.counts[CNT_PIXLIST] : A.npix;
     const uint32_t npix_round = (npix + 63u) & ~63u;            // whole waves take part in the staging
+    if (blockIdx.x == 0 && threadIdx.x == 0 && W.stats) {
+        // the queues of this pass are final by now (same stream): remember how full they got, so that the host
+        // can size them from what a scene really produces instead of the 2^bounce worst case
+        uint32_t pr = 0;
+        for (int l = 1; l < CNT_GATHER_NEXT; l++) pr = max(pr, W.counts[l]);
+        atomicMax(&W.stats[ST_PEAK_RAYS], (unsigned long long)pr);
+        atomicMax(&W.stats[ST_PEAK_QUERIES], (unsigned long long)W.counts[CNT_PHOTONQ]);
+    }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix_round; i += gridDim.x * blockDim.x) {
         const uint32_t i0 = i - (uint32_t)lane;                  // first pixel of this wave
         const bool staged = A.phase == 0 && i0 + 64u <= npix;    // wave-uniform
@@ -1971,6 +1984,8 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
         const uint32_t ql = in_range ? (A.phase == 1 ? W.pixel_list[i] : i) : 0u;
         int x = 0, y = 0;
         const bool valid = in_range && pixel_of(A.tiles, A.cam, A.q0 + ql, x, y);
+        // packed mode: slots of a ragged tile that lie outside the image are part of the exchanged buffer -> zero
+        if (A.packed && in_range && !valid && A.phase == 0) A.packed[(size_t)A.q0 + ql] = make_uint2(0u, 0u);
         if (!staged && !valid) continue;
         const size_t index = (size_t)y * A.cam.width + x;
         const float *rgb = W.sample_rgb + 3 * (size_t)ql * A.max_sample;
@@ -2029,18 +2044,26 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
         }
         if (!valid || over) continue;
         float g[3];
+        uint8_t cnt_byte = 0;
+        float zval = BIGFLOAT;
         if (n > 0) {
             g[0] = powf(c0, A.inv_gamma); g[1] = powf(c1, A.inv_gamma); g[2] = powf(c2, A.inv_gamma);
-            A.count[index] = (n <= A.min_sample) ? 0 : 255;
-            A.z[index] = hitz;
+            cnt_byte = (n <= A.min_sample) ? 0 : 255;
+            zval = hitz;
         } else {
             // background.Sample(Point3(x/W, y/H, 0)), FIN/main.cpp:326-328
             const V3 bgc = textured_color(A.S, ld3(A.bg), A.S.bg_map, mk((float)x / A.cam.width, (float)y / A.cam.height, 0));
             g[0] = powf(bgc.x, A.inv_gamma); g[1] = powf(bgc.y, A.inv_gamma); g[2] = powf(bgc.z, A.inv_gamma);
-            A.count[index] = 0;
-            A.z[index] = BIGFLOAT;
         }
-        A.rgb8[3 * index] = float_to_byte(g[0]); A.rgb8[3 * index + 1] = float_to_byte(g[1]); A.rgb8[3 * index + 2] = float_to_byte(g[2]);
+        const uint32_t r8 = float_to_byte(g[0]), g8 = float_to_byte(g[1]), b8 = float_to_byte(g[2]);
+        if (A.packed) {
+            const uint32_t zb = __float_as_uint(zval);
+            A.packed[(size_t)A.q0 + ql] = make_uint2(r8 | (g8 << 8) | (b8 << 16) | (zb << 24), (zb >> 8) | ((uint32_t)cnt_byte << 24));
+        } else {
+            A.count[index] = cnt_byte;
+            A.z[index] = zval;
+            A.rgb8[3 * index] = (uint8_t)r8; A.rgb8[3 * index + 1] = (uint8_t)g8; A.rgb8[3 * index + 2] = (uint8_t)b8;
+        }
     }
 }
 
@@ -2116,14 +2139,43 @@ void rtk_launch_gather(hipStream_t st, const DevPhotonMap &pm, const float4 *qa,
     hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(64 * RT_GATHER_WAVES), 0, st, G);
 }
 
+// Un-interleave an all-gathered frame: rank r contributed its tiles r, r+R, r+2R, ... as `per_rank` packed tiles of
+// tile_w*tile_h 8-byte pixel records (see ResolveArgs::packed); one thread per image pixel reads its record (8-byte
+// loads, contiguous along a tile row) and writes the three planes of the RenderImage.
+__global__ __launch_bounds__(256) void k_unpack_tiles(const uint2 *gathered, int world, int per_rank, int width, int height,
+                                                      int tile_w, int tile_h, int tiles_x, uint8_t *rgb8, float *z, uint8_t *count)
+{
+    const size_t n = (size_t)width * height;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * width);
+        const int tx = x / tile_w, ty = y / tile_h;
+        const int t = ty * tiles_x + tx;
+        const int r = t % world, k = t / world;
+        const uint2 v = gathered[((size_t)r * per_rank + k) * (size_t)(tile_w * tile_h) + (size_t)(y - ty * tile_h) * tile_w + (x - tx * tile_w)];
+        rgb8[3 * i] = (uint8_t)(v.x & 255u); rgb8[3 * i + 1] = (uint8_t)((v.x >> 8) & 255u); rgb8[3 * i + 2] = (uint8_t)((v.x >> 16) & 255u);
+        z[i] = __uint_as_float((v.x >> 24) | (v.y << 8));
+        count[i] = (uint8_t)(v.y >> 24);
+    }
+}
+
+void rtk_launch_unpack_tiles(hipStream_t st, const void *gathered, int world, int per_rank, int width, int height, int tile_w, int tile_h,
+                             uint8_t *rgb8, float *z, uint8_t *count)
+{
+    const int tiles_x = (width + tile_w - 1) / tile_w;
+    const size_t n = (size_t)width * height;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_unpack_tiles, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, (const uint2 *)gathered, world, per_rank, width, height,
+                       tile_w, tile_h, tiles_x, rgb8, z, count);
+}
+
 void rtk_launch_resolve(hipStream_t st, const DevScene &S, const DevWork &W, const DevCamera &cam, const DevTiles &tiles,
                         uint32_t q0, uint32_t npix, int min_sample, int max_sample, float threshold,
                         float inv_gamma, int phase, const float bg[3], uint8_t *rgb8, float *z,
-                        uint8_t *count, int max_blocks)
+                        uint8_t *count, void *packed, int max_blocks)
 {
     ResolveArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.min_sample = min_sample;
     A.max_sample = max_sample; A.threshold = threshold; A.inv_gamma = inv_gamma; A.phase = phase;
-    A.bg[0] = bg[0]; A.bg[1] = bg[1]; A.bg[2] = bg[2]; A.rgb8 = rgb8; A.z = z; A.count = count; A.direct_mode = 0; A.S = S;
+    A.bg[0] = bg[0]; A.bg[1] = bg[1]; A.bg[2] = bg[2]; A.rgb8 = rgb8; A.z = z; A.count = count; A.packed = (uint2 *)packed; A.direct_mode = 0; A.S = S;
     tiles_prepare(A.tiles);
     const int grid = grid_for(npix, 256, max_blocks);
     hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, st, W, A);

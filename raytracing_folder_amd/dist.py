@@ -77,7 +77,11 @@ def gather_frame(rgb, z, cnt, rank, world, tile_w=32, tile_h=8):
 
 
 class ShardedRenderer:
-    """One process per GPU: renders this rank's tiles into device tensors and gathers the frame."""
+    """One process per GPU: this rank's tiles are rendered straight into the buffer it contributes to the
+    all-gather (rt_render_tiles_packed_device: k_resolve writes the 8-byte pixel records tile by tile), ONE
+    all_gather_into_tensor moves them (RCCL over xGMI), and one small HIP kernel (rt_tiles_unpack_device)
+    un-interleaves the gathered tiles into the RenderImage planes -- no Python-side packing in the step.
+    `gather_ms` collects, per step, the time from the end of this rank's render to the finished frame."""
 
     def __init__(self, scene, cam, params, rank, world, device_index, tile_w=32, tile_h=8, host_gather=False):
         self.scene, self.cam, self.params = scene, cam, params
@@ -89,18 +93,46 @@ class ShardedRenderer:
         self.rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
         self.z = torch.zeros((h, w), dtype=torch.float32, device=dev)
         self.cnt = torch.zeros((h, w), dtype=torch.uint8, device=dev)
+        _, _, n = tile_grid(w, h, tile_w, tile_h)
+        self.per_rank = (n + world - 1) // world
+        # ranks whose share is one tile short leave the last slot zero: every rank contributes the same bytes
+        self.packed = torch.zeros((self.per_rank, tile_h, tile_w, BYTES_PER_PIXEL), dtype=torch.uint8, device=dev)
+        self.gathered = torch.zeros((world * self.per_rank, tile_h, tile_w, BYTES_PER_PIXEL), dtype=torch.uint8, device=dev)
+        self.gather_ms = []
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device_index).cuda_stream
 
     def render_own_tiles(self, want_stats=True):
+        """this rank's tiles into the image planes (single-GPU path, and the profiling leg of bench.py)"""
         tiles = capi.TileRange(self.tile_w, self.tile_h, self.rank, self.world)
-        stream = torch.cuda.current_stream(self.device_index).cuda_stream
         return self.scene.render_tiles_device(self.cam, self.params, tiles, self.device_index, self.rgb.data_ptr(),
-                                              self.z.data_ptr(), self.cnt.data_ptr(), stream=stream, sync=True,
+                                              self.z.data_ptr(), self.cnt.data_ptr(), stream=self._stream(), sync=True,
                                               want_stats=want_stats)
 
+    def render_own_tiles_packed(self, want_stats=True):
+        tiles = capi.TileRange(self.tile_w, self.tile_h, self.rank, self.world)
+        return self.scene.render_tiles_packed_device(self.cam, self.params, tiles, self.device_index, self.packed.data_ptr(),
+                                                     self.packed.numel(), stream=self._stream(), sync=True, want_stats=want_stats)
+
     def step(self):
-        st = self.render_own_tiles()
+        if self.world == 1:
+            st = self.render_own_tiles()
+            self.gather_ms.append(0.0)
+            return st, (self.rgb, self.z, self.cnt)
+        import time
+        st = self.render_own_tiles_packed()
+        t0 = time.perf_counter()
         if self.host_gather:
-            frame = gather_frame(self.rgb.cpu(), self.z.cpu(), self.cnt.cpu(), self.rank, self.world, self.tile_w, self.tile_h)
+            mine = self.packed.cpu()
+            gathered = torch.empty((self.world * self.per_rank,) + tuple(mine.shape[1:]), dtype=torch.uint8)
+            dist.all_gather_into_tensor(gathered, mine)
+            self.gathered.copy_(gathered)
         else:
-            frame = gather_frame(self.rgb, self.z, self.cnt, self.rank, self.world, self.tile_w, self.tile_h)
-        return st, frame
+            dist.all_gather_into_tensor(self.gathered, self.packed)     # rank r's tiles land in rows [r*per_rank, (r+1)*per_rank)
+        capi.tiles_unpack_device(self.device_index, self._stream(), self.gathered.data_ptr(), self.world, self.per_rank,
+                                 self.cam.width, self.cam.height, self.tile_w, self.tile_h,
+                                 self.rgb.data_ptr(), self.z.data_ptr(), self.cnt.data_ptr())
+        torch.cuda.synchronize(self.device_index)
+        self.gather_ms.append((time.perf_counter() - t0) * 1e3)
+        return st, (self.rgb, self.z, self.cnt)

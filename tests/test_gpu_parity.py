@@ -726,6 +726,49 @@ def test_async_device_renders_keep_stream_order(cornell, monkeypatch):
     assert (np.abs(rgb_copy.cpu().numpy().astype(int) - ref.astype(int)) <= 1).all()
 
 
+def test_packed_tile_render_and_hip_unpack_match_the_torch_reference():
+    """Multi-GPU step without Python packing: every "rank" (here one after the other on one GPU) renders its
+    interleaved tiles straight into its all-gather contribution; the packed bytes equal what the torch helper
+    packs from a plain render, and the HIP un-interleave of the gathered buffer equals the torch one -- ragged
+    frame (100 x 37: partial tiles on both edges), world sizes 1, 3 and 8 (more ranks than some rows of tiles)"""
+    import torch
+    from raytracing_folder_amd import dist as rtd
+    s, cam = scenes.load_cornell(100, 37)
+    s.set_photons(photons.synth_cornell_photon_map(4000, seed=6))
+    p = capi.default_params()
+    ref, zref, cref, _, _ = s.render(cam, p)
+    dev = torch.device("cuda", 0)
+    t_rgb, t_z, t_cnt = torch.from_numpy(ref).to(dev), torch.from_numpy(zref).to(dev), torch.from_numpy(cref).to(dev)
+    tx, ty, n = rtd.tile_grid(100, 37)
+    for world in (1, 3, 8):
+        per_rank = (n + world - 1) // world
+        gathered = torch.zeros((world, per_rank, 8, 32, 8), dtype=torch.uint8, device=dev)
+        for rank in range(world):
+            tiles = capi.TileRange(32, 8, rank, world)
+            nbytes, k = capi.tiles_packed_size(100, 37, tiles)
+            buf = torch.full((per_rank, 8, 32, 8), 77, dtype=torch.uint8, device=dev)      # stale bytes must all be overwritten
+            s.render_tiles_packed_device(cam, p, tiles, 0, buf.data_ptr(), nbytes, stream=None, sync=True, want_stats=False)
+            want = rtd.pack_own_tiles(t_rgb, t_z, t_cnt, rank, world)
+            got, exp = buf[:k].cpu().numpy(), want[:k].cpu().numpy()
+            assert (got[..., 3:] == exp[..., 3:]).all()                                     # z and count bytes: exact
+            assert (np.abs(got[..., :3].astype(int) - exp[..., :3].astype(int)) <= 1).all()  # colours: atomics' last ulp
+            if k < per_rank:
+                buf[k:] = 0
+            gathered[rank] = buf
+            with pytest.raises(capi.RtError):                                              # a buffer one byte short is refused
+                s.render_tiles_packed_device(cam, p, tiles, 0, buf.data_ptr(), nbytes - 1, stream=None, sync=True, want_stats=False)
+        o_rgb = torch.zeros_like(t_rgb); o_z = torch.zeros_like(t_z); o_cnt = torch.zeros_like(t_cnt)
+        capi.tiles_unpack_device(0, torch.cuda.current_stream().cuda_stream, gathered.data_ptr(), world, per_rank, 100, 37, 32, 8,
+                                 o_rgb.data_ptr(), o_z.data_ptr(), o_cnt.data_ptr())
+        torch.cuda.synchronize()
+        w_rgb, w_z, w_cnt = rtd.unpack_gathered(gathered, 100, 37, world)
+        assert (o_rgb == w_rgb).all() and (o_z == w_z).all() and (o_cnt == w_cnt).all()
+        assert (o_z.cpu().numpy() == zref).all() and (o_cnt.cpu().numpy() == cref).all()
+        assert (np.abs(o_rgb.cpu().numpy().astype(int) - ref.astype(int)) <= 1).all()
+    with pytest.raises(capi.RtError):                                                      # too few slots for the frame's tiles
+        capi.tiles_unpack_device(0, 0, gathered.data_ptr(), 8, 1, 100, 37, 32, 8, o_rgb.data_ptr(), o_z.data_ptr(), o_cnt.data_ptr())
+
+
 def test_queue_overflow_is_an_error_with_or_without_stats(monkeypatch):
     """A full ray / photon queue drops work, i.e. a wrong image: never RT_OK.  RT_QUEUE_CAP (a test hook) makes
     the queues tiny; the synchronous call fails with RT_ERR_LIMIT whether or not statistics are requested, the

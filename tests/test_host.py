@@ -21,12 +21,12 @@ def test_library_exports_every_declared_symbol():
     lib = capi.lib()
     for name in declared:
         assert getattr(lib, name)
-    assert lib.rt_abi_version() == 1
+    assert lib.rt_abi_version() == 2
 
 
 def test_struct_sizes_match_header():
     assert C.sizeof(capi.Camera) == 56 and C.sizeof(capi.Params) == 64
-    assert C.sizeof(capi.TileRange) == 16 and C.sizeof(capi.Stats) == 21 * 8
+    assert C.sizeof(capi.TileRange) == 16 and C.sizeof(capi.Stats) == 28 * 8
     p = capi.default_params()
     assert (p.min_sample, p.max_sample, p.bounce, p.knn_k, p.shadow_samples) == (4, 8, 4, 400, 4)
     assert p.threshold == np.float32(1e-3) and p.gamma == 2.2 and p.knn_radius == 1.0

@@ -37,9 +37,13 @@ def _ref(name):
 def _zimg_with(z, z_norm):
     """ComputeZBufferImage levels of `z` under the extrema of `z_norm` (the extrema of the reference's frame lie
     in 4-sample pixels): append the normalising frame's extrema as two extra pixels."""
-    fin = z_norm[z_norm != np.float32(1.0e30)]
+    big = np.float32(1.0e30)
+    fin = z_norm[z_norm != big]
     ext = np.array([fin.min(), fin.max()], np.float32)
-    both = np.concatenate([z.ravel(), ext]).reshape(1, -1)
+    # depths beyond those extrema are clipped onto them: the formula clamps their level to 0 / 255 anyway, and the
+    # frame's own extrema must not move
+    zc = np.where(z == big, big, np.clip(z, ext[0], ext[1])).astype(np.float32)
+    both = np.concatenate([zc.ravel(), ext]).reshape(1, -1)
     return capi.zbuffer_image(both)[0, :-2].reshape(z.shape)
 
 
