@@ -249,7 +249,7 @@ def main():
                 # transforms, 64-B ray-queue records (written once, read once), 17 B/sample + 8 B/pixel in the resolve
                 "k_gather": {"ms": P["ms_gather"], "launches": P["launches_gather"],
                              "alg": P["photon_queries"] * 48.0 + P["photons_visited"] * 24.0,
-                             "l2": P["photon_queries"] * 48.0 + P["gather_leaf_reads"] * 64.0 * 32.0},
+                             "l2": P["photon_queries"] * 48.0 + P["gather_leaf_reads"] * 32.0 * 32.0},      # 32-slot sub-leaf reads of 32-B slots
                 "k_primary+k_bounce": {"ms": P["ms_primary"] + P["ms_bounce"], "launches": P["launches_primary"] + P["launches_bounce"],
                                        "alg": p_rays * 48.0 + P["instance_visits"] * 84.0 + P["bvh_nodes_visited"] * 28.0 + P["tris_tested"] * 48.0,
                                        "l2": (P["rays_reflect"] + P["rays_refract"]) * 128.0 + P["instance_visits"] * 96.0 +

@@ -187,7 +187,7 @@ typedef struct rt_stats {
     uint64_t launches_trace, launches_gather, launches_resolve;
     uint64_t gather_rounds;         /* (query, trial radius) pairs processed by the gather          */
     uint64_t gather_slow;           /* of those, how many overflowed the LDS leaf list               */
-    uint64_t gather_leaf_reads;     /* 64-photon leaf reads, all passes                              */
+    uint64_t gather_leaf_reads;     /* 32-slot sub-leaf reads, all passes                            */
     /* ABI 2: the trace+shade time by kernel (ms_trace = ms_primary + ms_bounce).  Every ms_* field is a sum
      * of HIP-event intervals on the stream that ran the kernels.  With `streams` == 1 one chunk is in
      * flight at a time and the intervals are EXCLUSIVE kernel times; with more, a kernel shares the GPU
@@ -332,9 +332,9 @@ rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt_params *p,
                           const rt_tile_range *tiles, int device,
                           uint8_t *rgb8, float *z, uint8_t *count, rt_job **out);
 /* Same, but the outputs are DEVICE pointers on `device` and the work is enqueued on
- * `hip_stream` (a hipStream_t; NULL = the library's own non-blocking stream; to render in the order
- * of the caller's legacy default stream pass hipStreamLegacy, i.e. (void *)1 -- NOT 0); only this
- * call's tiles are written.  Synchronous with respect to enqueueing; completion follows stream
+ * `hip_stream` (an explicit hipStream_t; NULL = the library's own non-blocking stream, which is NOT
+ * ordered with the caller's legacy default stream -- a caller that works on the default stream must
+ * render under an explicit stream of its own and pass that); only this call's tiles are written.  Synchronous with respect to enqueueing; completion follows stream
  * order unless `sync` is non-zero.  A ray or photon query dropped by a full queue makes the image
  * wrong: with `sync` != 0 the call then returns RT_ERR_LIMIT (with or without stats_out); after
  * `sync` == 0 calls the verdict is collected by rt_render_check.  While an asynchronous render is

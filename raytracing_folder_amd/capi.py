@@ -32,7 +32,6 @@ assert (NODE.itemsize, BVHNODE.itemsize, BLINN.itemsize, LIGHT.itemsize, PHOTON.
         TEXTURE.itemsize, TEXMAP.itemsize) == (100, 28, 88, 44, 24, 40, 88)
 TEX_FILE, TEX_CHECKER, MAP_NONE, MAP_EMPTY = 1, 2, -1, -2
 
-HIP_STREAM_LEGACY = 1          # hipStreamLegacy, hip_runtime_api.h
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3
 LIGHT_AMBIENT, LIGHT_DIRECT, LIGHT_POINT = 0, 1, 2
 SHADE_FIN, SHADE_P13, SHADE_P12, SHADE_P6, SHADE_P3 = 0, 1, 2, 3, 4
@@ -126,6 +125,15 @@ def _c(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 
 
+def _stream_handle(stream):
+    if stream is None:
+        return None
+    if int(stream) == 0:
+        raise ValueError("stream handle 0 (torch's legacy default stream) cannot be named here: NULL means the library's own "
+                         "stream; use an explicit torch.cuda.Stream")
+    return C.c_void_p(int(stream))
+
+
 def default_params(**kw):
     p = Params()
     lib().rt_params_default(C.byref(p))
@@ -186,8 +194,9 @@ def tiles_packed_size(width, height, tiles):
 
 
 def tiles_unpack_device(device, stream, gathered_ptr, world, tiles_per_rank, width, height, tile_w, tile_h, rgb_ptr, z_ptr, cnt_ptr):
-    """gathered packed tiles of `world` ranks -> RenderImage planes, one HIP kernel on `stream` (0 = legacy default)"""
-    handle = C.c_void_p(stream if stream else HIP_STREAM_LEGACY)
+    """gathered packed tiles of `world` ranks -> RenderImage planes, one HIP kernel on `stream` (an explicit stream's
+    handle; None = the null stream of the device)"""
+    handle = _stream_handle(stream)
     _check(lib().rt_tiles_unpack_device(int(device), handle, C.c_void_p(gathered_ptr), int(world), int(tiles_per_rank), int(width),
                                         int(height), int(tile_w), int(tile_h), C.c_void_p(rgb_ptr), C.c_void_p(z_ptr), C.c_void_p(cnt_ptr)))
 
@@ -400,7 +409,7 @@ class Scene:
                                    want_stats=True):
         """This call's tiles as packed 8-byte pixel records (the all-gather contribution of a rank), see the header."""
         st = Stats()
-        handle = None if stream is None else C.c_void_p(stream if stream else HIP_STREAM_LEGACY)
+        handle = _stream_handle(stream)
         _check(lib().rt_render_tiles_packed_device(self._h, C.byref(cam), C.byref(params), C.byref(tiles), int(device), handle,
                                                    C.c_void_p(packed_ptr), C.c_uint64(int(packed_bytes)), 1 if sync else 0,
                                                    C.byref(st) if want_stats else None))
@@ -413,10 +422,12 @@ class Scene:
     def render_tiles_device(self, cam, params, tiles, device, rgb_ptr, z_ptr, cnt_ptr, stream=None, sync=True,
                             want_stats=True):
         """Render this call's tiles into DEVICE buffers (e.g. torch tensors' data_ptr()).
-        stream: None = the library's own stream; a hipStream_t handle otherwise -- 0 (what torch reports for
-        its default stream) means the legacy default stream and is passed as hipStreamLegacy."""
+        stream: None = the library's own stream; otherwise the handle of an EXPLICIT hipStream_t.  0 -- what torch
+        reports for its legacy default stream -- is refused: through this argument NULL means "the library's
+        stream", so work on the default stream would silently not be ordered with the render; run the caller's
+        side under a torch.cuda.Stream and pass its handle (raytracing_folder_amd.dist does)."""
         st = Stats()
-        handle = None if stream is None else C.c_void_p(stream if stream else HIP_STREAM_LEGACY)
+        handle = _stream_handle(stream)
         _check(lib().rt_render_tiles_device(self._h, C.byref(cam), C.byref(params), C.byref(tiles), int(device),
                                             handle, C.c_void_p(rgb_ptr),
                                             C.c_void_p(z_ptr), C.c_void_p(cnt_ptr), 1 if sync else 0,

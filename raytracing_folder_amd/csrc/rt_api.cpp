@@ -27,7 +27,7 @@ void rtk_launch_bounce(hipStream_t, const DevScene &, const DevWork &, const rt_
                        const DevRayQueue &, uint32_t *, int, int);
 void rtk_launch_trace(hipStream_t, const DevScene &, int, const float *, long long, uint8_t *, float *, float *, float *, int32_t *, uint8_t *);
 void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const float4 *, const float4 *, const uint32_t *,
-                       uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint16_t *, uint32_t *);
+                       uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint32_t *);
 void rtk_launch_resolve(hipStream_t, const DevScene &, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
                         float, float, int, const float *, uint8_t *, float *, uint8_t *, void *, int);
 void rtk_launch_unpack_tiles(hipStream_t, const void *, int, int, int, int, int, int, uint8_t *, float *, uint8_t *);
@@ -123,12 +123,12 @@ struct DevMeshBufs { DevBuf nodes, tris, tri_face, nrm, tex; };
 // the latency of one ray's path) overlap the wide launches of the other.
 #define RT_STREAMS 4                    /* slots compiled in; render_streams() says how many are used */
 struct Workspace {
-    DevBuf sample_rgb, sample_z, sample_hit, rq[2][5], pq[3], counts, pixel_list, spill;
+    DevBuf sample_rgb, sample_z, sample_hit, rq[2][5], pq[3], counts, pixel_list;
     size_t samples = 0; uint32_t rq_cap = 0, pq_cap = 0;
     hipStream_t stream = nullptr;       // slot 0 runs on the caller's / the device's main stream instead
     void release()
     {
-        for (DevBuf *b : {&sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &spill}) b->release();
+        for (DevBuf *b : {&sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list}) b->release();
         for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) rq[i][k].release();
         for (int k = 0; k < 3; k++) pq[k].release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -141,7 +141,7 @@ struct DeviceState {
     bool scene_valid = false, photons_valid = false;
     DevBuf nodes, objects, meshes, materials, lights, node_material, textures, texels, material_maps;
     std::vector<DevMeshBufs> mesh_bufs;
-    DevBuf pa, pb, tbox, grid;
+    DevBuf pa, pb, tbox, sbox, grid;
     DevScene scene{};
     Workspace ws[RT_STREAMS];
     DevBuf stats;
@@ -155,7 +155,7 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     void release()
     {
-        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &tbox, &grid,
+        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &tbox, &sbox, &grid,
                           &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
         for (Workspace &w : ws) w.release();
@@ -802,8 +802,9 @@ struct PRec { float pos[3], dir[3], maxp; uint32_t color; };
 
 // Gather structure: the photons LocatePhotons can reach (it descends only while index <
 // halfStoredPhotons = n/2 - 1, cyPhotonMap.h:217,371, so indices >= 2*half are never visited)
-// re-sorted by recursive median splits into 2^D leaves of <= 64 photons, with the tight box of
-// every subtree in heap order.
+// re-sorted by recursive median splits into 2^D sub-leaves of <= 32 photons with their tight boxes
+// (sbox); every four consecutive sub-leaves are one leaf of the tree the queries walk, whose
+// subtree boxes are kept in heap order (tbox).
 static rt_status upload_photons(rt_scene *s, DeviceState *D)
 {
     DevPhotonMap &pm = D->scene.pm;
@@ -828,20 +829,22 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D)
         r.color = (uint32_t)p.color[0] | ((uint32_t)p.color[1] << 8) | ((uint32_t)p.color[2] << 16);
     }
     uint32_t n_leaves = 1;
-    while ((size_t)n_leaves * RT_LEAF_PHOTONS < recs.size()) n_leaves <<= 1;
-    if (n_leaves > 65536) return fail(RT_ERR_LIMIT, "photon map too large for the gather structure (%zu photons)", recs.size());
-    std::vector<float> tbox(6 * 2 * (size_t)n_leaves);
-    std::vector<float4> pa((size_t)n_leaves * RT_LEAF_PHOTONS), pb(pa.size());
+    while ((size_t)n_leaves * RT_LEAF_SUBS * RT_SUB_PHOTONS < recs.size()) n_leaves <<= 1;
+    // leaf ids travel as 16-bit values through the kernel's LDS lists
+    if (n_leaves > 65536) return fail(RT_ERR_LIMIT, "photon map too large for the gather structure (%zu photons, at most 8 Mi)", recs.size());
+    const uint32_t n_sub = n_leaves * RT_LEAF_SUBS;
+    std::vector<float> hbox(6 * 2 * (size_t)n_sub);                     // boxes of the whole heap down to the sub-leaves
+    std::vector<float4> pa((size_t)n_sub * RT_SUB_PHOTONS), pb(pa.size());
     for (size_t i = 0; i < pa.size(); i++) { pa[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0); pb[i] = make_float4(0, 0, 0, 0); }
     struct Build {
-        std::vector<PRec> &r; std::vector<float> &tbox; std::vector<float4> &pa, &pb; uint32_t n_leaves;
+        std::vector<PRec> &r; std::vector<float> &hbox; std::vector<float4> &pa, &pb; uint32_t n_sub;
         void go(uint32_t node, size_t lo, size_t hi)
         {
-            float *b = &tbox[6 * (size_t)node];
+            float *b = &hbox[6 * (size_t)node];
             b[0] = b[1] = b[2] = 3.0e38f; b[3] = b[4] = b[5] = -3.0e38f;
             for (size_t i = lo; i < hi; i++) for (int a = 0; a < 3; a++) { b[a] = std::min(b[a], r[i].pos[a]); b[3 + a] = std::max(b[3 + a], r[i].pos[a]); }
-            if (node >= n_leaves) {
-                const size_t base = (size_t)(node - n_leaves) * RT_LEAF_PHOTONS;
+            if (node >= n_sub) {
+                const size_t base = (size_t)(node - n_sub) * RT_SUB_PHOTONS;
                 for (size_t i = lo; i < hi; i++) {
                     const PRec &q = r[i];
                     pa[base + (i - lo)] = make_float4(q.pos[0], q.pos[1], q.pos[2], q.dir[0]);
@@ -860,13 +863,17 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D)
             go(2 * node, lo, mid);
             go(2 * node + 1, mid, hi);
         }
-    } B{recs, tbox, pa, pb, n_leaves};
+    } B{recs, hbox, pa, pb, n_sub};
     B.go(1, 0, recs.size());
+    // heap node ids of a complete binary tree do not depend on its depth: the first 2*n_leaves boxes ARE the tree
+    // over the leaves, the last n_sub ones the sub-leaf boxes
+    const std::vector<float> tbox(hbox.begin(), hbox.begin() + 6 * 2 * (size_t)n_leaves);
     rt_status st;
     if ((st = D->pa.upload(pa.data(), pa.size() * sizeof(float4)))) return st;
     if ((st = D->pb.upload(pb.data(), pb.size() * sizeof(float4)))) return st;
     if ((st = D->tbox.upload(tbox.data(), tbox.size() * 4))) return st;
-    pm.pa = (const float4 *)D->pa.p; pm.pb = (const float4 *)D->pb.p; pm.tbox = (const float *)D->tbox.p;
+    if ((st = D->sbox.upload(&hbox[6 * (size_t)n_sub], 6 * (size_t)n_sub * 4))) return st;
+    pm.pa = (const float4 *)D->pa.p; pm.pb = (const float4 *)D->pb.p; pm.tbox = (const float *)D->tbox.p; pm.sbox = (const float *)D->sbox.p;
     pm.n_leaves = n_leaves; pm.n_photons = (uint32_t)recs.size();
     {   // density grid over the photons' bounding box, at most 64 cells along the longest axis
         const float *rb = &tbox[6];
@@ -956,8 +963,6 @@ static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int 
     for (int k = 0; k < 3; k++) if ((st = w.pq[k].ensure((size_t)pq_cap * 16))) return st;
     if ((st = w.counts.ensure(CNT_TOTAL * 4))) return st;
     if ((st = w.pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
-    // gather spill lists: one per wave of the gather grid (GATHER_BLOCKS x RT_GATHER_WAVES), n_leaves ids each
-    if ((st = w.spill.ensure((size_t)GATHER_BLOCKS * RT_GATHER_WAVES * std::max<uint32_t>(D->scene.pm.n_leaves, 1u) * sizeof(uint16_t)))) return st;
     if (!D->stats.p) { if ((st = D->stats.ensure(ST_COUNT * 8))) return st; }
     if (slot > 0 && !w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     w.samples = samples; w.rq_cap = (uint32_t)rq_cap; w.pq_cap = (uint32_t)pq_cap;
@@ -1055,7 +1060,7 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
     };
     rt_status s;
     // queue counters for levels 0..15 and the photon queue are reset; the pixel list count survives
-    HIP_TRY(hipMemsetAsync(W.counts, 0, (CNT_PHOTONQ + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(W.counts, 0, CNT_RESET * 4, st));
     if ((s = mark(-1))) return s;
     rtk_launch_primary(st, D->scene, W, P, W.rq[1], W.counts + 1, dc, dt, q0, npix, j0, ns, max_sample, mode, rays_dev, max_blocks);
     if ((s = mark(0))) return s;
@@ -1067,8 +1072,7 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
     if ((s = mark(1))) return s;
     if (D->scene.pm.n_leaves) {
         rtk_launch_gather(st, D->scene.pm, W.pq.qa, W.pq.qb, W.pq.qc, W.counts + CNT_PHOTONQ, W.pq.cap, P.knn_k, P.knn_radius,
-                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, (uint16_t *)D->ws[slot].spill.p,
-                          W.counts + CNT_GATHER_NEXT);
+                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, W.counts + CNT_GATHER_NEXT);
         if ((s = mark(2))) return s;
     }
     HIP_TRY(hipGetLastError());
@@ -1120,7 +1124,7 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
             const size_t first = D->ws[0].sample_rgb.bytes + D->ws[0].sample_z.bytes + D->ws[0].sample_hit.bytes + 10 * D->ws[0].rq[0][0].bytes +
-                                 3 * D->ws[0].pq[0].bytes + D->ws[0].spill.bytes;
+                                 3 * D->ws[0].pq[0].bytes;
             if (free_b < first + first / 4 + (total_b >> 3)) break;
         }
         if ((st = ensure_workspace(D, i, (size_t)ppc * p->max_sample, p->bounce, (size_t)ppc,
@@ -1481,17 +1485,16 @@ extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, 
         qb[i] = make_float4(normal[3 * i + 1], normal[3 * i + 2], 0, 0);
         qc[i] = make_float4(0, 0, 0, 0);
     }
-    const uint32_t cnt[2] = {(uint32_t)n, 0u};            // query count, work counter
+    const uint32_t cnt[9] = {(uint32_t)n, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};     // query count, the eight work counters
     if ((st = D->t_out[0].upload(qa.data(), (size_t)n * 16))) return st;
     if ((st = D->t_out[1].upload(qb.data(), (size_t)n * 16))) return st;
     if ((st = D->t_out[2].upload(qc.data(), (size_t)n * 16))) return st;
     if ((st = D->t_out[3].ensure((size_t)n * 12))) return st;
     if ((st = D->t_out[4].ensure((size_t)n * 12))) return st;
-    if ((st = D->t_in.upload(cnt, 8))) return st;
-    if ((st = D->ws[0].spill.ensure((size_t)GATHER_BLOCKS * RT_GATHER_WAVES * D->scene.pm.n_leaves * sizeof(uint16_t)))) return st;
+    if ((st = D->t_in.upload(cnt, sizeof cnt))) return st;
     rtk_launch_gather(D->stream, D->scene.pm, (const float4 *)D->t_out[0].p, (const float4 *)D->t_out[1].p, (const float4 *)D->t_out[2].p,
                       (const uint32_t *)D->t_in.p, cnt[0], k, radius, nullptr, (float *)D->t_out[3].p, (float *)D->t_out[4].p, 1, nullptr, GATHER_BLOCKS,
-                      (uint16_t *)D->ws[0].spill.p, (uint32_t *)D->t_in.p + 1);
+                      (uint32_t *)D->t_in.p + 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(D->stream));
     HIP_TRY(hipMemcpy(irr, D->t_out[3].p, (size_t)n * 12, hipMemcpyDeviceToHost));

@@ -13,10 +13,11 @@
 //                                      leaf's triangles are contiguous
 //              tri_face[ ]             face id per leaf-ordered triangle (read on accepted hits)
 //              nrm[ ]                  36 B per face: the three vertex normals (read once per ray)
-//   photons    DevPhoton slots in leaf-major order, 64 slots per leaf (padded with +inf
-//              positions), pa = (pos.xyz, dir.x), pb = (dir.y, dir.z, maxPower, power.r),
-//              pc = (power.g, power.b); tbox = heap-ordered boxes of the complete binary tree
-//              over the leaves (root = 1, leaves at [n_leaves, 2 n_leaves))
+//   photons    slots in sub-leaf-major order, 32 slots per SUB-LEAF (padded with +inf positions),
+//              pa = (pos.xyz, dir.x), pb = (dir.y, dir.z, maxPower, colour bytes); sbox = tight box
+//              of every sub-leaf; four consecutive sub-leaves (128 slots, two median splits apart)
+//              form a LEAF of the tree the queries walk: tbox = heap-ordered boxes of the complete
+//              binary tree over the leaves (root = 1, leaves at [n_leaves, 2 n_leaves))
 #ifndef RT_DEV_H
 #define RT_DEV_H
 
@@ -27,9 +28,10 @@
 #define RT_MAX_OBJECTS    4096
 #define RT_BVH_STACK      32     // per-lane traversal stack entries (LDS)
 #define RT_BLOCK          256    // threads per workgroup of the trace/shade kernels
-#define RT_LEAF_PHOTONS   64     // photon slots per gather leaf = one wavefront
+#define RT_SUB_PHOTONS    32     // photon slots per sub-leaf: a wavefront examines two sub-leaves per step
+#define RT_LEAF_SUBS      4      // sub-leaves per leaf of the walked tree (128 photon slots)
 #define RT_GATHER_WAVES   4      // waves per gather workgroup
-#define RT_LEAFLIST_CAP   64     // leaf ids kept per query in LDS before the slow path
+#define RT_LEAFLIST_CAP   40     // leaf ids kept per query in LDS before the slow path (40 leaves = 5120 slots)
 
 struct DevNodeXf { float itm[9]; float pos[3]; float tm[9]; float pad[3]; };
 
@@ -66,9 +68,10 @@ struct DevMesh {
 };
 
 struct DevPhotonMap {
-    const float4 *pa;            // [n_leaves*64]  position.xyz, direction.x
-    const float4 *pb;            //                direction.yz, GetMaxPower(), colour bytes r|g<<8|b<<16 (as uint bits)
+    const float4 *pa;            // [n_sub*32]  position.xyz, direction.x
+    const float4 *pb;            //             direction.yz, GetMaxPower(), colour bytes r|g<<8|b<<16 (as uint bits)
     const float  *tbox;          // [2*n_leaves][6]
+    const float  *sbox;          // [n_sub][6], n_sub = 4 * n_leaves: sub-leaf j of leaf l is 4*l + j
     uint32_t n_leaves;           // power of two, 0 = no photon map
     uint32_t n_photons;          // photons stored in the leaves
     // coarse density grid (photon count per cubic cell of side `cell`) used only to pick the first
@@ -175,9 +178,10 @@ struct DevWork {
     uint32_t *pixel_list;     // pixels (chunk-local) that take the second sample batch
     unsigned long long *stats;
 };
-#define CNT_GATHER_NEXT 15     // work counter of k_gather (64-query batches handed out so far)
 #define CNT_PHOTONQ 16
-#define CNT_PIXLIST 17
+#define CNT_GATHER_NEXT 17     // work counters of k_gather, one per XCD (8): query batches handed out so far from each segment
+#define CNT_RESET   25         // counters [0, CNT_RESET) are cleared before every pass
+#define CNT_PIXLIST 30         // survives the passes of a chunk
 #define CNT_TOTAL   32
 
 #endif

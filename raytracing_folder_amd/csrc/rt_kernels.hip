@@ -35,11 +35,12 @@
 #define RT_GATHER_GUESS 1.3f   // photons expected inside the first trial radius, in units of k (1.2-1.6 measured flat)
 #endif
 #ifndef RT_GATHER_RING
-#define RT_GATHER_RING 160     // LDS entries for the photons around the predicted k-th distance (0: always re-read in pass 2)
+#define RT_GATHER_RING 128     // LDS entries for the photons around the predicted k-th distance (0: always re-read in pass 2)
 #endif
 #ifndef RT_GATHER_BATCH
-#define RT_GATHER_BATCH 16     // queries a wave lists per phase A (sized so that lists + ring keep 5 waves/SIMD)
+#define RT_GATHER_BATCH 32     // queries a wave lists per phase A (40 leaf ids each: lists + ring keep 5 waves/SIMD)
 #endif
+#define RT_SUBLIST_CAP 192     // sub-leaf ids of one query (three per lane), from at most RT_LEAFLIST_CAP * RT_LEAF_SUBS = 160
 
 // ------------------------------------------------------------------------------------------------
 // float3 algebra in the reference's evaluation order (cyPoint.h:259-350, cyMatrix.h:542-546)
@@ -1400,14 +1401,13 @@ struct GatherArgs {
     DevPhotonMap pm;
     const float4 *qa, *qb, *qc;      // query queue
     const uint32_t *count_ptr;       // number of queries (device)
-    uint32_t *next_batch;            // work counter, zero at launch
+    uint32_t *next_batch;            // eight work counters (one per XCD), zero at launch
     uint32_t count_cap;
     int k; float radius;
     float *sample_rgb;               // mode 0: atomicAdd w * irr * max(0, N.(-dir)) into the slot
     float *out_irr, *out_dir;        // mode 1: write irr[3], dir[3] per query (rt_estimate_irradiance)
     int mode;
     unsigned long long *stats;
-    uint16_t *spill;                 // [waves in the grid][n_leaves]: leaf lists too long for LDS
 };
 
 // Wave-wide inclusive scans on the DPP path (row_shr 1/2/4/8 inside each row of 16 lanes, then
@@ -1476,6 +1476,7 @@ __device__ __forceinline__ void wave_sync()
 
 struct GatherLds {
     uint16_t leaves[RT_GATHER_BATCH][RT_LEAFLIST_CAP];   // per query (lane) leaf ids
+    uint16_t subs[RT_SUBLIST_CAP];                       // the current query's sub-leaf ids (compaction scratch)
     uint32_t hist[256];
     float    sel_d[64];
     uint32_t sel_i[64];
@@ -1518,45 +1519,52 @@ __device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuer
     return c;
 }
 
-// Visit every photon slot of the query's leaves: f(candidate, slot) is called wave-uniformly (all 64
-// lanes, same leaf) so it may use ballots.  The loads of leaf it+1 are issued before leaf it is
-// processed (one leaf = two coalesced 16-byte loads per lane, nothing else is fetched per photon), so a
-// wave always has a leaf in flight while it works: measured on MI355X the un-pipelined version spent
-// 78 % of its wave cycles parked on s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES).
+// Visit every photon slot of the query's sub-leaves, TWO sub-leaves of 32 slots per step (lanes 0-31 the first,
+// lanes 32-63 the second; an odd last one leaves the upper half idle): f(candidate, slot) is called wave-uniformly
+// (all 64 lanes) so it may use ballots.  The loads of step it+1 are issued before step it is processed (two
+// coalesced 16-byte loads per lane, nothing else is fetched per photon), so a wave always has a step in flight
+// while it works: measured on MI355X the un-pipelined version spent 78 % of its wave cycles parked on s_waitcnt
+// (SQ_WAIT_ANY / SQ_WAVE_CYCLES).  sub_at(e) returns the e-th sub-leaf id as a wave-uniform value.
+#define SUB_NONE 0xFFFFFFFFu
 template <class L, class F>
-__device__ __forceinline__ void scan_leaves(const DevPhotonMap &pm, L &&leaf_at, uint32_t n_iter,
-                                            int lane, const GatherQuery &Q, F &&f)
+__device__ __forceinline__ void scan_subleaves(const DevPhotonMap &pm, L &&sub_at, uint32_t n_sub, int lane,
+                                               const GatherQuery &Q, F &&f)
 {
-    if (n_iter == 0) return;
-    // leaf ids are wave-uniform (SGPR): base pointer arithmetic stays on the scalar unit and the loads
-    // take the "scalar base + lane offset" form
-    auto ld = [&](uint32_t it, float4 &a, float4 &b, uint32_t &slot) {
-        const uint32_t leaf = leaf_at(it);
-        slot = leaf * RT_LEAF_PHOTONS + (uint32_t)lane;
-        a = (pm.pa + (size_t)leaf * RT_LEAF_PHOTONS)[lane];
-        b = (pm.pb + (size_t)leaf * RT_LEAF_PHOTONS)[lane];
+    if (n_sub == 0) return;
+    const uint32_t n_iter = (n_sub + 1u) >> 1;
+    const bool upper = lane >= 32;
+    const uint32_t l32 = (uint32_t)lane & 31u;
+    auto ld = [&](uint32_t it, float4 &a, float4 &b, uint32_t &slot, bool &valid) {
+        const uint32_t s0 = sub_at(2u * it);
+        const uint32_t s1 = (2u * it + 1u < n_sub) ? sub_at(2u * it + 1u) : SUB_NONE;
+        valid = !upper || s1 != SUB_NONE;
+        const uint32_t sub = upper ? (s1 != SUB_NONE ? s1 : s0) : s0;       // idle lanes re-read the first one's line
+        slot = sub * RT_SUB_PHOTONS + l32;
+        a = pm.pa[slot];
+        b = pm.pb[slot];
     };
 #if RT_GATHER_AHEAD == 0
     for (uint32_t it = 0; it < n_iter; it++) {
-        float4 a, b; uint32_t sl;
-        ld(it, a, b, sl);
-        f(make_cand(a, b, Q, true), (size_t)sl);
+        float4 a, b; uint32_t sl; bool v;
+        ld(it, a, b, sl, v);
+        f(make_cand(a, b, Q, v), (size_t)sl);
     }
 #else
     // two register sets used alternately, each refilled right after it was consumed; the reload index
-    // is clamped instead of branched over (the last leaf may be fetched twice) so that neither set
+    // is clamped instead of branched over (the last step may be fetched twice) so that neither set
     // is a loop-carried copy of the other
     float4 a0, b0, a1, b1;
     uint32_t s0, s1;
-    ld(0u, a0, b0, s0);
+    bool v0, v1;
+    ld(0u, a0, b0, s0, v0);
     uint32_t it = 0;
     for (; it + 1 < n_iter; it += 2) {
-        ld(it + 1, a1, b1, s1);
-        f(make_cand(a0, b0, Q, true), (size_t)s0);
-        ld(min(it + 2, n_iter - 1), a0, b0, s0);
-        f(make_cand(a1, b1, Q, true), (size_t)s1);
+        ld(it + 1, a1, b1, s1, v1);
+        f(make_cand(a0, b0, Q, v0), (size_t)s0);
+        ld(min(it + 2, n_iter - 1), a0, b0, s0, v0);
+        f(make_cand(a1, b1, Q, v1), (size_t)s1);
     }
-    if (it < n_iter) f(make_cand(a0, b0, Q, true), (size_t)s0);
+    if (it < n_iter) f(make_cand(a0, b0, Q, v0), (size_t)s0);
 #endif
 }
 
@@ -1580,23 +1588,41 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     if (nq > G.count_cap) nq = G.count_cap;
     if (nq == 0) return;                                 // most chunks of a frame see no photon query at all
     const uint32_t n_leaves = G.pm.n_leaves;
+    const uint32_t n_sub_total = n_leaves * RT_LEAF_SUBS;
     const float r2 = G.radius * G.radius;
     const uint32_t K = (uint32_t)G.k;
-    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     unsigned long long visited = 0;
     uint32_t n_rounds = 0, n_slow = 0, n_reads = 0;       // wave-uniform tallies
     float pred_rk2 = 0.0f;                                // k-th squared distance of this wave's previous query (a hint only)
 
-    // 64-query batches are handed out dynamically (one atomic per batch): query cost varies by two
-    // orders of magnitude with the local photon density, so a static split leaves a long tail
+    // batches of RT_GATHER_BATCH queries are handed out dynamically (one atomic per batch): query cost varies by
+    // two orders of magnitude with the local photon density, so a static split leaves a long tail
     const uint32_t n_batches = (nq + (uint32_t)RT_GATHER_BATCH - 1u) / (uint32_t)RT_GATHER_BATCH;
     const float guess_c = RT_GATHER_GUESS * (float)K * G.pm.cell * G.pm.cell / (float)M_PI;
 
+    // XCD affinity: the queue is in sample order, so neighbouring batches look up neighbouring points and read the
+    // same sub-leaves.  The queue is cut into eight contiguous segments, one per XCD: the waves of an XCD (640 of
+    // them) then work inside a narrow window of the queue at any time and share its photons through their XCD's
+    // 4 MB L2 instead of each XCD streaming every window's photons from the Infinity Cache.  A wave whose segment
+    // is used up takes batches from the next ones (query cost varies 100x: no static split).  Speed only: any
+    // assignment gives the same results.
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const uint32_t seg_len = (n_batches + 7u) / 8u;
+    uint32_t seg = xcc, seg_tried = 0;
     for (;;) {
         uint32_t batch = 0;
-        if (lane == 0) batch = atomicAdd(G.next_batch, 1u);
+        if (lane == 0) batch = atomicAdd(G.next_batch + seg, 1u);
         batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch);
-        if (batch >= n_batches) break;
+        const uint32_t seg_first = seg * seg_len;
+        const uint32_t seg_size = seg_first >= n_batches ? 0u : min(seg_len, n_batches - seg_first);
+        if (batch >= seg_size) {                               // this segment is finished: move on, or stop after all eight
+            if (++seg_tried >= 8u) break;
+            seg = (seg + 1u) & 7u;
+            continue;
+        }
+        batch += seg_first;
         const uint32_t qbase = batch * (uint32_t)RT_GATHER_BATCH;
         const uint32_t qi = qbase + lane;
         const bool have = lane < RT_GATHER_BATCH && qi < nq;
@@ -1634,6 +1660,9 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 }
             }
             wave_sync();
+#ifdef RT_EXP_PHASEA            /* cost attribution build: phase A only, results are garbage */
+            pending = false;
+#endif
             // ---------------- phase B: the wave takes the pending queries one by one --------------
             unsigned long long todo = __ballot(pending);
             while (todo) {
@@ -1648,33 +1677,72 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 const uint32_t qnl = lane_u(nl, q);
                 const bool final_round = rq2 >= r2;
                 const bool slow = qnl > RT_LEAFLIST_CAP;   // the LDS list overflowed
-                uint32_t n_iter = qnl;
-                uint16_t *spill = G.spill + (size_t)wave_global * n_leaves;
-                if (slow) {
-                    // rebuild the list in this wave's global scratch: 64 leaf boxes per step, ballot-compacted
-                    n_iter = 0;
-                    for (uint32_t base = 0; base < n_leaves; base += 64u) {
-                        const uint32_t leaf = base + (uint32_t)lane;
-                        const bool in = leaf < n_leaves && box_dist2(G.pm.tbox + 6 * (size_t)(n_leaves + leaf), Q.px, Q.py, Q.pz) < rq2;
+                // ---- the query's sub-leaves: four boxes per listed leaf, tested 64 at a time, kept in registers ----
+                // (a leaf holds 128 photon slots; most query balls cut only part of one: testing its four 32-slot
+                // sub-boxes examines about a fifth fewer photons than reading whole 64-slot leaves did)
+                uint32_t n_sub = 0;
+                uint32_t my_sub0 = 0, my_sub1 = 0, my_sub2 = 0;     // lane i keeps list entries i, 64 + i and 128 + i
+                if (!slow) {
+                    for (uint32_t base = 0; base < qnl * RT_LEAF_SUBS; base += 64u) {
+                        const uint32_t e = base + (uint32_t)lane;
+                        const bool have_e = (e >> 2) < qnl;
+                        const uint32_t sub = have_e ? (uint32_t)L.leaves[q][e >> 2] * RT_LEAF_SUBS + (e & 3u) : 0u;
+                        const bool in = have_e && box_dist2(G.pm.sbox + 6 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
                         const unsigned long long m = __ballot(in);
-                        if (in) spill[n_iter + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)leaf;
-                        n_iter += (uint32_t)__popcll(m);
+                        if (in) L.subs[n_sub + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)sub;
+                        n_sub += (uint32_t)__popcll(m);
                     }
                     wave_sync();
+                    my_sub0 = (uint32_t)lane < n_sub ? (uint32_t)L.subs[lane] : 0u;
+                    my_sub1 = (uint32_t)lane + 64u < n_sub ? (uint32_t)L.subs[lane + 64] : 0u;
+                    my_sub2 = (uint32_t)lane + 128u < n_sub ? (uint32_t)L.subs[lane + 128] : 0u;
+                    wave_sync();                           // L.subs is reused by the next query
+                } else {
+                    // list too long for LDS: every pass walks ALL sub-leaf boxes instead (64 per step) -- no list is kept
+                    for (uint32_t base = 0; base < n_sub_total; base += 64u) {
+                        const uint32_t sub = base + (uint32_t)lane;
+                        const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 6 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
+                        n_sub += (uint32_t)__popcll(__ballot(in));
+                    }
                 }
-                n_rounds++; n_slow += slow ? 1u : 0u; n_reads += n_iter;
-                // run one pass over the query's leaves.  An LDS list has at most 64 entries: lane i keeps
-                // entry i in a register and the loop reads it with v_readlane (no LDS round trip in the
-                // address path); a spill list is read from this wave's global scratch.
-                const uint32_t my_leaf = (!slow && (uint32_t)lane < n_iter) ? (uint32_t)L.leaves[q][lane] : 0u;
+                n_rounds++; n_slow += slow ? 1u : 0u; n_reads += n_sub;
+                // run one pass over the query's sub-leaves
                 auto for_each = [&](auto &&f) {
-                    if (slow) scan_leaves(G.pm, [&](uint32_t it) { return (uint32_t)spill[it]; }, n_iter, lane, Q, f);
-                    else scan_leaves(G.pm, [&](uint32_t it) { return (uint32_t)__builtin_amdgcn_readlane((int)my_leaf, (int)it); }, n_iter, lane, Q, f);
+                    if (!slow) {
+                        scan_subleaves(G.pm, [&](uint32_t e) {
+                            return e < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)my_sub0, (int)e)
+                                 : e < 128u ? (uint32_t)__builtin_amdgcn_readlane((int)my_sub1, (int)(e - 64u))
+                                            : (uint32_t)__builtin_amdgcn_readlane((int)my_sub2, (int)(e - 128u));
+                        }, n_sub, lane, Q, f);
+                        return;
+                    }
+                    for (uint32_t base = 0; base < n_sub_total; base += 64u) {
+                        const uint32_t sub = base + (uint32_t)lane;
+                        const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 6 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
+                        unsigned long long m = __ballot(in);
+                        while (m) {
+                            const uint32_t s0 = base + (uint32_t)(__ffsll((long long)m) - 1);
+                            m &= m - 1;
+                            uint32_t s1 = SUB_NONE;
+                            if (m) { s1 = base + (uint32_t)(__ffsll((long long)m) - 1); m &= m - 1; }
+                            scan_subleaves(G.pm, [&](uint32_t e) { return e == 0u ? s0 : s1; }, s1 == SUB_NONE ? 1u : 2u, lane, Q, f);
+                        }
+                    }
                 };
                 float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // pass 1: sums over ALL candidates
+#ifdef RT_EXP_LOADONLY          /* cost attribution build: phase A + the leaf reads, nothing else; results are garbage */
+                for_each([&](const Cand &cd, size_t) { s_pr += cd.pa.x + cd.pb.x; });
+                visited += n_sub;
+                if (G.mode == 1 && s_pr == 12345.678f && lane == 0) G.out_irr[0] = s_pr;
+                if (lane == q) pending = false;
+                continue;
+#endif
                 // sum of power (GetPower = Color24 -> Color times power) and of dir * maxPower for one photon
                 // (branch-free variant: take == false adds exact zeros; measured slower than the branch)
                 auto accumulate5 = [&](float dirx, float diry, float dirz, float maxp, uint32_t cbits, bool take) {
+#ifdef RT_EXP_NOACC             /* cost attribution build: no summation; results are garbage */
+                    return;
+#endif
 #if RT_GATHER_BRANCHY
                     if (!take) return;
 #endif
@@ -1720,7 +1788,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     if (cd.ok) atomicAdd(&L.hist[cd.key >> 16], 1u);
                 });
 #endif
-                visited += n_iter;
+                visited += n_sub;
                 if (!final_round && M <= K) {
                     // not enough inside the trial radius: grow it (count ~ r^2 on a surface) and retry
                     float grow = 1.5f * (float)K / (float)(M > 0 ? M : 1u);
@@ -1807,7 +1875,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     }
 #endif
                     if (!from_ring) {
-                    n_reads += n_iter;
+                    n_reads += n_sub;
                     // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
                     s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
                     for_each([&](const Cand &cd, size_t s) {
@@ -1876,7 +1944,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                             }
                         }
                     } else {
-                        n_reads += n_iter;
+                        n_reads += n_sub;
                         s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
                         for_each([&](const Cand &cd, size_t) { accumulate(cd.pa, cd.pb, cd.ok); });
                     }
@@ -1914,7 +1982,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
         }
     }
     if (lane == 0 && G.stats && visited) {
-        atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * 64ull);
+        atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * (unsigned long long)RT_SUB_PHOTONS);
         atomicAdd(&G.stats[ST_GATHER_ROUNDS], (unsigned long long)n_rounds);
         atomicAdd(&G.stats[ST_GATHER_SLOW], (unsigned long long)n_slow);
         atomicAdd(&G.stats[ST_GATHER_LEAF_READS], (unsigned long long)n_reads);
@@ -1973,7 +2041,7 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
         // the queues of this pass are final by now (same stream): remember how full they got, so that the host
         // can size them from what a scene really produces instead of the 2^bounce worst case
         uint32_t pr = 0;
-        for (int l = 1; l < CNT_GATHER_NEXT; l++) pr = max(pr, W.counts[l]);
+        for (int l = 1; l < CNT_PHOTONQ; l++) pr = max(pr, W.counts[l]);
         atomicMax(&W.stats[ST_PEAK_RAYS], (unsigned long long)pr);
         atomicMax(&W.stats[ST_PEAK_QUERIES], (unsigned long long)W.counts[CNT_PHOTONQ]);
     }
@@ -2132,10 +2200,10 @@ void rtk_launch_trace(hipStream_t st, const DevScene &S, int model, const float 
 void rtk_launch_gather(hipStream_t st, const DevPhotonMap &pm, const float4 *qa, const float4 *qb,
                        const float4 *qc, const uint32_t *count_ptr, uint32_t count_cap, int k,
                        float radius, float *sample_rgb, float *out_irr, float *out_dir, int mode,
-                       unsigned long long *stats, int blocks, uint16_t *spill, uint32_t *next_batch)
+                       unsigned long long *stats, int blocks, uint32_t *next_batch)
 {
     GatherArgs G; G.pm = pm; G.qa = qa; G.qb = qb; G.qc = qc; G.count_ptr = count_ptr; G.count_cap = count_cap;
-    G.k = k; G.radius = radius; G.sample_rgb = sample_rgb; G.out_irr = out_irr; G.out_dir = out_dir; G.mode = mode; G.stats = stats; G.spill = spill; G.next_batch = next_batch;
+    G.k = k; G.radius = radius; G.sample_rgb = sample_rgb; G.out_irr = out_irr; G.out_dir = out_dir; G.mode = mode; G.stats = stats; G.next_batch = next_batch;
     hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(64 * RT_GATHER_WAVES), 0, st, G);
 }
 

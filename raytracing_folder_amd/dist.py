@@ -99,9 +99,12 @@ class ShardedRenderer:
         self.packed = torch.zeros((self.per_rank, tile_h, tile_w, BYTES_PER_PIXEL), dtype=torch.uint8, device=dev)
         self.gathered = torch.zeros((world * self.per_rank, tile_h, tile_w, BYTES_PER_PIXEL), dtype=torch.uint8, device=dev)
         self.gather_ms = []
+        # everything of a step -- render, all-gather, un-interleave -- is ordered on ONE explicit stream (torch's legacy
+        # default stream has handle 0, which the C ABI reads as "the library's own stream": not ordered with ours)
+        self.stream = torch.cuda.Stream(device=dev)
 
     def _stream(self):
-        return torch.cuda.current_stream(self.device_index).cuda_stream
+        return self.stream.cuda_stream
 
     def render_own_tiles(self, want_stats=True):
         """this rank's tiles into the image planes (single-GPU path, and the profiling leg of bench.py)"""
@@ -121,18 +124,19 @@ class ShardedRenderer:
             self.gather_ms.append(0.0)
             return st, (self.rgb, self.z, self.cnt)
         import time
-        st = self.render_own_tiles_packed()
-        t0 = time.perf_counter()
-        if self.host_gather:
-            mine = self.packed.cpu()
-            gathered = torch.empty((self.world * self.per_rank,) + tuple(mine.shape[1:]), dtype=torch.uint8)
-            dist.all_gather_into_tensor(gathered, mine)
-            self.gathered.copy_(gathered)
-        else:
-            dist.all_gather_into_tensor(self.gathered, self.packed)     # rank r's tiles land in rows [r*per_rank, (r+1)*per_rank)
-        capi.tiles_unpack_device(self.device_index, self._stream(), self.gathered.data_ptr(), self.world, self.per_rank,
-                                 self.cam.width, self.cam.height, self.tile_w, self.tile_h,
-                                 self.rgb.data_ptr(), self.z.data_ptr(), self.cnt.data_ptr())
-        torch.cuda.synchronize(self.device_index)
+        with torch.cuda.stream(self.stream):
+            st = self.render_own_tiles_packed()                             # synchronous: this rank's tiles are final
+            t0 = time.perf_counter()
+            if self.host_gather:
+                mine = self.packed.cpu()
+                gathered = torch.empty((self.world * self.per_rank,) + tuple(mine.shape[1:]), dtype=torch.uint8)
+                dist.all_gather_into_tensor(gathered, mine)
+                self.gathered.copy_(gathered)
+            else:
+                dist.all_gather_into_tensor(self.gathered, self.packed)     # rank r's tiles land in rows [r*per_rank, (r+1)*per_rank)
+            capi.tiles_unpack_device(self.device_index, self._stream(), self.gathered.data_ptr(), self.world, self.per_rank,
+                                     self.cam.width, self.cam.height, self.tile_w, self.tile_h,
+                                     self.rgb.data_ptr(), self.z.data_ptr(), self.cnt.data_ptr())
+            self.stream.synchronize()
         self.gather_ms.append((time.perf_counter() - t0) * 1e3)
         return st, (self.rgb, self.z, self.cnt)

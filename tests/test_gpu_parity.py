@@ -758,7 +758,9 @@ def test_packed_tile_render_and_hip_unpack_match_the_torch_reference():
             with pytest.raises(capi.RtError):                                              # a buffer one byte short is refused
                 s.render_tiles_packed_device(cam, p, tiles, 0, buf.data_ptr(), nbytes - 1, stream=None, sync=True, want_stats=False)
         o_rgb = torch.zeros_like(t_rgb); o_z = torch.zeros_like(t_z); o_cnt = torch.zeros_like(t_cnt)
-        capi.tiles_unpack_device(0, torch.cuda.current_stream().cuda_stream, gathered.data_ptr(), world, per_rank, 100, 37, 32, 8,
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        capi.tiles_unpack_device(0, side.cuda_stream, gathered.data_ptr(), world, per_rank, 100, 37, 32, 8,
                                  o_rgb.data_ptr(), o_z.data_ptr(), o_cnt.data_ptr())
         torch.cuda.synchronize()
         w_rgb, w_z, w_cnt = rtd.unpack_gathered(gathered, 100, 37, world)
@@ -766,7 +768,7 @@ def test_packed_tile_render_and_hip_unpack_match_the_torch_reference():
         assert (o_z.cpu().numpy() == zref).all() and (o_cnt.cpu().numpy() == cref).all()
         assert (np.abs(o_rgb.cpu().numpy().astype(int) - ref.astype(int)) <= 1).all()
     with pytest.raises(capi.RtError):                                                      # too few slots for the frame's tiles
-        capi.tiles_unpack_device(0, 0, gathered.data_ptr(), 8, 1, 100, 37, 32, 8, o_rgb.data_ptr(), o_z.data_ptr(), o_cnt.data_ptr())
+        capi.tiles_unpack_device(0, None, gathered.data_ptr(), 8, 1, 100, 37, 32, 8, o_rgb.data_ptr(), o_z.data_ptr(), o_cnt.data_ptr())
 
 
 def test_queue_overflow_is_an_error_with_or_without_stats(monkeypatch):
