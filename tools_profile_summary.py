@@ -1,40 +1,100 @@
 #!/usr/bin/env python3
-"""Condense a gpurun_out/prof_* directory (rocprofv3 --kernel-trace --stats and the two --pmc passes of
-bench.py) into the files kept under profiles/: <tag>_bench_kernel_stats.csv and <tag>_bench_pmc_hbm.json.
-usage: python tools_profile_summary.py gpurun_out/prof_r1b r01b"""
+"""Condense a gpurun_out/prof_<tag> directory (tools_profile_run.sh: rocprofv3 --kernel-trace --stats and the --pmc passes of
+bench.py) into the files kept under profiles/:
+    <tag>_bench_kernel_stats.csv    rocprofv3's own per-kernel statistics of the --stats pass
+    <tag>_bench_pmc_hbm.json        FETCH_SIZE / WRITE_SIZE per kernel and launch (gfx950: fetch side doubled)
+    <tag>_bench_sq_counters.json    SQ / TCC / TCP counters per kernel and launch + the average launch time of the same pass
+usage: python tools_profile_summary.py gpurun_out/prof_r2a r02a "<workload note>" """
 import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-stats = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
-shutil.copy(stats, f"profiles/{tag}_bench_kernel_stats.csv")
-out = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
-                  "--no-cpu-baseline (one pass per counter; stats pass: --kernel-trace --stats, --steps 2 --warmup 1)",
-       "workload": "Cornell 1920x1080x64spp, 1M-photon map from the GPU photon pass, 16 chunks of 8 Mi samples per frame (32 of 4 Mi before r01d)",
-       "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
-       "note": "gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM "
-               "section); hbm_bytes_per_launch applies that x2 to the fetch side",
-       "kernels": {}}
-data = {}
-for name, pat in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = glob.glob(f"{src}/{pat}/*/*_counter_collection.csv")[0]
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if not k.startswith("k_"):
+note = sys.argv[3] if len(sys.argv) > 3 else ""
+
+
+def kname(n):
+    k = n.split("(")[0].replace("void ", "").strip()
+    return k if k.startswith("k_") else None
+
+
+def counters(passname):
+    """{kernel: {counter: sum}}, {kernel: launches}, {kernel: avg_us} from one pmc pass"""
+    files = glob.glob(f"{src}/{passname}/**/*counter_collection.csv", recursive=True)
+    if not files:
+        return None
+    agg, disp = collections.defaultdict(lambda: collections.defaultdict(float)), collections.defaultdict(set)
+    for r in csv.DictReader(open(files[0])):
+        k = kname(r["Kernel_Name"])
+        if not k:
             continue
-        k = k.split("<")[0]
-        agg[k][0] += 1
-        agg[k][1] += float(r["Counter_Value"])
-    for k, (n, v) in agg.items():
-        data.setdefault(k, {})[name] = {"launches": n, "sum_KiB": round(v, 1), "per_launch_KiB": round(v / n, 1)}
-for k, d in data.items():
-    d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE"]["per_launch_KiB"] + d["WRITE_SIZE"]["per_launch_KiB"]) * 1024)
-out["kernels"] = data
-json.dump(out, open(f"profiles/{tag}_bench_pmc_hbm.json", "w"), indent=1)
-print(open(f"profiles/{tag}_bench_kernel_stats.csv").read()[:900])
-print({k: v["hbm_bytes_per_launch"] for k, v in data.items()})
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    dur = collections.defaultdict(list)
+    for f in glob.glob(f"{src}/{passname}/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = kname(r["Kernel_Name"])
+            if k:
+                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return agg, {k: len(v) for k, v in disp.items()}, {k: sum(v) / len(v) for k, v in dur.items() if v}
+
+
+os.makedirs("profiles", exist_ok=True)
+st = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)
+if st:
+    shutil.copy(st[0], f"profiles/{tag}_bench_kernel_stats.csv")
+    print(open(st[0]).read()[:1200])
+
+hbm = {}
+for name, passname in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    c = counters(passname)
+    if not c:
+        continue
+    agg, n, _ = c
+    for k in agg:
+        hbm.setdefault(k, {})[name] = {"launches": n[k], "sum_KiB": round(agg[k][name], 1), "per_launch_KiB": round(agg[k][name] / n[k], 1)}
+if hbm:
+    for k, d in hbm.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE"]["per_launch_KiB"] + d["WRITE_SIZE"]["per_launch_KiB"]) * 1024)
+    json.dump({"command": "tools_profile_run.sh: rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
+                          "--no-cpu-baseline --profile-frames 0 (one pass per counter)",
+               "workload": note, "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
+               "note": "gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM section); "
+                       "hbm_bytes_per_launch applies that x2 to the fetch side",
+               "kernels": hbm}, open(f"profiles/{tag}_bench_pmc_hbm.json", "w"), indent=1)
+    print({k: v.get("hbm_bytes_per_launch") for k, v in hbm.items()})
+
+sq = {}
+for passname in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_l2"):
+    c = counters(passname)
+    if not c:
+        continue
+    agg, n, avg = c
+    for k in agg:
+        d = sq.setdefault(k, {"launches": n[k]})
+        for cname, v in agg[k].items():
+            d[cname] = round(v / n[k], 1)
+        if k in avg:
+            d.setdefault("avg_launch_us", round(avg[k], 1))
+if sq:
+    for k, d in sq.items():
+        if "SQ_INSTS_VALU" in d and "avg_launch_us" in d:
+            # wave64 VALU instructions issue over 2 cycles on a SIMD-32; 1024 SIMDs at the 2.4 GHz peak clock
+            d["valu_issue_frac_of_peak"] = round(d["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e3 * d["avg_launch_us"]), 4)
+        if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]:
+            d["wait_any_frac"] = round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 4)
+        if "TCC_HIT_sum" in d and d["TCC_HIT_sum"] + d.get("TCC_MISS_sum", 0) > 0:
+            d["l2_hit_rate"] = round(d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"]), 4)
+    json.dump({"command": "tools_profile_run.sh: rocprofv3 --kernel-trace --pmc <4 counters per pass> --output-format csv -- python3 bench.py --steps 1 "
+                          "--warmup 0 --no-cpu-baseline --profile-frames 0",
+               "workload": note,
+               "units": "per-launch averages; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are per-wave quad-cycles summed over all waves, SQ_INSTS_* wave "
+                        "instructions; avg_launch_us from the kernel trace of the same pass (kernels of up to three chunks overlap in it)",
+               "kernels": sq}, open(f"profiles/{tag}_bench_sq_counters.json", "w"), indent=1)
+    for k, d in sq.items():
+        print(k, {x: d[x] for x in d if x in ("launches", "avg_launch_us", "SQ_INSTS_VALU", "valu_issue_frac_of_peak", "wait_any_frac", "l2_hit_rate", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SALU")})
