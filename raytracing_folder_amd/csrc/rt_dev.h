@@ -180,7 +180,8 @@ struct DevWork {
 };
 #define CNT_PHOTONQ 16
 #define CNT_GATHER_NEXT 17     // work counters of k_gather, one per XCD (8): query batches handed out so far from each segment
-#define CNT_RESET   25         // counters [0, CNT_RESET) are cleared before every pass
+#define CNT_PRIMARY_NEXT 25    // work counter of k_wavefront: batches of 256 primary samples handed out so far
+#define CNT_RESET   26         // counters [0, CNT_RESET) are cleared before every pass
 #define CNT_PIXLIST 30         // survives the passes of a chunk
 #define CNT_TOTAL   32
 

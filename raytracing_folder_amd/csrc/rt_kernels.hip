@@ -1,8 +1,11 @@
 // rt_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the render path.
 //
-//   k_primary   K1+K2+K3+K4  primary-ray generation, closest-hit traversal, Blinn shade with an
-//                            any-hit shadow ray per light, child-ray spawn (wave-aggregated push)
-//   k_bounce    K2+K3+K4     the same for one level of the reflection/refraction ray tree
+//   k_wavefront K1+K2+K3+K4  the whole ray tree of a chunk in one persistent launch: primary-ray generation,
+//                            closest-hit traversal, Blinn shade with an any-hit shadow ray per light, children
+//                            pushed onto the workgroup's ray stack in LDS and popped 256 at a time (FIN, P13)
+//   k_primary   K1+K2+K3+K4  the same for the primary rays only, children to the global SoA ray queues
+//   k_bounce    K2+K3+K4     one level of the reflection/refraction ray tree from a global queue (the other
+//                            shading models; rays k_wavefront could not keep in LDS)
 //   k_gather    K5           k-nearest photon gather, one query per wavefront step
 //   k_resolve   K6           per-pixel average / variance gate / gamma / Color24 pack
 //   k_trace     K2           closest-hit only (parity entry point rt_trace_rays)
@@ -438,6 +441,9 @@ struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; 
 struct ShadeCtx {
     DevScene S; DevWork W; rt_params P;
     DevRayQueue qout; uint32_t *qout_count;
+    // k_wavefront only: the workgroup's ray stack in LDS (same four 16-byte words per ray as the global queue);
+    // children go there first and to qout only when it is full.  NULL in the per-level kernels.
+    float4 *lds_a, *lds_b, *lds_c; uint4 *lds_d; uint32_t *lds_count; uint32_t lds_cap;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -623,6 +629,18 @@ __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 
                                          uint32_t slot, int bounce, uint32_t kind, uint32_t node, uint32_t sample,
                                          V3 side_dir = V3{0, 0, 0}, V3 side_K = V3{0, 0, 0})
 {
+    if (!SIDE && C.lds_count) {
+        // workgroup-local stack first (LDS atomic, one per wave); what does not fit goes to the global queue
+        const uint32_t at = wave_push(pred, C.lds_count);
+        if (pred && at < C.lds_cap) {
+            C.lds_a[at] = make_float4(o.x, o.y, o.z, d.x);
+            C.lds_b[at] = make_float4(d.y, d.z, thr.x, thr.y);
+            C.lds_c[at] = make_float4(thr.z, absorb.x, absorb.y, absorb.z);
+            C.lds_d[at] = make_uint4(slot, (uint32_t)bounce | (kind << 8), node, sample);
+        }
+        pred = pred && at >= C.lds_cap;
+        if (!__any(pred)) return;
+    }
     const uint32_t idx = wave_push(pred, C.qout_count);
     if (pred) {
         if (idx < C.qout.cap) {
@@ -1081,6 +1099,56 @@ struct PrimaryArgs {
 
 // Register budget: the texture-free instantiations are held to 168 VGPRs (3 waves/SIMD; a few values
 // spill to scratch) -- measured 4 % faster on MI355X than letting them grow to 192 VGPRs at 2 waves.
+// sample gid of this launch -> its primary ray (generateSample + ray build, FIN/main.cpp:147-162, 281-292); false = no such sample
+__device__ __forceinline__ bool primary_setup(const ShadeCtx &C, const PrimaryArgs &A, unsigned long long gid, unsigned long long total,
+                                              bool h_table, const float *s_h2, const float *s_h3, PathIn &in)
+{
+    in.thr = mk(1.f, 1.f, 1.f); in.absorb = mk(0, 0, 0); in.bounce = C.P.bounce; in.kind = KIND_REFLECT; in.primary = true;
+    in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.slot = 0; in.node = 1; in.sample = 0;
+    in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
+    if (gid >= total) return false;
+    uint32_t pi, jj;
+    if (total <= 0xFFFFFFFFull) { pi = fastdiv((uint32_t)gid, A.div_ns); jj = (uint32_t)gid - pi * (uint32_t)A.ns; }
+    else { pi = (uint32_t)(gid / (unsigned long long)A.ns); jj = (uint32_t)(gid % (unsigned long long)A.ns); }
+    const int j = A.j0 + (int)jj;
+    const uint32_t ql = (A.mode == 1) ? C.W.pixel_list[pi] : pi;      // chunk-local pixel
+    in.slot = ql * (uint32_t)A.max_sample + (uint32_t)j;
+    if (A.mode == 2) {
+        const float *r = A.rays + 6 * (size_t)ql;
+        in.o = ld3(r); in.d = ld3(r + 3);
+        in.sample = A.q0 + ql;                     // caller's ray index
+        return true;
+    }
+    int x, y;
+    if (!pixel_of(A.tiles, A.cam, A.q0 + ql, x, y)) return false;
+    const V3 tmp = mk(x * A.cam.u, y * A.cam.v, 0) + ld3(A.cam.b);     // :235-236
+    float sx = (h_table ? s_h2[jj] : halton(j, 2)) * A.cam.u;          // :153
+    float sy = A.cam.v * (h_table ? s_h3[jj] : halton(j, 3));          // :154
+    sx += tmp.x; sy += tmp.y;
+    const V3 sample = mk(sx, sy, tmp.z);
+    const uint32_t pixel_id = (uint32_t)y * (uint32_t)A.cam.width + (uint32_t)x;
+    in.sample = pixel_id * (uint32_t)A.max_sample + (uint32_t)j;
+    V3 d_campos = mk(0, 0, 0);
+    if (A.cam.dof != 0) {
+        // :246-262: a table of CAM_SAMPLE lens points per pixel (radius sqrt(Halton(i,2))*dof,
+        // random angle), of which every sample picks one at random (:284)
+        RngCtx pc; pc.seed = C.P.seed; pc.sample = in.sample; pc.node = 0;
+        float u0, u1;
+        rng2(pc, RNG_PICK, 0u, u0, u1);
+        int pick = (int)(u0 * 64.0f);
+        pick = pick > 63 ? 63 : pick;
+        RngCtx lc; lc.seed = C.P.seed; lc.sample = pixel_id; lc.node = 0;
+        rng2(lc, RNG_LENS, (uint32_t)(pick + 1), u0, u1);
+        float r = halton(pick + 1, 2);
+        r = sqrtf(r) * A.cam.dof;
+        const float theta = (float)(M_PI * 2.0 * (double)u0);
+        d_campos = mmul(A.cam.m, mk(r * cosf(theta), r * sinf(theta), 0));
+    }
+    in.o = ld3(A.cam.pos) + d_campos;                                  // :288
+    in.d = normalize(mmul(A.cam.m, sample) - d_campos);                // :289-292
+    return true;
+}
+
 #define RT_TRACE_OCC __attribute__((amdgpu_waves_per_eu(TEX ? 2 : 3)))
 template <int MODEL, bool TEX>
 RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
@@ -1100,55 +1168,8 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, P
     __syncthreads();
     // every lane iterates the same number of times (wave-collective pushes inside shade_path)
     for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < total; base += stride) {
-        const unsigned long long gid = base + threadIdx.x;
-        bool active = gid < total;
         PathIn in;
-        in.thr = mk(1.f, 1.f, 1.f); in.absorb = mk(0, 0, 0); in.bounce = C.P.bounce; in.kind = KIND_REFLECT; in.primary = true;
-        in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.slot = 0; in.node = 1; in.sample = 0;
-        in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
-        if (active) {
-            uint32_t pi, jj;
-            if (total <= 0xFFFFFFFFull) { pi = fastdiv((uint32_t)gid, A.div_ns); jj = (uint32_t)gid - pi * (uint32_t)A.ns; }
-            else { pi = (uint32_t)(gid / (unsigned long long)A.ns); jj = (uint32_t)(gid % (unsigned long long)A.ns); }
-            const int j = A.j0 + (int)jj;
-            const uint32_t ql = (A.mode == 1) ? C.W.pixel_list[pi] : pi;      // chunk-local pixel
-            in.slot = ql * (uint32_t)A.max_sample + (uint32_t)j;
-            if (A.mode == 2) {
-                const float *r = A.rays + 6 * (size_t)ql;
-                in.o = ld3(r); in.d = ld3(r + 3);
-                in.sample = A.q0 + ql;                     // caller's ray index
-            } else {
-                int x, y;
-                if (!pixel_of(A.tiles, A.cam, A.q0 + ql, x, y)) active = false;
-                else {
-                    const V3 tmp = mk(x * A.cam.u, y * A.cam.v, 0) + ld3(A.cam.b);     // :235-236
-                    float sx = (h_table ? s_h2[jj] : halton(j, 2)) * A.cam.u;          // :153
-                    float sy = A.cam.v * (h_table ? s_h3[jj] : halton(j, 3));          // :154
-                    sx += tmp.x; sy += tmp.y;
-                    const V3 sample = mk(sx, sy, tmp.z);
-                    const uint32_t pixel_id = (uint32_t)y * (uint32_t)A.cam.width + (uint32_t)x;
-                    in.sample = pixel_id * (uint32_t)A.max_sample + (uint32_t)j;
-                    V3 d_campos = mk(0, 0, 0);
-                    if (A.cam.dof != 0) {
-                        // :246-262: a table of CAM_SAMPLE lens points per pixel (radius sqrt(Halton(i,2))*dof,
-                        // random angle), of which every sample picks one at random (:284)
-                        RngCtx pc; pc.seed = C.P.seed; pc.sample = in.sample; pc.node = 0;
-                        float u0, u1;
-                        rng2(pc, RNG_PICK, 0u, u0, u1);
-                        int pick = (int)(u0 * 64.0f);
-                        pick = pick > 63 ? 63 : pick;
-                        RngCtx lc; lc.seed = C.P.seed; lc.sample = pixel_id; lc.node = 0;
-                        rng2(lc, RNG_LENS, (uint32_t)(pick + 1), u0, u1);
-                        float r = halton(pick + 1, 2);
-                        r = sqrtf(r) * A.cam.dof;
-                        const float theta = (float)(M_PI * 2.0 * (double)u0);
-                        d_campos = mmul(A.cam.m, mk(r * cosf(theta), r * sinf(theta), 0));
-                    }
-                    in.o = ld3(A.cam.pos) + d_campos;                                  // :288
-                    in.d = normalize(mmul(A.cam.m, sample) - d_campos);                // :289-292
-                }
-            }
-        }
+        const bool active = primary_setup(C, A, base + threadIdx.x, total, h_table, s_h2, s_h3, in);
         if (active) nprim++;
         shade_path<MODEL, TEX>(C, in, active, stack, cnt);
     }
@@ -1195,6 +1216,82 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
         shade_path<MODEL, TEX>(C, in, active, stack, cnt);
     }
     flush_counters(C.W.stats, cnt, 0, nrefl, nrefr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole ray tree of a chunk in ONE launch: a persistent grid of workgroups, each with its own ray stack in
+// LDS (BASELINE.json north_star: "persistent-threads wavefront tracer with ray queues in LDS").  A workgroup
+// takes 256 primary samples at a time from a device-side counter; the reflection/refraction children its rays
+// spawn are pushed onto ITS stack (wave-aggregated LDS atomic) and popped 256 at a time -- whenever 256 are
+// waiting, or when the primary samples have run out -- so the deep, sparse levels of the tree are traced by
+// full wavefronts next to other workgroups' primary rays instead of in launches of their own that cannot fill
+// 256 CUs.  Nothing is handed between workgroups (no cross-CU visibility protocol needed); a ray that finds
+// the stack full goes to the global queue and is picked up by the per-level k_bounce launches that follow
+// (normally empty).  FIN and P13 models (at most two children per hit); the others keep the per-level kernels.
+// ------------------------------------------------------------------------------------------------
+#ifndef RT_WF_STACK
+#define RT_WF_STACK 640        // rays per workgroup stack: 4 x 16 B x 640 = 40 KB next to the 32 KB of BVH stacks -> 2 workgroups per CU
+#endif
+#ifndef RT_WF_WAVES
+#define RT_WF_WAVES 2          // waves per SIMD = workgroups per CU the kernel is built for
+#endif
+template <int MODEL, bool TEX>
+__attribute__((amdgpu_waves_per_eu(RT_WF_WAVES, RT_WF_WAVES))) __global__ __launch_bounds__(RT_BLOCK) void k_wavefront(ShadeCtx C, PrimaryArgs A)
+{
+    __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
+    __shared__ float4 s_qa[RT_WF_STACK], s_qb[RT_WF_STACK], s_qc[RT_WF_STACK];
+    __shared__ uint4 s_qd[RT_WF_STACK];
+    __shared__ uint32_t s_count, s_batch;
+    __shared__ float s_h2[RT_BLOCK], s_h3[RT_BLOCK];
+    uint32_t *stack = s_stack + threadIdx.x;
+    Counters cnt = {0, 0, 0, 0};
+    uint32_t nprim = 0, nrefl = 0, nrefr = 0;
+    const uint32_t npix = (A.mode == 1) ? C.W.counts[CNT_PIXLIST] : A.npix;
+    const unsigned long long total = (unsigned long long)npix * (unsigned long long)A.ns;
+    const unsigned long long n_batches = (total + RT_BLOCK - 1) / RT_BLOCK;
+    const bool h_table = A.mode != 2 && A.ns <= RT_BLOCK;
+    if (h_table && (int)threadIdx.x < A.ns) { s_h2[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 2); s_h3[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 3); }
+    if (threadIdx.x == 0) s_count = 0;
+    C.lds_a = s_qa; C.lds_b = s_qb; C.lds_c = s_qc; C.lds_d = s_qd; C.lds_count = &s_count; C.lds_cap = RT_WF_STACK;
+    bool more_primaries = true;                           // workgroup-uniform
+    for (;;) {
+        __syncthreads();                                  // last round's pushes are complete
+        uint32_t waiting = s_count;
+        if (waiting > RT_WF_STACK) waiting = RT_WF_STACK; // the excess went to the global queue
+        const bool pop = waiting >= RT_BLOCK || (!more_primaries && waiting > 0);
+        if (!pop && !more_primaries) break;
+        __syncthreads();                                  // everyone has read s_count
+        PathIn in;
+        bool active;
+        if (pop) {
+            const uint32_t n = min(waiting, (uint32_t)RT_BLOCK);
+            active = threadIdx.x < n;
+            in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
+            in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0;
+            in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
+            if (active) {
+                const uint32_t src = waiting - 1u - threadIdx.x;          // newest (deepest) first: the stack stays shallow
+                const float4 a = s_qa[src], b = s_qb[src], c = s_qc[src];
+                const uint4 dd = s_qd[src];
+                in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
+                in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
+                in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.node = dd.z; in.sample = dd.w;
+                if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
+            }
+            __syncthreads();                              // all pops read before anything is pushed over them
+            if (threadIdx.x == 0) s_count = waiting - n;
+        } else {
+            if (threadIdx.x == 0) { s_batch = atomicAdd(C.W.counts + CNT_PRIMARY_NEXT, 1u); if (s_count > RT_WF_STACK) s_count = RT_WF_STACK; }
+            __syncthreads();
+            const unsigned long long batch = s_batch;
+            if (batch >= n_batches) { more_primaries = false; continue; }
+            active = primary_setup(C, A, batch * RT_BLOCK + threadIdx.x, total, h_table, s_h2, s_h3, in);
+            if (active) nprim++;
+        }
+        __syncthreads();                                  // s_count settled before this round's pushes
+        shade_path<MODEL, TEX>(C, in, active, stack, cnt);
+    }
+    flush_counters(C.W.stats, cnt, nprim, nrefl, nrefr);
 }
 
 // K2 alone: n closest-hit queries (rt_trace_rays)
@@ -1993,459 +2090,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5, second form: the same estimate with the photon reads SHARED between neighbouring queries.
-//
-// Cost attribution on MI355X (profiles/): of k_gather's 48 ms per bench frame, 28 ms are
-// the sub-leaf reads themselves -- 650 GB per frame through the CUs' vector L1 at ~23 TB/s, two thirds of the
-// 64 B/clk/CU the L1 can return -- and only 6 ms the arithmetic.  Consecutive queue entries are neighbouring
-// samples whose balls cut nearly the same sub-leaves, so here a wave takes GROUPS of four pending queries,
-// merges their sub-leaf lists into one union list (each entry tagged with the queries whose radius reaches
-// it) and reads every listed sub-leaf ONCE per pass for all four.  With shared reads a second pass is cheap,
-// so the ring of k_gather (the LDS cache that avoided re-reading) is dropped:
-//   pass 1  (shared): count + 256-bin histogram of the 24-bit distance key per query;
-//   per query: grow the radius and retry (M <= k inside a trial radius) / take all (M <= k, full radius) /
-//              locate the bin of the k-th (8 bits per level, further levels only when > 64 share a bin);
-//   pass 2  (shared): sum what lies below the bin, collect the bin (<= 64 entries) for the exact rank selection.
-// Same acceptance test, same keys, same selection as k_gather: the k nearest accepted photons, exactly.
-// Sums are per-lane partials in union-list order, combined by a fixed DPP scan: deterministic.
-// ------------------------------------------------------------------------------------------------
-#ifndef RT_GS_GROUP
-#define RT_GS_GROUP 4
-#endif
-#define RT_ULIST_CAP 192
-struct GatherSharedLds {
-    uint16_t leaves[RT_GATHER_BATCH][RT_LEAFLIST_CAP];   // per query (lane) leaf ids, ascending
-    uint16_t uleaf[RT_GS_GROUP * RT_LEAFLIST_CAP];       // the group's distinct leaves (compaction scratch)
-    uint32_t ulist[RT_ULIST_CAP];                        // union list: sub-leaf id | query mask << 16 (compaction scratch)
-    uint32_t hist[RT_GS_GROUP][256];
-    float    sel_d[RT_GS_GROUP][64];
-    uint32_t sel_i[RT_GS_GROUP][64];
-    uint32_t sel_n[RT_GS_GROUP];
-};
-
-// one level of the k-th search on a 256-bin histogram: which bin holds rank `need`, how many lie before it
-__device__ __forceinline__ void hist_locate(const uint32_t *hist, int lane, uint32_t need, uint32_t &digit, uint32_t &before, uint32_t &cntb)
-{
-    const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-    const uint32_t mine = h0 + h1 + h2 + h3;
-    const uint32_t incl = wave_scan_add_u(mine);
-    const uint32_t excl = incl - mine;
-    const unsigned long long m = __ballot(incl >= need);
-    const int owner = m ? __ffsll((long long)m) - 1 : 63;
-    uint32_t d = 0, bf = 0, cb = 0;
-    if (lane == owner) {
-        if (excl + h0 >= need) { d = 4 * lane; bf = excl; cb = h0; }
-        else if (excl + h0 + h1 >= need) { d = 4 * lane + 1; bf = excl + h0; cb = h1; }
-        else if (excl + h0 + h1 + h2 >= need) { d = 4 * lane + 2; bf = excl + h0 + h1; cb = h2; }
-        else { d = 4 * lane + 3; bf = excl + h0 + h1 + h2; cb = h3; }
-    }
-    digit = lane_u(d, owner); before = lane_u(bf, owner); cntb = lane_u(cb, owner);
-}
-
-__global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather_shared(GatherArgs G)
-{
-    __shared__ GatherSharedLds lds_all[RT_GATHER_WAVES];
-    GatherSharedLds &L = lds_all[threadIdx.x >> 6];
-    const int lane = threadIdx.x & 63;
-    const bool upper = lane >= 32;
-    const uint32_t l32 = (uint32_t)lane & 31u;
-    uint32_t nq = *G.count_ptr;
-    if (nq > G.count_cap) nq = G.count_cap;
-    if (nq == 0) return;
-    const uint32_t n_leaves = G.pm.n_leaves;
-    const uint32_t n_sub_total = n_leaves * RT_LEAF_SUBS;
-    const float r2 = G.radius * G.radius;
-    const uint32_t K = (uint32_t)G.k;
-    unsigned long long visited = 0;
-    uint32_t n_rounds = 0, n_slow = 0, n_reads = 0;       // wave-uniform tallies
-    const uint32_t n_batches = (nq + (uint32_t)RT_GATHER_BATCH - 1u) / (uint32_t)RT_GATHER_BATCH;
-    const float guess_c = RT_GATHER_GUESS * (float)K * G.pm.cell * G.pm.cell / (float)M_PI;
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 7u;
-    const uint32_t seg_len = (n_batches + 7u) / 8u;
-    uint32_t seg = xcc, seg_tried = 0;
-    for (;;) {
-        uint32_t batch = 0;
-        if (lane == 0) batch = atomicAdd(G.next_batch + seg, 1u);
-        batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch);
-        const uint32_t seg_first = seg * seg_len;
-        const uint32_t seg_size = seg_first >= n_batches ? 0u : min(seg_len, n_batches - seg_first);
-        if (batch >= seg_size) {
-            if (++seg_tried >= 8u) break;
-            seg = (seg + 1u) & 7u;
-            continue;
-        }
-        batch += seg_first;
-        const uint32_t qbase = batch * (uint32_t)RT_GATHER_BATCH;
-        const uint32_t qi = qbase + lane;
-        const bool have = lane < RT_GATHER_BATCH && qi < nq;
-        float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
-        if (have) { a = G.qa[qi]; b = G.qb[qi]; c = G.qc[qi]; }
-        bool pending = have;
-        float r2cur = r2;
-        if (have && n_leaves > 1) {
-            const int gx = min(max((int)((a.x - G.pm.grid_min[0]) * G.pm.inv_cell), 0), G.pm.grid_dim[0] - 1);
-            const int gy = min(max((int)((a.y - G.pm.grid_min[1]) * G.pm.inv_cell), 0), G.pm.grid_dim[1] - 1);
-            const int gz = min(max((int)((a.z - G.pm.grid_min[2]) * G.pm.inv_cell), 0), G.pm.grid_dim[2] - 1);
-            const uint32_t cnt = G.pm.grid[((size_t)gz * G.pm.grid_dim[1] + gy) * G.pm.grid_dim[0] + gx];
-            r2cur = fminf(fmaxf(guess_c / (float)(cnt > 0u ? cnt : 1u), r2 * 1.0e-4f), r2);
-        }
-
-        while (__ballot(pending)) {
-            // ---------------- phase A: pending lanes list the leaves inside their trial radius (ascending ids) ----
-            uint32_t nl = 0;
-            if (pending && n_leaves) {
-                uint32_t node = 1;
-                while (node) {
-                    bool descend = false;
-                    if (box_dist2(G.pm.tbox + 6 * (size_t)node, a.x, a.y, a.z) < r2cur) {
-                        if (node >= n_leaves) {
-                            if (nl < RT_LEAFLIST_CAP) L.leaves[lane][nl] = (uint16_t)(node - n_leaves);
-                            nl++;
-                        } else { node = 2 * node; descend = true; }
-                    }
-                    if (!descend) {
-                        while (node & 1u) node >>= 1;
-                        if (node) node += 1;
-                    }
-                }
-            }
-            wave_sync();
-            // ---------------- phase B: groups of up to four pending queries --------------------------------------
-            unsigned long long todo = __ballot(pending);
-            while (todo) {
-                int gq[RT_GS_GROUP];                       // lanes (= queries) of the group, -1 = empty seat
-                int ng = 0;
-                bool slow = false;
-#pragma unroll
-                for (int g = 0; g < RT_GS_GROUP; g++) {
-                    gq[g] = -1;
-                    if (todo && !slow) {
-                        const int q = __ffsll((long long)todo) - 1;
-                        const bool q_slow = lane_u(nl, q) > RT_LEAFLIST_CAP;
-                        // a query whose leaf list overflowed LDS walks ALL sub-leaf boxes, alone
-                        if (q_slow && ng > 0) continue;
-                        gq[g] = q; ng++; todo &= todo - 1;
-                        slow = q_slow;
-                    }
-                }
-                GatherQuery Q[RT_GS_GROUP];
-                uint32_t qnl[RT_GS_GROUP];
-#pragma unroll
-                for (int g = 0; g < RT_GS_GROUP; g++) {
-                    const int q = gq[g] < 0 ? 0 : gq[g];
-                    Q[g].px = lane_f(a.x, q); Q[g].py = lane_f(a.y, q); Q[g].pz = lane_f(a.z, q);
-                    Q[g].nx = lane_f(a.w, q); Q[g].ny = lane_f(b.x, q); Q[g].nz = lane_f(b.y, q);
-                    Q[g].rq2 = lane_f(r2cur, q);
-                    Q[g].kscale = 16777000.0f / Q[g].rq2;
-                    qnl[g] = gq[g] < 0 ? 0u : lane_u(nl, q);
-                }
-                // ---- union of the group's sub-leaves ----------------------------------------------------------
-                uint32_t n_u = 0;                          // union entries
-                uint32_t my_u0 = 0, my_u1 = 0, my_u2 = 0;  // lane i keeps entries i, 64 + i, 128 + i
-                if (!slow) {
-                    // (1) distinct leaves: an entry of list g survives unless an earlier list holds the same leaf
-                    uint32_t cum[RT_GS_GROUP + 1];            // list g occupies entries [cum[g], cum[g+1])
-                    cum[0] = 0;
-#pragma unroll
-                    for (int g = 0; g < RT_GS_GROUP; g++) cum[g + 1] = cum[g] + qnl[g];
-                    const uint32_t nt = cum[RT_GS_GROUP];
-                    uint32_t n_ul = 0;
-                    for (uint32_t base = 0; base < nt; base += 64u) {
-                        const uint32_t e = base + (uint32_t)lane;
-                        const bool have_e = e < nt;
-                        int g = 0;
-                        uint32_t idx = e;
-                        int qlane = gq[0];
-#pragma unroll
-                        for (int h = 1; h < RT_GS_GROUP; h++) if (e >= cum[h]) { g = h; idx = e - cum[h]; qlane = gq[h]; }
-                        const uint32_t leaf = have_e ? (uint32_t)L.leaves[qlane < 0 ? 0 : qlane][idx] : 0xFFFFFFFFu;
-                        bool dup = false;
-#pragma unroll
-                        for (int h = 0; h < RT_GS_GROUP - 1; h++) {
-                            if (gq[h] < 0) continue;
-                            for (uint32_t j = 0; j < qnl[h]; j++) dup = dup || (h < g && (uint32_t)L.leaves[gq[h]][j] == leaf);
-                        }
-                        const bool keep = have_e && !dup;
-                        const unsigned long long m = __ballot(keep);
-                        if (keep) L.uleaf[n_ul + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)leaf;
-                        n_ul += (uint32_t)__popcll(m);
-                    }
-                    wave_sync();
-                    // (2) the four sub-boxes of every distinct leaf against every query of the group
-                    bool overflow = false;
-                    for (uint32_t base = 0; base < n_ul * RT_LEAF_SUBS; base += 64u) {
-                        const uint32_t e = base + (uint32_t)lane;
-                        const bool have_e = (e >> 2) < n_ul;
-                        const uint32_t sub = have_e ? (uint32_t)L.uleaf[e >> 2] * RT_LEAF_SUBS + (e & 3u) : 0u;
-                        const float *bx = G.pm.sbox + 6 * (size_t)sub;
-                        uint32_t mask = 0;
-#pragma unroll
-                        for (int g = 0; g < RT_GS_GROUP; g++)
-                            if (gq[g] >= 0 && have_e && box_dist2(bx, Q[g].px, Q[g].py, Q[g].pz) < Q[g].rq2) mask |= 1u << g;
-                        const unsigned long long m = __ballot(mask != 0u);
-                        const uint32_t at = n_u + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        if (mask != 0u && at < RT_ULIST_CAP) L.ulist[at] = sub | (mask << 16);
-                        n_u += (uint32_t)__popcll(m);
-                    }
-                    overflow = n_u > RT_ULIST_CAP;
-                    wave_sync();
-                    if (overflow) {
-                        // the union does not fit: give the seats back and take the first query alone (a single list
-                        // has at most RT_LEAFLIST_CAP * RT_LEAF_SUBS <= RT_ULIST_CAP entries)
-#pragma unroll
-                        for (int g = 1; g < RT_GS_GROUP; g++) if (gq[g] >= 0) { todo |= 1ull << gq[g]; gq[g] = -1; qnl[g] = 0; }
-                        ng = 1;
-                        n_u = 0;
-                        for (uint32_t base = 0; base < qnl[0] * RT_LEAF_SUBS; base += 64u) {
-                            const uint32_t e = base + (uint32_t)lane;
-                            const bool have_e = (e >> 2) < qnl[0];
-                            const uint32_t sub = have_e ? (uint32_t)L.leaves[gq[0]][e >> 2] * RT_LEAF_SUBS + (e & 3u) : 0u;
-                            const bool in = have_e && box_dist2(G.pm.sbox + 6 * (size_t)sub, Q[0].px, Q[0].py, Q[0].pz) < Q[0].rq2;
-                            const unsigned long long m = __ballot(in);
-                            if (in) L.ulist[n_u + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sub | (1u << 16);
-                            n_u += (uint32_t)__popcll(m);
-                        }
-                        wave_sync();
-                    }
-                    my_u0 = (uint32_t)lane < n_u ? L.ulist[lane] : 0u;
-                    my_u1 = (uint32_t)lane + 64u < n_u ? L.ulist[lane + 64] : 0u;
-                    my_u2 = (uint32_t)lane + 128u < n_u ? L.ulist[lane + 128] : 0u;
-                    wave_sync();
-                }
-                n_rounds += (uint32_t)ng; n_slow += slow ? 1u : 0u;
-
-                // one pass over the union: f(pa, pb, slot, lane's query mask, wave's query mask), two sub-leaves per step,
-                // the next step's loads in flight while this one is processed
-                auto for_each = [&](auto &&f) {
-                    if (!slow) {
-                        if (n_u == 0) return;
-                        n_reads += n_u; visited += n_u;
-                        const uint32_t n_iter = (n_u + 1u) >> 1;
-                        auto ent_at = [&](uint32_t e) {
-                            return e < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)my_u0, (int)e)
-                                 : e < 128u ? (uint32_t)__builtin_amdgcn_readlane((int)my_u1, (int)(e - 64u))
-                                            : (uint32_t)__builtin_amdgcn_readlane((int)my_u2, (int)(e - 128u));
-                        };
-                        auto ld = [&](uint32_t it, float4 &pa, float4 &pb, uint32_t &slot, uint32_t &lmask, uint32_t &wmask) {
-                            const uint32_t e0 = ent_at(2u * it);
-                            const uint32_t e1 = (2u * it + 1u < n_u) ? ent_at(2u * it + 1u) : 0u;      // mask 0: idle upper half
-                            const uint32_t ent = upper ? e1 : e0;
-                            lmask = ent >> 16;
-                            wmask = (e0 | e1) >> 16;
-                            slot = ((upper && e1 == 0u ? e0 : ent) & 0xFFFFu) * RT_SUB_PHOTONS + l32;
-                            pa = G.pm.pa[slot];
-                            pb = G.pm.pb[slot];
-                        };
-                        float4 a0, b0, a1, b1;
-                        uint32_t s0, s1, lm0, lm1, wm0, wm1;
-                        ld(0u, a0, b0, s0, lm0, wm0);
-                        uint32_t it = 0;
-                        for (; it + 1 < n_iter; it += 2) {
-                            ld(it + 1, a1, b1, s1, lm1, wm1);
-                            f(a0, b0, s0, lm0, wm0);
-                            ld(min(it + 2, n_iter - 1), a0, b0, s0, lm0, wm0);
-                            f(a1, b1, s1, lm1, wm1);
-                        }
-                        if (it < n_iter) f(a0, b0, s0, lm0, wm0);
-                        return;
-                    }
-                    // slow: one query, every sub-leaf box of the map is tested, 64 per step; no list is kept
-                    for (uint32_t base = 0; base < n_sub_total; base += 64u) {
-                        const uint32_t sub = base + (uint32_t)lane;
-                        const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 6 * (size_t)sub, Q[0].px, Q[0].py, Q[0].pz) < Q[0].rq2;
-                        unsigned long long m = __ballot(in);
-                        n_reads += (uint32_t)__popcll(m); visited += (uint32_t)__popcll(m);
-                        while (m) {
-                            const uint32_t e0 = base + (uint32_t)(__ffsll((long long)m) - 1);
-                            m &= m - 1;
-                            uint32_t e1 = 0xFFFFFFFFu;
-                            if (m) { e1 = base + (uint32_t)(__ffsll((long long)m) - 1); m &= m - 1; }
-                            const bool idle = upper && e1 == 0xFFFFFFFFu;
-                            const uint32_t slot = (upper && !idle ? e1 : e0) * RT_SUB_PHOTONS + l32;
-                            f(G.pm.pa[slot], G.pm.pb[slot], slot, idle ? 0u : 1u, 1u);
-                        }
-                    }
-                };
-
-                // ---- pass 1: counts + first-level histograms --------------------------------------------------
-                uint32_t M[RT_GS_GROUP];
-#pragma unroll
-                for (int g = 0; g < RT_GS_GROUP; g++) M[g] = 0;
-                for (int i = lane; i < 256 * RT_GS_GROUP; i += 64) (&L.hist[0][0])[i] = 0;
-                wave_sync();
-                for_each([&](const float4 &pa, const float4 &pb, uint32_t, uint32_t lmask, uint32_t wmask) {
-#pragma unroll
-                    for (int g = 0; g < RT_GS_GROUP; g++) {
-                        if (!((wmask >> g) & 1u)) continue;
-                        const Cand cd = make_cand(pa, pb, Q[g], ((lmask >> g) & 1u) != 0u);
-                        M[g] += (uint32_t)__popcll(__ballot(cd.ok));
-                        if (cd.ok) atomicAdd(&L.hist[g][cd.key >> 16], 1u);
-                    }
-                });
-                wave_sync();
-                // ---- per query: retry / take all / locate the k-th's bin ---------------------------------------
-                // mode: 0 = not in pass 2 (empty seat, retry, or nothing found), 1 = sum everything accepted, 2 = select
-                int mode[RT_GS_GROUP];
-                uint32_t need[RT_GS_GROUP], prefix[RT_GS_GROUP], in_bin[RT_GS_GROUP], bin_mask[RT_GS_GROUP];
-#pragma unroll
-                for (int g = 0; g < RT_GS_GROUP; g++) {
-                    mode[g] = 0; need[g] = K; prefix[g] = 0; in_bin[g] = 0; bin_mask[g] = 0;
-                    if (gq[g] < 0) continue;
-                    const bool final_round = Q[g].rq2 >= r2;
-                    if (!final_round && M[g] <= K) {
-                        float grow = 1.5f * (float)K / (float)(M[g] > 0 ? M[g] : 1u);
-                        grow = fminf(fmaxf(grow, 2.0f), 16.0f);
-                        if (lane == gq[g]) r2cur = fminf(Q[g].rq2 * grow, r2);
-                        continue;                          // stays pending: listed again with the larger radius
-                    }
-                    if (M[g] <= K) { mode[g] = M[g] > 0 ? 1 : 0; continue; }
-                    mode[g] = 2;
-                    int shift = 16;
-                    for (;;) {
-                        uint32_t digit, before, cntb;
-                        hist_locate(L.hist[g], lane, need[g], digit, before, cntb);
-                        need[g] -= before;
-                        prefix[g] |= digit << shift;
-                        in_bin[g] = cntb;
-                        if (in_bin[g] <= 64u || shift == 0) break;
-                        // more than 64 photons in the bin: one more 8-bit level over the photons inside it (this query only)
-                        shift -= 8;
-                        wave_sync();
-                        for (int i = lane; i < 256; i += 64) L.hist[g][i] = 0;
-                        wave_sync();
-                        const uint32_t hi_mask = ~((1u << (shift + 8)) - 1u) & 0xFFFFFFu;
-                        const uint32_t pfx = prefix[g];
-                        for_each([&](const float4 &pa, const float4 &pb, uint32_t, uint32_t lmask, uint32_t wmask) {
-                            if (!((wmask >> g) & 1u)) return;
-                            const Cand cd = make_cand(pa, pb, Q[g], ((lmask >> g) & 1u) != 0u);
-                            if (cd.ok && (cd.key & hi_mask) == pfx) atomicAdd(&L.hist[g][(cd.key >> shift) & 255u], 1u);
-                        });
-                        wave_sync();
-                    }
-                    bin_mask[g] = ~((1u << shift) - 1u) & 0xFFFFFFu;
-                }
-                // ---- pass 2: sums below the bin, the bin's members collected (or, for > 64 equal keys, the first `need`) ----
-                float s_pr[RT_GS_GROUP], s_pg[RT_GS_GROUP], s_pb[RT_GS_GROUP], s_dx[RT_GS_GROUP], s_dy[RT_GS_GROUP], s_dz[RT_GS_GROUP];
-                float tmax[RT_GS_GROUP];
-                uint32_t tie_taken[RT_GS_GROUP];
-#pragma unroll
-                for (int g = 0; g < RT_GS_GROUP; g++) { s_pr[g] = s_pg[g] = s_pb[g] = s_dx[g] = s_dy[g] = s_dz[g] = 0.0f; tmax[g] = 0.0f; tie_taken[g] = 0; }
-                if (lane < RT_GS_GROUP) L.sel_n[lane] = 0;
-                wave_sync();
-                auto accumulate = [&](int g, float dirx, float diry, float dirz, float maxp, uint32_t cbits) {
-                    s_pr[g] += byte_over_255(cbits & 255u) * maxp; s_pg[g] += byte_over_255((cbits >> 8) & 255u) * maxp; s_pb[g] += byte_over_255((cbits >> 16) & 255u) * maxp;
-                    s_dx[g] += dirx * maxp; s_dy[g] += diry * maxp; s_dz[g] += dirz * maxp;
-                };
-                int any_mode = 0;
-#pragma unroll
-                for (int g = 0; g < RT_GS_GROUP; g++) any_mode |= mode[g];
-                if (any_mode) {
-                    for_each([&](const float4 &pa, const float4 &pb, uint32_t slot, uint32_t lmask, uint32_t wmask) {
-#pragma unroll
-                        for (int g = 0; g < RT_GS_GROUP; g++) {
-                            if (mode[g] == 0 || !((wmask >> g) & 1u)) continue;
-                            const Cand cd = make_cand(pa, pb, Q[g], ((lmask >> g) & 1u) != 0u);
-                            bool take = cd.ok;
-                            if (mode[g] == 2) {
-                                const uint32_t kb = cd.key & bin_mask[g];
-                                take = cd.ok && kb < prefix[g];
-                                const bool inb = cd.ok && kb == prefix[g];
-                                const unsigned long long mb = __ballot(inb);
-                                if (mb) {
-                                    if (in_bin[g] <= 64u) {
-                                        uint32_t base = 0;
-                                        const int leader = __ffsll((long long)mb) - 1;
-                                        if (lane == leader) { base = L.sel_n[g]; L.sel_n[g] = base + (uint32_t)__popcll(mb); }
-                                        base = lane_u(base, leader);
-                                        if (inb) {
-                                            const uint32_t at = base + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                                            if (at < 64u) { L.sel_d[g][at] = cd.d2; L.sel_i[g][at] = slot; }
-                                        }
-                                    } else {
-                                        // more than 64 photons share all 24 key bits: take the first `need` in scan order
-                                        const uint32_t rank = tie_taken[g] + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                                        if (inb && rank < need[g]) { take = true; tmax[g] = fmaxf(tmax[g], cd.d2); }
-                                        tie_taken[g] += (uint32_t)__popcll(mb);
-                                    }
-                                }
-                            }
-                            if (take) accumulate(g, pa.w, pb.x, pb.y, pb.z, __float_as_uint(pb.w));
-                        }
-                    });
-                }
-                wave_sync();
-                // ---- per query: exact rank selection inside the bin, area, output ----------------------------------
-#pragma unroll
-                for (int g = 0; g < RT_GS_GROUP; g++) {
-                    if (gq[g] < 0) continue;
-                    const int q = gq[g];
-                    const bool final_round = Q[g].rq2 >= r2;
-                    if (!final_round && M[g] <= K) continue;              // retried
-                    float area_d2 = Q[g].rq2;                              // dist2[0]; only reached with rq2 == r2 when M <= K
-                    if (mode[g] == 2) {
-                        if (in_bin[g] <= 64u) {
-                            const uint32_t n_sel = lane_u(min(L.sel_n[g], 64u), 0);
-                            const bool mine = (uint32_t)lane < n_sel;
-                            const float md = mine ? L.sel_d[g][lane] : 3.0e38f;
-                            uint32_t rank = 0;
-                            for (uint32_t j = 0; j < n_sel; j++) {
-                                const float od = L.sel_d[g][j];
-                                rank += (od < md || (od == md && j < (uint32_t)lane)) ? 1u : 0u;
-                            }
-                            if (mine && rank < need[g]) {
-                                const uint32_t si = L.sel_i[g][lane];
-                                const float4 pa = G.pm.pa[si], pb = G.pm.pb[si];
-                                accumulate(g, pa.w, pb.x, pb.y, pb.z, __float_as_uint(pb.w));
-                                tmax[g] = md;
-                            }
-                        }
-                        area_d2 = wave_max0(tmax[g]);                      // np.dist2[0] = largest kept distance
-                    }
-                    float irr_r = wave_sum(s_pr[g]), irr_g = wave_sum(s_pg[g]), irr_b = wave_sum(s_pb[g]);
-                    float dx = wave_sum(s_dx[g]), dy = wave_sum(s_dy[g]), dz = wave_sum(s_dz[g]);
-                    if (M[g] > 0) {
-                        const float area = (float)M_PI * area_d2;          // :326
-                        if (area > 0) { const float inv = 1.0f / area; irr_r *= inv; irr_g *= inv; irr_b *= inv; }
-                        const float l = sqrtf(dx * dx + dy * dy + dz * dz);    // direction.Normalize() :334
-                        dx /= l; dy /= l; dz /= l;
-                    }
-                    if (G.mode == 1) {
-                        if (lane == 0) {
-                            const size_t qq = (size_t)qbase + (size_t)q;
-                            G.out_irr[3 * qq] = irr_r; G.out_irr[3 * qq + 1] = irr_g; G.out_irr[3 * qq + 2] = irr_b;
-                            G.out_dir[3 * qq] = dx; G.out_dir[3 * qq + 1] = dy; G.out_dir[3 * qq + 2] = dz;
-                        }
-                    } else {
-                        // idr_Color += kd * photonrad * max(0, N.(-dir)) (FIN/main.cpp:701-704), times the ray weight
-                        const float wr = lane_f(b.z, q), wg = lane_f(b.w, q), wb = lane_f(c.x, q);
-                        const uint32_t slot = __float_as_uint(lane_f(c.y, q));
-                        float theta = Q[g].nx * (-dx) + Q[g].ny * (-dy) + Q[g].nz * (-dz);
-                        theta = theta > 0.0f ? theta : 0.0f;
-                        if (lane < 3) {
-                            const float w = lane == 0 ? wr : (lane == 1 ? wg : wb);
-                            const float ir = lane == 0 ? irr_r : (lane == 1 ? irr_g : irr_b);
-                            atomicAdd(G.sample_rgb + 3 * (size_t)slot + lane, (w * ir) * theta);
-                        }
-                    }
-                    if (lane == q) pending = false;
-                }
-                wave_sync();
-            }
-            wave_sync();
-        }
-    }
-    if (lane == 0 && G.stats && visited) {
-        atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * (unsigned long long)RT_SUB_PHOTONS);
-        atomicAdd(&G.stats[ST_GATHER_ROUNDS], (unsigned long long)n_rounds);
-        atomicAdd(&G.stats[ST_GATHER_SLOW], (unsigned long long)n_slow);
-        atomicAdd(&G.stats[ST_GATHER_LEAF_READS], (unsigned long long)n_reads);
-    }
-    if (G.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&G.stats[ST_PHOTON_QUERIES], (unsigned long long)nq);
-}
-
-// ------------------------------------------------------------------------------------------------
 // K6: per pixel, the tail of RenderPixel (FIN/main.cpp:273-338): hits-only average
 // (averageColor :191-199), VariantOverThreshold (:164-189) gate for the second batch, gamma
 // (powf(c, 1.0/gamma) :318-320), Color24 pack (cyColor.h:245-246), z of the last hit sample,
@@ -2613,6 +2257,22 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
     A.div_ns = fastdiv_make((uint32_t)(ns > 0 ? ns : 1));
     const int grid = grid_for((unsigned long long)npix * ns, RT_BLOCK, max_blocks);
     const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
+    C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_d = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
+    // default: the whole ray tree in one persistent launch with LDS ray stacks (FIN / P13 models); RT_TRACER=levels: one
+    // launch per level of the tree (round 1's structure, kept for the other models and for A/B: DESIGN.md section 3)
+    static int wavefront = -1;
+    if (wavefront < 0) { const char *e = getenv("RT_TRACER"); wavefront = (e && !strcmp(e, "levels")) ? 0 : 1; }
+    if (wavefront && (P.shade_model == RT_SHADE_FIN || P.shade_model == RT_SHADE_P13)) {
+        const int wgrid = grid_for((unsigned long long)npix * ns, RT_BLOCK, 256 * RT_WF_WAVES);      // resident workgroups per CU (LDS)
+        if (P.shade_model == RT_SHADE_FIN) {
+            if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+            else hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+        } else {
+            if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_P13, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+            else hipLaunchKernelGGL((k_wavefront<RT_SHADE_P13, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+        }
+        return;
+    }
 #define RT_LAUNCH_PRIMARY(M) do { if (tex) hipLaunchKernelGGL((k_primary<M, true>), dim3(grid), dim3(RT_BLOCK), 0, st, C, A); \
                                   else hipLaunchKernelGGL((k_primary<M, false>), dim3(grid), dim3(RT_BLOCK), 0, st, C, A); } while (0)
     switch (P.shade_model) {
@@ -2630,6 +2290,7 @@ void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, cons
                        int level, int max_blocks)
 {
     ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
+    C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_d = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
     const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
 #define RT_LAUNCH_BOUNCE(M) do { if (tex) hipLaunchKernelGGL((k_bounce<M, true>), dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level); \
                                  else hipLaunchKernelGGL((k_bounce<M, false>), dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level); } while (0)
@@ -2659,12 +2320,7 @@ void rtk_launch_gather(hipStream_t st, const DevPhotonMap &pm, const float4 *qa,
 {
     GatherArgs G; G.pm = pm; G.qa = qa; G.qb = qb; G.qc = qc; G.count_ptr = count_ptr; G.count_cap = count_cap;
     G.k = k; G.radius = radius; G.sample_rgb = sample_rgb; G.out_irr = out_irr; G.out_dir = out_dir; G.mode = mode; G.stats = stats; G.next_batch = next_batch;
-    // RT_GATHER_KERNEL=ring selects round 1's per-query kernel (A/B measurements); the default shares the photon reads
-    // between groups of four neighbouring queries
-    static int use_ring = -1;
-    if (use_ring < 0) { const char *e = getenv("RT_GATHER_KERNEL"); use_ring = (e && !strcmp(e, "ring")) ? 1 : 0; }
-    if (use_ring) hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(64 * RT_GATHER_WAVES), 0, st, G);
-    else hipLaunchKernelGGL(k_gather_shared, dim3(blocks * 4 / 5), dim3(64 * RT_GATHER_WAVES), 0, st, G);   // 4 workgroups per CU (LDS)
+    hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(64 * RT_GATHER_WAVES), 0, st, G);
 }
 
 // Un-interleave an all-gathered frame: rank r contributed its tiles r, r+R, r+2R, ... as `per_rank` packed tiles of
