@@ -159,7 +159,13 @@ typedef struct rt_params {
     int32_t  shadow_samples;     /* MIN_SHADOW_SAMPLES 4 (identical rays at size 0) */
     uint32_t seed;               /* counter-RNG seed for stochastic features        */
     double   gamma;              /* #define gamma 2.2 (a double literal)            */
-    int32_t  reserved[4];
+    /* caustic map (RT_SHADE_P13 / P12 only; P13/main.cpp:518-531): EstimateIrradiance<caustic_k> with
+     * `caustic_radius` on the scene's caustic photons at diffuse hits reached with specount > 2;
+     * caustic_k = 0 (the default, as in the committed reference where the lookup is commented out)
+     * switches it off.  prj13.html quotes k = 400, r = 0.5. */
+    int32_t  caustic_k;
+    float    caustic_radius;
+    int32_t  reserved[2];
 } rt_params;
 
 /* Which tiles of the image this call renders.  Tiles are tile_w x tile_h pixels, numbered
@@ -253,6 +259,9 @@ rt_status rt_scene_get_maps(const rt_scene *s, rt_texmap *material_maps, int32_t
  * (FIN/include/cyPhotonMap.h:196-218): photons[0] unused, photons[1..n_stored] heap-ordered.
  * n_stored = 0 clears the map (photon term contributes 0). */
 rt_status rt_scene_set_photons(rt_scene *s, const rt_photon *photons, uint32_t n_stored);
+/* The second map of RayTracingProj13 (`causticmap`, P13/main.cpp:338,379-404): same format, looked up only
+ * by the P13-family shading models when rt_params.caustic_k > 0. */
+rt_status rt_scene_set_caustic_photons(rt_scene *s, const rt_photon *photons, uint32_t n_stored);
 
 /* Host-side loader with the reference's XML/OBJ schema (FIN/xmlload.cpp:65-554,
  * FIN/include/cyTriMesh.h:263-547, FIN/include/objects.h:137-145).  OBJ names resolve
@@ -316,6 +325,16 @@ rt_status rt_photons_read_dat(const char *path, rt_photon *out, uint32_t cap, ui
  * already scaled by 4*pi/n; balance them with rt_photon_balance before rt_scene_set_photons. */
 rt_status rt_photon_pass(rt_scene *s, int device, uint32_t max_photons, int photon_bounce, uint32_t seed,
                          rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out);
+
+/* The caustic pass of RayTracingProj13 (P13/main.cpp:379-404 + CausticTracing :431-457; a comment block in the
+ * committed file): every emitted photon is followed for up to photon_bounce (CAUSTIC_PHOTON_BOUNCE 5)
+ * RandomPhotonBounce steps; a hit on a diffuse surface is STORED only after more than one specular hit on
+ * the way (hitspec > 1: e.g. into and out of the glass sphere) but COUNTED either way, and emission stops
+ * once `max_diffuse_hits` (MAX_NUM_OF_CAUSTIC_PHOTON) are counted.  Same generator, output format and
+ * 4*pi/n_stored power scaling as rt_photon_pass.  out needs room for max_diffuse_hits + 9 records. */
+rt_status rt_caustic_pass(rt_scene *s, int device, uint32_t max_diffuse_hits, int photon_bounce, uint32_t seed,
+                          rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out);
+
 
 /* ---- rendering: replaces BeginRender/StopRender + RenderPixel + RenderImage progress
  *      (FIN/main.cpp:202-344,984-1012; FIN/include/scene.h:586-589) ---------------------- */

@@ -43,7 +43,7 @@ class Params(C.Structure):
                 ("bounce", C.c_int32), ("hemisphere_sample", C.c_int32), ("knn_k", C.c_int32),
                 ("knn_radius", C.c_float), ("shade_model", C.c_int32),
                 ("shadow_samples", C.c_int32), ("seed", C.c_uint32), ("gamma", C.c_double),
-                ("reserved", C.c_int32 * 4)]
+                ("caustic_k", C.c_int32), ("caustic_radius", C.c_float), ("reserved", C.c_int32 * 2)]
 
 
 def default_params(**kw):
@@ -68,7 +68,8 @@ class _Scene(C.Structure):
                 ("lights", C.c_void_p), ("n_lights", C.c_int32), ("photons", C.c_void_p),
                 ("n_photons", C.c_uint32), ("env", C.c_float * 3), ("bg", C.c_float * 3),
                 ("textures", C.c_void_p), ("n_textures", C.c_int32), ("texels", C.c_void_p),
-                ("material_maps", C.c_void_p), ("env_map", C.c_void_p), ("bg_map", C.c_void_p)]
+                ("material_maps", C.c_void_p), ("env_map", C.c_void_p), ("bg_map", C.c_void_p),
+                ("caustic", C.c_void_p), ("n_caustic", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -126,7 +127,7 @@ class Scene:
 
     def __init__(self, nodes, meshes=(), materials=None, lights=None, photons=None,
                  env=(0, 0, 0), bg=(0, 0, 0), textures=None, texels=None, material_maps=None,
-                 env_map=None, bg_map=None):
+                 env_map=None, bg_map=None, caustic=None):
         self.nodes = _c(nodes, NODE)
         self.meshes = list(meshes)
         self.materials = _c(materials if materials is not None else np.zeros(0, BLINN), BLINN)
@@ -146,6 +147,8 @@ class Scene:
         self.c.material_maps = _p(self.material_maps) if self.material_maps is not None else None
         self.c.env_map = _p(self.env_map) if self.env_map is not None else None
         self.c.bg_map = _p(self.bg_map) if self.bg_map is not None else None
+        self.caustic = _c(caustic, PHOTON) if caustic is not None else np.zeros(0, PHOTON)
+        self.c.caustic, self.c.n_caustic = _p(self.caustic), max(0, len(self.caustic) - 1)
 
 
 def halton(i, base):
@@ -414,7 +417,7 @@ def sample_count_image(cnt):
 
 
 # ---- the product's exported arrays as oracle inputs (same bytes on both sides) -----------------------
-def scene_from_export(export, photons=None, env=None, bg=None):
+def scene_from_export(export, photons=None, env=None, bg=None, caustic=None):
     """orc.Scene over the very arrays raytracing_folder_amd.capi.Scene.export() returns (environment and
     background colours come from the export unless given)."""
     env = tuple(export.get("env", (0, 0, 0))) if env is None else env
@@ -423,7 +426,7 @@ def scene_from_export(export, photons=None, env=None, bg=None):
     return Scene(export["nodes"], meshes, export["materials"], export["lights"], photons, env, bg,
                  textures=export.get("textures"), texels=export.get("texels"),
                  material_maps=export.get("material_maps"), env_map=export.get("env_map"),
-                 bg_map=export.get("bg_map"))
+                 bg_map=export.get("bg_map"), caustic=caustic)
 
 
 def camera_from(cam):
@@ -448,3 +451,12 @@ def set_trace_discarded(on):
 def discarded_rays():
     lib().orc_discarded_rays.restype = C.c_uint64
     return lib().orc_discarded_rays()
+
+
+def caustic_pass(scene, max_diffuse_hits, max_bounce=5, seed=20171203):
+    out = np.zeros(int(max_diffuse_hits) + 9, PHOTON)
+    att = C.c_uint64()
+    lib().orc_caustic_pass.restype = C.c_uint32
+    n = lib().orc_caustic_pass(C.byref(scene.c), C.c_uint32(int(seed)), C.c_uint32(int(max_diffuse_hits)), int(max_bounce),
+                               _p(out), C.byref(att))
+    return out[: n + 1].copy(), att.value

@@ -707,13 +707,13 @@ static v3 attenuation(v3 absorption, float l)
 static float gray3(v3 c);
 static float clampf(float v, float lo, float hi);
 static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3]);
-static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3]);
+static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, int specount, float out[3]);
 static void shade_p6(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3]);
 static void shade_p3(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, float out[3]);
 
 void orc_shade(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h, int bounce, float out[3])
 {
-    if (P->shade_model == RT_SHADE_P13 || P->shade_model == RT_SHADE_P12) shade_p13(s, P, ray, h, bounce, out);
+    if (P->shade_model == RT_SHADE_P13 || P->shade_model == RT_SHADE_P12) shade_p13(s, P, ray, h, bounce, 0, out);   /* Shade(..., bouncelimit, 0), P13/main.cpp:286 */
     else if (P->shade_model == RT_SHADE_P6) shade_p6(s, P, ray, h, bounce, out);
     else if (P->shade_model == RT_SHADE_P3) shade_p3(s, P, ray, h, out);
     else shade_fin(s, P, ray, h, bounce, out);
@@ -871,12 +871,12 @@ static void shade_fin(const orc_scene *s, const rt_params *P, const float ray[6]
 /* MtlBlinn::Shade, P13/main.cpp:485-756 (glossiness jitter needs rand(): only the
  * deterministic reflectionGlossiness == refractionGlossiness == 0 case is restated). */
 static float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   /* P13/main.cpp:98-106 */
-static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *hInfo, int bounceCount, float out[3])
+static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *hInfo, int bounceCount, int specount, float out[3])
 {
     const rt_blinn *m = hit_material(s, hInfo);
     const int p12 = P->shade_model == RT_SHADE_P12;
     v3 ra_color = V3(0, 0, 0), re_color = V3(0, 0, 0), re_ra_color;
-    v3 ambient_color = V3(0, 0, 0), diffuse_color = V3(0, 0, 0);
+    v3 ambient_color = V3(0, 0, 0), diffuse_color = V3(0, 0, 0), cau_Color = V3(0, 0, 0);
     v3 N = v3p(hInfo->N), Pp = v3p(hInfo->p);
     v3 Kd, Ks;
     material_colors(s, hInfo, m, &Kd, &Ks);
@@ -888,6 +888,16 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
             orc_illuminate(s, P, l, hInfo->p, hInfo->N, Il);
             ambient_color = vadd(ambient_color, vmul(v3p(Il), Kd));                   /* :510 */
         } else {
+            /* the caustic lookup the reference keeps in a comment (P13/main.cpp:518-533), live when rt_params.caustic_k > 0:
+             * causticmap.EstimateIrradiance<k>(causticrad, dirc, radius, hInfo.p, &N, ...); cau_Color += Kd*causticrad*theta */
+            if (P->caustic_k > 0 && s->n_caustic > 0 && gray3(v3p(m->diffuse)) > 0 && specount > 2) {
+                float irr[3], dirc[3];
+                orc_estimate_irradiance(s->caustic, s->n_caustic, P->caustic_k, P->caustic_radius, hInfo->p, hInfo->N, irr, dirc);
+                float theta = vdot(N, vneg(v3p(dirc)));
+                theta = (theta > 0.0 ? theta : 0.0f);
+                cau_Color = vadd(cau_Color, vscale(vmul(Kd, v3p(irr)), theta));
+            }
+            specount++;
             orc_illuminate(s, P, l, hInfo->p, hInfo->N, Il);
             v3 I_i = v3p(Il);
             v3 L = vscale(light_direction(l, Pp), (float)-1);
@@ -900,7 +910,7 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
         }
     }
     const uint32_t me = g_rng.node;
-    v3 all = vadd(ambient_color, diffuse_color);                                      /* :622 (idr, cau = 0) */
+    v3 all = vadd(ambient_color, vadd(diffuse_color, cau_Color));                     /* :622 all = ambient + (diffuse + idr + cau), idr = 0 */
     if (p12) {
         /* RayTracingProj12 main.cpp:393-448: cosine-weighted hemisphere rays, HEMISPHERE_SAMPLE at
          * the primary hit and 1 below it; all = ambient + ((diffuse/pi) + idr)*Kd */
@@ -930,7 +940,7 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
                 if (orc_trace(s, P->shade_model, r, &hh)) {
                     float c[3];
                     g_rng.node = child_node(me, 3u + (uint32_t)i);
-                    shade_p13(s, P, r, &hh, bounceCount - 1, c);
+                    shade_p13(s, P, r, &hh, bounceCount - 1, specount, c);
                     g_rng.node = me;
                     ic = v3p(c);
                 } else ic = environment_color(s, v3p(r + 3));
@@ -963,7 +973,7 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
         if (orc_trace(s, P->shade_model, r, &hh)) {
             float c[3];
             g_rng.node = child_node(me, 1u);
-            shade_p13(s, P, r, &hh, bounceCount - 1, c);
+            shade_p13(s, P, r, &hh, bounceCount - 1, specount, c);
             g_rng.node = me;
             re_color = v3p(c);
         } else re_color = environment_color(s, v3p(r + 3));
@@ -1005,7 +1015,7 @@ static void shade_p13(const orc_scene *s, const rt_params *P, const float ray[6]
             if (orc_trace(s, P->shade_model, r, &hh)) {
                 float c[3];
                 g_rng.node = child_node(me, 2u);
-                shade_p13(s, P, r, &hh, bounceCount - 1, c);
+                shade_p13(s, P, r, &hh, bounceCount - 1, specount, c);
                 g_rng.node = me;
                 ra_color = v3p(c);
             } else ra_color = environment_color(s, v3p(r + 3));
@@ -1786,6 +1796,60 @@ int orc_sample_count_image(const uint8_t *sampleCount, int width, int height, ui
         }
     }
     return smax;
+}
+
+/* The caustic loop of generatePhotonMap (P13/main.cpp:383-398) + CausticTracing (:431-457), with FIN's
+ * RandomPhotonBounce and the counter RNG of the photon pass: every diffuse hit is counted, only those behind more
+ * than one specular hit are stored; out is 1-based, returns the number stored. */
+uint32_t orc_caustic_pass(const orc_scene *s, uint32_t seed, uint32_t max_diffuse_hits, int max_bounce,
+                          rt_photon *out, uint64_t *attempts_out)
+{
+    int npl = 0;
+    for (int l = 0; l < s->n_lights; l++) if (s->lights[l].type == RT_LIGHT_POINT) npl++;
+    uint32_t n = 0;
+    uint64_t attempt = 0, counted = 0;
+    memset(&out[0], 0, sizeof(rt_photon));
+    for (; npl > 0 && counted < max_diffuse_hits; attempt++) {
+        philox_t rng;
+        rng.key0 = seed; rng.key1 = 0x52544D49u; rng.c0 = (uint32_t)attempt; rng.c1 = (uint32_t)(attempt >> 32); rng.blk = 0; rng.used = 4;
+        int pick = (int)(philox_next(&rng) * (float)npl);
+        if (pick >= npl) pick = npl - 1;
+        const rt_light *L = 0;
+        for (int l = 0; l < s->n_lights; l++) if (s->lights[l].type == RT_LIGHT_POINT) { if (pick == 0) { L = &s->lights[l]; break; } pick--; }
+        v3 c = v3p(L->intensity);
+        const v3 position = v3p(L->position);
+        const float x = 2 * philox_next(&rng) - 1, y = 2 * philox_next(&rng) - 1, z = 2 * philox_next(&rng) - 1;
+        float ray[6];
+        st3(ray, position);
+        st3(ray + 3, vnorm(vsub(vadd(V3(x, y, z), position), position)));
+        orc_hit h;
+        if (!orc_trace(s, RT_SHADE_FIN, ray, &h)) continue;
+        const rt_blinn *m = hit_material(s, &h);
+        int hitspec = gray3(v3p(m->diffuse)) > 0 ? 0 : 1;                      /* :391-396 */
+        int bounce = max_bounce;
+        uint32_t stored = 0;
+        while (bounce > 0 && random_photon_bounce(m, &h, ray, &c, &rng)) {       /* CausticTracing */
+            orc_hit nh;
+            if (!orc_trace(s, RT_SHADE_FIN, ray, &nh)) break;
+            m = hit_material(s, &nh);
+            if (gray3(v3p(m->diffuse)) > 0) {
+                if (hitspec > 1 && stored < 8) {
+                    float pw[3] = { c.x, c.y, c.z };
+                    orc_photon_pack(nh.p, ray + 3, pw, &out[++n]);
+                    stored++;
+                }
+                counted++;                                                      /* savedPhoton++ (:448) */
+            } else hitspec++;
+            bounce--;
+            h = nh;
+        }
+    }
+    if (n > 0) {
+        const float scale = (float)(1.0 * 4 * M_PI / n);
+        for (uint32_t i = 1; i <= n; i++) out[i].power *= scale;
+    }
+    if (attempts_out) *attempts_out = attempt;
+    return n;
 }
 
 /* generatePhotonMap (FIN/main.cpp:350-396) + PhotonTracing (:439-459) + RandomPhoton (:489-497);

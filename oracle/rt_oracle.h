@@ -49,6 +49,7 @@ typedef struct orc_scene {
     const rt_texture *textures; int32_t n_textures; const uint8_t *texels;
     const rt_texmap *material_maps;                   /* 2 per material (diffuse, specular) or NULL */
     const rt_texmap *env_map, *bg_map;                /* NULL = none */
+    const rt_photon *caustic;   uint32_t n_caustic;   /* the second map (P13's causticmap): balanced, [0] unused */
 } orc_scene;
 
 typedef struct orc_hit {
@@ -124,6 +125,9 @@ int   orc_sample_count_image(const uint8_t *sampleCount, int width, int height, 
  * max_photons + 9 records; returns the photon count */
 uint32_t orc_photon_pass(const orc_scene *s, uint32_t seed, uint32_t max_photons, int max_bounce,
                          rt_photon *out, uint64_t *attempts_out);
+
+uint32_t orc_caustic_pass(const orc_scene *s, uint32_t seed, uint32_t max_diffuse_hits, int max_bounce,
+                          rt_photon *out, uint64_t *attempts_out);
 
 /* cyBVH build (MeanSplit), returns node count incl. unused node 0 */
 int   orc_bvh_build(const float *v, const uint32_t *f, int32_t nf, int32_t max_per_leaf,

@@ -48,7 +48,7 @@ class Params(C.Structure):
                 ("bounce", C.c_int32), ("hemisphere_sample", C.c_int32), ("knn_k", C.c_int32),
                 ("knn_radius", C.c_float), ("shade_model", C.c_int32),
                 ("shadow_samples", C.c_int32), ("seed", C.c_uint32), ("gamma", C.c_double),
-                ("reserved", C.c_int32 * 4)]
+                ("caustic_k", C.c_int32), ("caustic_radius", C.c_float), ("reserved", C.c_int32 * 2)]
 
 
 class TileRange(C.Structure):
@@ -75,10 +75,10 @@ SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_set_nodes", "rt_scene_set_mesh",
     "rt_scene_set_mesh_texcoords", "rt_scene_get_mesh_texcoords",
     "rt_scene_set_materials", "rt_scene_set_lights", "rt_scene_set_environment", "rt_scene_get_environment",
-    "rt_scene_set_photons", "rt_scene_set_textures", "rt_scene_set_material_maps", "rt_scene_set_environment_maps",
+    "rt_scene_set_photons", "rt_scene_set_caustic_photons", "rt_scene_set_textures", "rt_scene_set_material_maps", "rt_scene_set_environment_maps",
     "rt_scene_get_textures", "rt_scene_get_maps", "rt_image_read_rgb", "rt_image_write_png", "rt_image_zbuffer", "rt_image_sample_count", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
     "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
-    "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photons_write_dat", "rt_photons_read_dat", "rt_photon_pass", "rt_render_begin",
+    "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photons_write_dat", "rt_photons_read_dat", "rt_photon_pass", "rt_caustic_pass", "rt_render_begin",
     "rt_render_tiles_device", "rt_render_tiles_packed_device", "rt_tiles_packed_size", "rt_tiles_unpack_device", "rt_render_check", "rt_render_progress", "rt_render_stop", "rt_render_wait",
     "rt_job_stats", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
 ]
@@ -302,6 +302,14 @@ class Scene:
         a = _c(balanced_1based, PHOTON)
         _check(lib().rt_scene_set_photons(self._h, _p(a), C.c_uint32(len(a) - 1)))
 
+    def set_caustic_photons(self, balanced_1based):
+        """the second map (P13's causticmap): same format as set_photons; used when params.caustic_k > 0"""
+        if balanced_1based is None or len(balanced_1based) < 2:
+            _check(lib().rt_scene_set_caustic_photons(self._h, None, C.c_uint32(0)))
+            return
+        a = _c(balanced_1based, PHOTON)
+        _check(lib().rt_scene_set_caustic_photons(self._h, _p(a), C.c_uint32(len(a) - 1)))
+
     def load_xml(self, path):
         _check(lib().rt_scene_load_xml(self._h, os.fsencode(path)))
 
@@ -386,6 +394,14 @@ class Scene:
         n, att = C.c_uint32(), C.c_uint64()
         _check(lib().rt_photon_pass(self._h, int(device), C.c_uint32(int(max_photons)), int(photon_bounce),
                                     C.c_uint32(int(seed)), _p(out), C.c_uint32(len(out)), C.byref(n), C.byref(att)))
+        return out[: n.value + 1].copy(), att.value
+
+    def caustic_pass(self, max_diffuse_hits, photon_bounce=5, seed=20171203, device=0):
+        """P13's caustic loop on the GPU: returns (unbalanced 1-based photon array, attempts)."""
+        out = np.zeros(int(max_diffuse_hits) + 9, PHOTON)
+        n, att = C.c_uint32(), C.c_uint64()
+        _check(lib().rt_caustic_pass(self._h, int(device), C.c_uint32(int(max_diffuse_hits)), int(photon_bounce),
+                                     C.c_uint32(int(seed)), _p(out), C.c_uint32(len(out)), C.byref(n), C.byref(att)))
         return out[: n.value + 1].copy(), att.value
 
     def render(self, cam, params, tiles=None, device=0):

@@ -318,6 +318,7 @@ struct SceneData {
     std::vector<rt_blinn> materials;
     std::vector<rt_light> lights;
     std::vector<rt_photon> photons;    // balanced, [0] unused; empty = no photon map
+    std::vector<rt_photon> caustic_photons;   // the second map (P13's causticmap), same format
     rt_camera camera{};
     float env[3] = {0, 0, 0}, bg[3] = {0, 0, 0};
     bool has_camera = false;

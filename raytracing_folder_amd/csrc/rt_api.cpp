@@ -46,7 +46,7 @@ static int gather_blocks()
 }
 #define GATHER_BLOCKS gather_blocks()
 
-void rtk_launch_photon_trace(hipStream_t, const DevScene &, unsigned long long, uint32_t, uint32_t, int, float *, uint32_t *);
+void rtk_launch_photon_trace(hipStream_t, const DevScene &, unsigned long long, uint32_t, uint32_t, int, float *, uint32_t *, int);
 
 // ---- errors ---------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -123,14 +123,14 @@ struct DevMeshBufs { DevBuf nodes, tris, tri_face, nrm, tex; };
 // the latency of one ray's path) overlap the wide launches of the other.
 #define RT_STREAMS 4                    /* slots compiled in; render_streams() says how many are used */
 struct Workspace {
-    DevBuf sample_rgb, sample_z, sample_hit, rq[2][5], pq[3], counts, pixel_list;
+    DevBuf sample_rgb, sample_z, sample_hit, rq[2][5], pq[3], cq[3], counts, pixel_list;
     size_t samples = 0; uint32_t rq_cap = 0, pq_cap = 0;
     hipStream_t stream = nullptr;       // slot 0 runs on the caller's / the device's main stream instead
     void release()
     {
         for (DevBuf *b : {&sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list}) b->release();
         for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) rq[i][k].release();
-        for (int k = 0; k < 3; k++) pq[k].release();
+        for (int k = 0; k < 3; k++) { pq[k].release(); cq[k].release(); }
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -138,10 +138,11 @@ struct Workspace {
 
 struct DeviceState {
     int device = -1;
-    bool scene_valid = false, photons_valid = false;
+    bool scene_valid = false, photons_valid = false, caustic_valid = false;
     DevBuf nodes, objects, meshes, materials, lights, node_material, textures, texels, material_maps;
     std::vector<DevMeshBufs> mesh_bufs;
     DevBuf pa, pb, tbox, sbox, grid;
+    DevBuf cpa, cpb, ctbox, csbox, cgrid;       // the caustic map
     DevScene scene{};
     Workspace ws[RT_STREAMS];
     DevBuf stats;
@@ -155,7 +156,7 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     void release()
     {
-        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &tbox, &sbox, &grid,
+        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &tbox, &sbox, &grid, &cpa, &cpb, &ctbox, &csbox, &cgrid,
                           &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
         for (Workspace &w : ws) w.release();
@@ -183,9 +184,9 @@ struct rt_scene {
     std::mutex mu;
     std::vector<DeviceState *> devs;
     std::atomic<int> live_jobs{0};
-    void invalidate(bool scene, bool photons)
+    void invalidate(bool scene, bool photons, bool caustic = false)
     {
-        for (DeviceState *d : devs) { if (scene) d->scene_valid = false; if (photons) d->photons_valid = false; }
+        for (DeviceState *d : devs) { if (scene) d->scene_valid = false; if (photons) d->photons_valid = false; if (caustic) d->caustic_valid = false; }
     }
 };
 
@@ -455,6 +456,18 @@ extern "C" rt_status rt_scene_set_photons(rt_scene *s, const rt_photon *photons,
     if (n_stored == 0) s->data.photons.clear();
     else s->data.photons.assign(photons, photons + (size_t)n_stored + 1);
     s->invalidate(false, true);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_set_caustic_photons(rt_scene *s, const rt_photon *photons, uint32_t n_stored)
+{
+    rt_status st = check_idle(s, "rt_scene_set_caustic_photons");
+    if (st) return st;
+    if (n_stored > 0 && !photons) return fail(RT_ERR_ARG, "rt_scene_set_caustic_photons: photons is NULL");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (n_stored == 0) s->data.caustic_photons.clear();
+    else s->data.caustic_photons.assign(photons, photons + (size_t)n_stored + 1);
+    s->invalidate(false, false, true);
     return RT_OK;
 }
 
@@ -805,12 +818,14 @@ struct PRec { float pos[3], dir[3], maxp; uint32_t color; };
 // re-sorted by recursive median splits into 2^D sub-leaves of <= 32 photons with their tight boxes
 // (sbox); every four consecutive sub-leaves are one leaf of the tree the queries walk, whose
 // subtree boxes are kept in heap order (tbox).
-static rt_status upload_photons(rt_scene *s, DeviceState *D)
+static rt_status upload_photons(rt_scene *s, DeviceState *D, bool caustic)
 {
-    DevPhotonMap &pm = D->scene.pm;
+    DevPhotonMap &pm = caustic ? D->scene.cm : D->scene.pm;
     memset(&pm, 0, sizeof pm);
-    D->photons_valid = true;
-    const std::vector<rt_photon> &ph = s->data.photons;
+    (caustic ? D->caustic_valid : D->photons_valid) = true;
+    const std::vector<rt_photon> &ph = caustic ? s->data.caustic_photons : s->data.photons;
+    DevBuf &b_pa = caustic ? D->cpa : D->pa, &b_pb = caustic ? D->cpb : D->pb, &b_tbox = caustic ? D->ctbox : D->tbox,
+           &b_sbox = caustic ? D->csbox : D->sbox, &b_grid = caustic ? D->cgrid : D->grid;
     if (ph.size() < 2) return RT_OK;
     const uint32_t n = (uint32_t)ph.size() - 1;
     const long long half = (long long)(n / 2) - 1;
@@ -869,11 +884,11 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D)
     // over the leaves, the last n_sub ones the sub-leaf boxes
     const std::vector<float> tbox(hbox.begin(), hbox.begin() + 6 * 2 * (size_t)n_leaves);
     rt_status st;
-    if ((st = D->pa.upload(pa.data(), pa.size() * sizeof(float4)))) return st;
-    if ((st = D->pb.upload(pb.data(), pb.size() * sizeof(float4)))) return st;
-    if ((st = D->tbox.upload(tbox.data(), tbox.size() * 4))) return st;
-    if ((st = D->sbox.upload(&hbox[6 * (size_t)n_sub], 6 * (size_t)n_sub * 4))) return st;
-    pm.pa = (const float4 *)D->pa.p; pm.pb = (const float4 *)D->pb.p; pm.tbox = (const float *)D->tbox.p; pm.sbox = (const float *)D->sbox.p;
+    if ((st = b_pa.upload(pa.data(), pa.size() * sizeof(float4)))) return st;
+    if ((st = b_pb.upload(pb.data(), pb.size() * sizeof(float4)))) return st;
+    if ((st = b_tbox.upload(tbox.data(), tbox.size() * 4))) return st;
+    if ((st = b_sbox.upload(&hbox[6 * (size_t)n_sub], 6 * (size_t)n_sub * 4))) return st;
+    pm.pa = (const float4 *)b_pa.p; pm.pb = (const float4 *)b_pb.p; pm.tbox = (const float *)b_tbox.p; pm.sbox = (const float *)b_sbox.p;
     pm.n_leaves = n_leaves; pm.n_photons = (uint32_t)recs.size();
     {   // density grid over the photons' bounding box, at most 64 cells along the longest axis
         const float *rb = &tbox[6];
@@ -888,8 +903,8 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D)
             for (int a = 0; a < 3; a++) g[a] = std::min(dim[a] - 1, std::max(0, (int)((q.pos[a] - rb[a]) / cell)));
             grid[((size_t)g[2] * dim[1] + g[1]) * dim[0] + g[0]]++;
         }
-        if ((st = D->grid.upload(grid.data(), grid.size() * 4))) return st;
-        pm.grid = (const uint32_t *)D->grid.p;
+        if ((st = b_grid.upload(grid.data(), grid.size() * 4))) return st;
+        pm.grid = (const uint32_t *)b_grid.p;
         for (int a = 0; a < 3; a++) { pm.grid_min[a] = rb[a]; pm.grid_dim[a] = dim[a]; }
         pm.cell = cell; pm.inv_cell = 1.0f / cell;
     }
@@ -907,8 +922,9 @@ static rt_status prepare_device(rt_scene *s, int device, DeviceState **out)
     DeviceState *D = device_state(s, device);
     if (!D->stream) HIP_TRY(hipStreamCreateWithFlags(&D->stream, hipStreamNonBlocking));
     rt_status st;
-    if (!D->scene_valid) { const DevPhotonMap keep = D->scene.pm; if ((st = upload_scene(s, D))) return st; D->scene.pm = keep; }
-    if (!D->photons_valid) if ((st = upload_photons(s, D))) return st;
+    if (!D->scene_valid) { const DevPhotonMap keep = D->scene.pm, keepc = D->scene.cm; if ((st = upload_scene(s, D))) return st; D->scene.pm = keep; D->scene.cm = keepc; }
+    if (!D->photons_valid) if ((st = upload_photons(s, D, false))) return st;
+    if (!D->caustic_valid) if ((st = upload_photons(s, D, true))) return st;
     *out = D;
     return RT_OK;
 }
@@ -936,7 +952,7 @@ static int render_streams()
     return v < 1 ? 1 : (v > RT_STREAMS ? RT_STREAMS : v);
 }
 
-static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int bounce, size_t list_pixels, int fan = 2)
+static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int bounce, size_t list_pixels, int fan = 2, bool caustic = false)
 {
     rt_status st;
     Workspace &w = D->ws[slot];
@@ -961,6 +977,7 @@ static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int 
     if ((st = w.sample_hit.ensure(samples))) return st;
     for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) if ((st = w.rq[i][k].ensure((size_t)rq_cap * 16))) return st;
     for (int k = 0; k < 3; k++) if ((st = w.pq[k].ensure((size_t)pq_cap * 16))) return st;
+    if (caustic) for (int k = 0; k < 3; k++) if ((st = w.cq[k].ensure((size_t)pq_cap * 16))) return st;
     if ((st = w.counts.ensure(CNT_TOTAL * 4))) return st;
     if ((st = w.pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
     if (!D->stats.p) { if ((st = D->stats.ensure(ST_COUNT * 8))) return st; }
@@ -979,6 +996,7 @@ static DevWork make_work(DeviceState *D, int slot)
         W.rq[i].d = (uint4 *)w.rq[i][3].p; W.rq[i].e = (float4 *)w.rq[i][4].p; W.rq[i].cap = w.rq_cap;
     }
     W.pq.qa = (float4 *)w.pq[0].p; W.pq.qb = (float4 *)w.pq[1].p; W.pq.qc = (float4 *)w.pq[2].p; W.pq.cap = w.pq_cap;
+    W.cq.qa = (float4 *)w.cq[0].p; W.cq.qb = (float4 *)w.cq[1].p; W.cq.qc = (float4 *)w.cq[2].p; W.cq.cap = w.cq[0].p ? w.pq_cap : 0;
     W.counts = (uint32_t *)w.counts.p; W.pixel_list = (uint32_t *)w.pixel_list.p;
     W.stats = (unsigned long long *)D->stats.p;
     return W;
@@ -1038,6 +1056,7 @@ static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const 
         return fail(RT_ERR_ARG, "render: hemisphere_sample must be 1..256 for RT_SHADE_P12");
     if (p->knn_k < 1 || p->knn_k > 65536 || !(p->knn_radius > 0)) return fail(RT_ERR_ARG, "render: bad photon gather parameters");
     if (!(p->gamma > 0)) return fail(RT_ERR_ARG, "render: gamma must be positive");
+    if (p->caustic_k < 0 || p->caustic_k > 65536 || (p->caustic_k > 0 && !(p->caustic_radius > 0))) return fail(RT_ERR_ARG, "render: bad caustic gather parameters");
     if (t->tile_w <= 0 || t->tile_h <= 0 || t->stride <= 0 || t->first < 0) return fail(RT_ERR_ARG, "render: bad tile range");
     if (p->shadow_samples > 32) return fail(RT_ERR_LIMIT, "render: at most 32 shadow samples per light");
     return RT_OK;
@@ -1073,6 +1092,12 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
     if (D->scene.pm.n_leaves) {
         rtk_launch_gather(st, D->scene.pm, W.pq.qa, W.pq.qb, W.pq.qc, W.counts + CNT_PHOTONQ, W.pq.cap, P.knn_k, P.knn_radius,
                           W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, W.counts + CNT_GATHER_NEXT);
+        if ((s = mark(2))) return s;
+    }
+    if (D->scene.cm.n_leaves && P.caustic_k > 0 && W.cq.cap) {
+        // the P13-family models queued their caustic lookups separately: same kernel on the second map
+        rtk_launch_gather(st, D->scene.cm, W.cq.qa, W.cq.qb, W.cq.qc, W.counts + CNT_CAUSTICQ, W.cq.cap, P.caustic_k, P.caustic_radius,
+                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, W.counts + CNT_GATHER_NEXT2);
         if ((s = mark(2))) return s;
     }
     HIP_TRY(hipGetLastError());
@@ -1128,7 +1153,8 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
             if (free_b < first + first / 4 + (total_b >> 3)) break;
         }
         if ((st = ensure_workspace(D, i, (size_t)ppc * p->max_sample, p->bounce, (size_t)ppc,
-                                   p->shade_model == RT_SHADE_P12 && p->hemisphere_sample > 1 ? 1 + p->hemisphere_sample : 2))) return st;
+                                   p->shade_model == RT_SHADE_P12 && p->hemisphere_sample > 1 ? 1 + p->hemisphere_sample : 2,
+                                   p->caustic_k > 0 && D->scene.cm.n_leaves != 0))) return st;
         Ws[i] = make_work(D, i);
         n_ready++;
     }
@@ -1522,7 +1548,7 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
     if ((st = order_after_pending(D, D->stream))) return st;
     const size_t limit = chunk_samples_limit();
     const size_t chunk = (size_t)std::min<int64_t>(n, (int64_t)limit);
-    if ((st = ensure_workspace(D, 0, chunk, pv.bounce, 1))) return st;
+    if ((st = ensure_workspace(D, 0, chunk, pv.bounce, 1, 2, pv.caustic_k > 0 && D->scene.cm.n_leaves != 0))) return st;
     const DevWork W = make_work(D, 0);
     DevCamera dc; camera_setup(cam, dc);
     DevTiles dt; memset(&dt, 0, sizeof dt);
@@ -1565,46 +1591,67 @@ static void pack_photon(const float *rec, rt_photon &o)
     }
 }
 
-extern "C" rt_status rt_photon_pass(rt_scene *s, int device, uint32_t max_photons, int photon_bounce, uint32_t seed,
-                                    rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out)
+// generatePhotonMap's two loops (P13/main.cpp:338-404): mode 0 = the photon map (stop when max_count photons are STORED),
+// mode 1 = the caustic map (stop when max_count diffuse hits are COUNTED; only those behind more than one specular
+// hit are stored).  Attempts are consumed in order, the count checked between attempts like the reference's while().
+static rt_status photon_pass(rt_scene *s, int device, uint32_t max_count, int photon_bounce, uint32_t seed, int mode,
+                             rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out, const char *who)
 {
-    if (!s || !out || !n_out) return fail(RT_ERR_ARG, "rt_photon_pass: NULL argument");
-    if (max_photons == 0 || photon_bounce < 1 || photon_bounce > 8) return fail(RT_ERR_ARG, "rt_photon_pass: need max_photons > 0 and 1 <= photon_bounce <= 8");
-    if (out_cap < max_photons + 8 + 1) return fail(RT_ERR_ARG, "rt_photon_pass: out must hold max_photons + 9 records (index 0 unused, up to 7 photons of overshoot)");
+    if (!s || !out || !n_out) return fail(RT_ERR_ARG, "%s: NULL argument", who);
+    if (max_count == 0 || photon_bounce < 1 || photon_bounce > 8) return fail(RT_ERR_ARG, "%s: need a positive count and 1 <= photon_bounce <= 8", who);
+    if (out_cap < max_count + 8 + 1) return fail(RT_ERR_ARG, "%s: out must hold the count + 9 records (index 0 unused, up to 7 photons of overshoot)", who);
     DeviceState *D = nullptr;
     rt_status st = prepare_device(s, device, &D);
     if (st) return st;
     bool have_source = false;
     for (const rt_light &l : s->data.lights) if (l.type == RT_LIGHT_POINT) have_source = true;
-    if (!have_source) return fail(RT_ERR_STATE, "rt_photon_pass: the scene has no photon source (point light)");
+    if (!have_source) return fail(RT_ERR_STATE, "%s: the scene has no photon source (point light)", who);
     DeviceClaim claim(D);
-    if (!claim.ok) return fail(RT_ERR_STATE, "rt_photon_pass: another call on this scene is using device %d", device);
+    if (!claim.ok) return fail(RT_ERR_STATE, "%s: another call on this scene is using device %d", who, device);
     if ((st = order_after_pending(D, D->stream))) return st;
     const uint32_t batch = 1u << 18;
     if ((st = D->t_out[0].ensure((size_t)batch * 8 * 9 * 4))) return st;
     if ((st = D->t_out[1].ensure((size_t)batch * 4))) return st;
     std::vector<float> recs((size_t)batch * 8 * 9);
     std::vector<uint32_t> counts(batch);
-    uint32_t n = 0;
+    uint32_t n = 0;                 // photons stored
+    uint64_t counted = 0;           // what the loop condition counts: stored photons (mode 0) or diffuse hits (mode 1)
     uint64_t attempts = 0;
     memset(&out[0], 0, sizeof(rt_photon));
     int empty_batches = 0;
-    while (n < max_photons) {
-        rtk_launch_photon_trace(D->stream, D->scene, attempts, batch, seed, photon_bounce, (float *)D->t_out[0].p, (uint32_t *)D->t_out[1].p);
+    while (counted < max_count) {
+        rtk_launch_photon_trace(D->stream, D->scene, attempts, batch, seed, photon_bounce, (float *)D->t_out[0].p, (uint32_t *)D->t_out[1].p, mode);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(D->stream));
         HIP_TRY(hipMemcpy(recs.data(), D->t_out[0].p, recs.size() * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(counts.data(), D->t_out[1].p, counts.size() * 4, hipMemcpyDeviceToHost));
-        const uint32_t before = n;
+        const uint64_t before = counted;
         uint32_t a = 0;
-        for (; a < batch && n < max_photons; a++)          // the reference checks the count between attempts (:362)
-            for (uint32_t j = 0; j < counts[a]; j++) pack_photon(&recs[((size_t)a * 8 + j) * 9], out[++n]);
+        for (; a < batch && counted < max_count; a++) {    // the reference checks the count between attempts (:341, :383)
+            const uint32_t stored = counts[a] & 0xFFFFu, hits = counts[a] >> 16;
+            for (uint32_t j = 0; j < stored && n + 1 < out_cap; j++) pack_photon(&recs[((size_t)a * 8 + j) * 9], out[++n]);
+            counted += mode == 0 ? stored : hits;
+        }
         attempts += a;
-        if (n == before && ++empty_batches >= 4) return fail(RT_ERR_STATE, "rt_photon_pass: no photon is ever stored in this scene");
+        if (counted == before && ++empty_batches >= 4) return fail(RT_ERR_STATE, "%s: no photon is ever stored in this scene", who);
     }
-    const float scale = (float)(1.0 * 4 * M_PI / n);       // ScalePhotonPowers(1.0*4*M_PI/NumPhotons), :396
-    for (uint32_t i = 1; i <= n; i++) out[i].power *= scale;
+    if (n > 0) {
+        const float scale = (float)(1.0 * 4 * M_PI / n);       // ScalePhotonPowers(1.0*4*M_PI/NumPhotons), :366 / :400
+        for (uint32_t i = 1; i <= n; i++) out[i].power *= scale;
+    }
     *n_out = n;
     if (attempts_out) *attempts_out = attempts;
     return RT_OK;
+}
+
+extern "C" rt_status rt_photon_pass(rt_scene *s, int device, uint32_t max_photons, int photon_bounce, uint32_t seed,
+                                    rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out)
+{
+    return photon_pass(s, device, max_photons, photon_bounce, seed, 0, out, out_cap, n_out, attempts_out, "rt_photon_pass");
+}
+
+extern "C" rt_status rt_caustic_pass(rt_scene *s, int device, uint32_t max_diffuse_hits, int photon_bounce, uint32_t seed,
+                                     rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out)
+{
+    return photon_pass(s, device, max_diffuse_hits, photon_bounce, seed, 1, out, out_cap, n_out, attempts_out, "rt_caustic_pass");
 }

@@ -91,6 +91,7 @@ struct DevScene {
     int32_t n_nodes, n_objects, n_meshes, n_materials, n_lights;
     float env[3], bg[3];
     DevPhotonMap pm;
+    DevPhotonMap cm;             // caustic map (P13-family models, rt_params.caustic_k > 0)
     // textures: all NULL / RT_MAP_NONE when the scene has none (then no uvw is computed either)
     const rt_texture *textures; const uint8_t *texels; int32_t n_textures;
     const rt_texmap *material_maps;          // 2 per material, or NULL
@@ -174,15 +175,18 @@ struct DevWork {
     uint8_t *sample_hit;      // [chunk_pixels*max_sample]
     DevRayQueue rq[2];
     DevPhotonQueue pq;
-    uint32_t *counts;         // [0..15] ray-queue counts per level, [16] photon queue, [17] pixel list
+    DevPhotonQueue cq;        // queries against the caustic map (buffers exist only when it is in use)
+    uint32_t *counts;         // see the CNT_* indices below
     uint32_t *pixel_list;     // pixels (chunk-local) that take the second sample batch
     unsigned long long *stats;
 };
 #define CNT_PHOTONQ 16
 #define CNT_GATHER_NEXT 17     // work counters of k_gather, one per XCD (8): query batches handed out so far from each segment
 #define CNT_PRIMARY_NEXT 25    // work counter of k_wavefront: batches of 256 primary samples handed out so far
-#define CNT_RESET   26         // counters [0, CNT_RESET) are cleared before every pass
-#define CNT_PIXLIST 30         // survives the passes of a chunk
-#define CNT_TOTAL   32
+#define CNT_CAUSTICQ 26        // caustic-map query count
+#define CNT_GATHER_NEXT2 27    // the eight work counters of the caustic gather
+#define CNT_RESET   35         // counters [0, CNT_RESET) are cleared before every pass
+#define CNT_PIXLIST 46         // survives the passes of a chunk
+#define CNT_TOTAL   48
 
 #endif

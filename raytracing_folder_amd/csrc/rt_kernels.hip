@@ -436,7 +436,8 @@ __device__ __forceinline__ int __reduce_max_sync_compat(int v)
     return v;
 }
 
-struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; bool primary; uint32_t node, sample; V3 side_dir, side_K; };
+struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; bool primary; uint32_t node, sample; V3 side_dir, side_K;
+                uint32_t spec; };      // Shade's `specount` argument (P13/main.cpp:485): lights seen on the way, for the caustic lookup
 
 struct ShadeCtx {
     DevScene S; DevWork W; rt_params P;
@@ -627,7 +628,7 @@ __device__ __forceinline__ void add_sample(const ShadeCtx &C, uint32_t slot, V3 
 template <bool SIDE = false>
 __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 d, V3 thr, V3 absorb,
                                          uint32_t slot, int bounce, uint32_t kind, uint32_t node, uint32_t sample,
-                                         V3 side_dir = V3{0, 0, 0}, V3 side_K = V3{0, 0, 0})
+                                         V3 side_dir = V3{0, 0, 0}, V3 side_K = V3{0, 0, 0}, uint32_t spec = 0)
 {
     if (!SIDE && C.lds_count) {
         // workgroup-local stack first (LDS atomic, one per wave); what does not fit goes to the global queue
@@ -636,7 +637,7 @@ __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 
             C.lds_a[at] = make_float4(o.x, o.y, o.z, d.x);
             C.lds_b[at] = make_float4(d.y, d.z, thr.x, thr.y);
             C.lds_c[at] = make_float4(thr.z, absorb.x, absorb.y, absorb.z);
-            C.lds_d[at] = make_uint4(slot, (uint32_t)bounce | (kind << 8), node, sample);
+            C.lds_d[at] = make_uint4(slot, (uint32_t)bounce | (kind << 8) | (spec << 16), node, sample);
         }
         pred = pred && at >= C.lds_cap;
         if (!__any(pred)) return;
@@ -650,19 +651,20 @@ __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 
                 C.qout.c[idx] = make_float4(thr.z, absorb.x, side_K.y, side_K.z);
                 C.qout.e[idx] = make_float4(side_dir.x, side_dir.y, side_dir.z, side_K.x);
             } else C.qout.c[idx] = make_float4(thr.z, absorb.x, absorb.y, absorb.z);
-            C.qout.d[idx] = make_uint4(slot, (uint32_t)bounce | (kind << 8), node, sample);
+            C.qout.d[idx] = make_uint4(slot, (uint32_t)bounce | (kind << 8) | (spec << 16), node, sample);
         } else atomicAdd(&C.W.stats[ST_QUEUE_OVERFLOW], 1ull);
     }
 }
 
-__device__ __forceinline__ void push_photon_query(const ShadeCtx &C, bool pred, V3 p, V3 N, V3 w, uint32_t slot)
+__device__ __forceinline__ void push_photon_query(const ShadeCtx &C, bool pred, V3 p, V3 N, V3 w, uint32_t slot, bool caustic = false)
 {
-    const uint32_t idx = wave_push(pred, C.W.counts + CNT_PHOTONQ);
+    const DevPhotonQueue &Q = caustic ? C.W.cq : C.W.pq;
+    const uint32_t idx = wave_push(pred, C.W.counts + (caustic ? CNT_CAUSTICQ : CNT_PHOTONQ));
     if (pred) {
-        if (idx < C.W.pq.cap) {
-            C.W.pq.qa[idx] = make_float4(p.x, p.y, p.z, N.x);
-            C.W.pq.qb[idx] = make_float4(N.y, N.z, w.x, w.y);
-            C.W.pq.qc[idx] = make_float4(w.z, __uint_as_float(slot), 0.f, 0.f);
+        if (idx < Q.cap) {
+            Q.qa[idx] = make_float4(p.x, p.y, p.z, N.x);
+            Q.qb[idx] = make_float4(N.y, N.z, w.x, w.y);
+            Q.qc[idx] = make_float4(w.z, __uint_as_float(slot), 0.f, 0.f);
         } else atomicAdd(&C.W.stats[ST_QUEUE_OVERFLOW], 1ull);
     }
 }
@@ -678,6 +680,8 @@ struct ShadeOut {
     V3 kd, N;                        // photon query: diffuse colour and shading normal
     bool want_side;                  // P6: a reflection ray that exists only if the refraction ray hits
     V3 side_dir, side_K;
+    int n_caustic;                   // P13: caustic-map lookups this hit makes (one per light past specount > 2, all identical)
+    uint32_t spec_out;               // P13: specount handed to the children
     int n_gi;                        // P12: hemisphere rays to spawn (weights/dirs are drawn at push time)
     V3 gi_x, gi_y, gi_z;             // P12: frame of the hemisphere
 };
@@ -756,7 +760,7 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
 // child refraction*ra_ratio*exp(-absorption.r * z_child) (z_child = BIGFLOAT on a miss).
 template <int MODEL, bool TEX>
 __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
-                          ShadeOut &o, uint32_t *stack, Counters &cnt)
+                          ShadeOut &o, uint32_t *stack, Counters &cnt, uint32_t spec_in)
 {
     constexpr bool p12 = MODEL == RT_SHADE_P12;
     const rt_blinn &m = S.materials[S.node_material[h.node]];
@@ -766,11 +770,17 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
     material_colors<TEX>(S, h, m, Kd, Ks);
     const float alpha = m.glossiness;
     V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
+    uint32_t spec = spec_in;
+    int n_caustic = 0;
     for (int i = 0; i < S.n_lights; i++) {
         const rt_light &l = S.lights[i];
         const V3 Il = illuminate<MODEL>(S, P, l, i, Pp, rc, stack, cnt);
         if (l.type == RT_LIGHT_AMBIENT) ambient = ambient + Il * Kd;                     // :510
         else {
+            // the caustic lookup the reference sketches in a comment (:518-533): per non-ambient light, on a photon
+            // surface (diffuse.Gray() > 0), once specount has passed 2; specount++ after every such light
+            if (gray(ld3(m.diffuse)) > 0 && spec > 2u) n_caustic++;
+            spec++;
             V3 L = light_direction(l, Pp) * (float)-1;
             if (!p12) L = normalize(L);                                                   // P13 adds L.Normalize() (:540)
             const V3 V = normalize(-ray_d);
@@ -781,6 +791,8 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
         }
     }
     o.color = ambient + diffuse;                                                          // :622
+    o.spec_out = spec > 255u ? 255u : spec;
+    o.n_caustic = (P.caustic_k > 0 && S.cm.n_leaves != 0) ? n_caustic : 0;
     o.n_gi = 0;
     if (p12) {
         // RayTracingProj12 main.cpp:393-448: all = ambient + ((diffuse/pi) + idr)*Kd, idr = mean over the
@@ -981,6 +993,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
     o.rdir = o.tdir = mk(0, 0, 1); o.rK = o.tK = o.child_absorb = o.kd = o.N = mk(0, 0, 0);
     o.n_gi = 0; o.gi_x = o.gi_y = o.gi_z = mk(0, 0, 1);
     o.want_side = false; o.side_dir = mk(0, 0, 1); o.side_K = mk(0, 0, 0);
+    o.n_caustic = 0; o.spec_out = in.spec;
     constexpr bool p6 = MODEL == RT_SHADE_P6, p3 = MODEL == RT_SHADE_P3;
     bool spawn_side = false;
     if (active && !in.primary) {
@@ -1002,7 +1015,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
         RngCtx rc; rc.seed = P.seed; rc.sample = in.sample; rc.node = in.node;
         if (p3) shade_p3<TEX>(S, P, h, in.o, rc, o, stack, cnt);
         else if (p6) shade_p6<TEX>(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
-        else if (p13) shade_p13<MODEL, TEX>(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
+        else if (p13) shade_p13<MODEL, TEX>(S, P, h, in.d, in.bounce, rc, o, stack, cnt, in.spec);
         else shade_fin<TEX>(S, P, h, in.d, in.bounce, rc, o, stack, cnt);
         add_sample(C, in.slot, thr * o.color, in.primary);
         // a child (or query) whose accumulated weight is exactly zero cannot change the pixel
@@ -1013,7 +1026,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
     }
     // pushes are wave-collective: every lane of the wave reaches them
     push_ray(C, o.want_refl, h.p, o.rdir, thr * o.rK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFLECT,
-             child_node(in.node, 1u), in.sample);
+             child_node(in.node, 1u), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out);
     if (p6) {
         const V3 sK = thr * o.side_K;
         push_ray<true>(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
@@ -1022,8 +1035,13 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
         push_ray(C, spawn_side, in.o, in.side_dir, in.side_K, mk(0, 0, 0), in.slot, in.bounce, KIND_REFLECT, child_node(in.node, 4u), in.sample);
     } else
     push_ray(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
-             child_node(in.node, 2u), in.sample);
+             child_node(in.node, 2u), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out);
     push_photon_query(C, o.want_photon, h.p, o.N, thr * o.kd, in.slot);
+    if (p13) {
+        // cau_Color += Kd * causticrad * theta, once per counted light (P13/main.cpp:518-531): one query, weight x count
+        const V3 wc = (thr * o.kd) * (float)o.n_caustic;
+        push_photon_query(C, active && hit && o.n_caustic > 0 && (wc.x != 0.f || wc.y != 0.f || wc.z != 0.f), h.p, o.N, wc, in.slot, true);
+    }
     if (MODEL == RT_SHADE_P12) {
         // hemisphere rays: idr += childColour * (dir.N) / Nofsample, times Kd (main.cpp:420-446)
         const int n_max = __reduce_max_sync_compat(o.n_gi);
@@ -1043,7 +1061,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
                 hd = normalize(hd);                        // Ray_idr.dir.Normalize() (:433)
                 want = (w.x != 0.f || w.y != 0.f || w.z != 0.f);
             }
-            push_ray(C, want, h.p, hd, w, mk(0, 0, 0), in.slot, in.bounce - 1, KIND_GI, child_node(in.node, 3u + (uint32_t)i), in.sample);
+            push_ray(C, want, h.p, hd, w, mk(0, 0, 0), in.slot, in.bounce - 1, KIND_GI, child_node(in.node, 3u + (uint32_t)i), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out);
         }
     }
 }
@@ -1105,7 +1123,7 @@ __device__ __forceinline__ bool primary_setup(const ShadeCtx &C, const PrimaryAr
 {
     in.thr = mk(1.f, 1.f, 1.f); in.absorb = mk(0, 0, 0); in.bounce = C.P.bounce; in.kind = KIND_REFLECT; in.primary = true;
     in.o = mk(0, 0, 0); in.d = mk(0, 0, 1); in.slot = 0; in.node = 1; in.sample = 0;
-    in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
+    in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0); in.spec = 0;
     if (gid >= total) return false;
     uint32_t pi, jj;
     if (total <= 0xFFFFFFFFull) { pi = fastdiv((uint32_t)gid, A.div_ns); jj = (uint32_t)gid - pi * (uint32_t)A.ns; }
@@ -1192,7 +1210,7 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
         const bool active = gid < total;
         PathIn in;
         in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
-        in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0;
+        in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0; in.spec = 0;
         in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
         if (active) {
 #ifdef RT_BOUNCE_SCRAMBLE          /* experiment: destroy the queue's coherence inside 64 Ki-ray windows */
@@ -1205,7 +1223,7 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
             const uint4 dd = qin.d[src];
             in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
             in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
-            in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.node = dd.z; in.sample = dd.w;
+            in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.spec = (dd.y >> 16) & 0xFFu; in.node = dd.z; in.sample = dd.w;
             if (MODEL == RT_SHADE_P6 && in.kind == KIND_REFRACT) {
                 const float4 e = qin.e[src];
                 in.side_dir = mk(e.x, e.y, e.z); in.side_K = mk(e.w, c.z, c.w);
@@ -1267,7 +1285,7 @@ __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES, RT_WF_WAVES))) __global__ __laun
             const uint32_t n = min(waiting, (uint32_t)RT_BLOCK);
             active = threadIdx.x < n;
             in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
-            in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0;
+            in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0; in.spec = 0;
             in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
             if (active) {
                 const uint32_t src = waiting - 1u - threadIdx.x;          // newest (deepest) first: the stack stays shallow
@@ -1275,7 +1293,7 @@ __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES, RT_WF_WAVES))) __global__ __laun
                 const uint4 dd = s_qd[src];
                 in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
                 in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
-                in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.node = dd.z; in.sample = dd.w;
+                in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.spec = (dd.y >> 16) & 0xFFu; in.node = dd.z; in.sample = dd.w;
                 if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
             }
             __syncthreads();                              // all pops read before anything is pushed over them
@@ -1351,7 +1369,8 @@ struct PhotonArgs {
     unsigned long long first_attempt; uint32_t n_attempts;
     uint32_t seed; int max_bounce;
     float *out;            // [n_attempts][RT_PHOTON_SLOTS][9]: pos, dir, power
-    uint32_t *count;       // [n_attempts]
+    uint32_t *count;       // [n_attempts]: photons stored | diffuse hits counted << 16
+    int mode;              // 0: photon map (PhotonTracing), 1: caustic map (CausticTracing)
 };
 
 
@@ -1430,7 +1449,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_photon_trace(DevScene S, PhotonArg
     // choose one photon source uniformly (the reference hard-codes two lights, :367-370)
     int npl = 0;
     for (int l = 0; l < S.n_lights; l++) if (S.lights[l].type == RT_LIGHT_POINT) npl++;
-    uint32_t stored = 0;
+    uint32_t stored = 0, hits = 0;
     float *out = A.out + (size_t)i * RT_PHOTON_SLOTS * 9;
     if (npl > 0) {
         int pick = (int)(rng.next() * (float)npl);
@@ -1445,6 +1464,30 @@ __global__ __launch_bounds__(RT_BLOCK) void k_photon_trace(DevScene S, PhotonArg
         V3 rp = position;
         V3 rd = normalize((mk(x, y, z) + position) - position);
         Hit h;
+        if (A.mode == 1) {
+            // caustic pass (P13/main.cpp:383-398 + CausticTracing :431-457): the first hit sets hitspec (0 on a photon
+            // surface, else 1); then every diffuse hit is COUNTED and, behind more than one specular hit, STORED
+            if (trace<false, RT_SHADE_FIN>(S, rp, rd, BIGFLOAT, h, stack, cnt)) {
+                const rt_blinn *m = &S.materials[S.node_material[h.node]];
+                int hitspec = gray(ld3(m->diffuse)) > 0 ? 0 : 1;
+                int bounce = A.max_bounce;
+                while (bounce > 0 && random_photon_bounce(*m, h, rp, rd, c, rng)) {
+                    Hit nh;
+                    if (!trace<false, RT_SHADE_FIN>(S, rp, rd, BIGFLOAT, nh, stack, cnt)) break;
+                    m = &S.materials[S.node_material[nh.node]];
+                    if (gray(ld3(m->diffuse)) > 0) {
+                        if (hitspec > 1 && stored < RT_PHOTON_SLOTS) {
+                            float *o = out + 9 * stored;
+                            o[0] = nh.p.x; o[1] = nh.p.y; o[2] = nh.p.z; o[3] = rd.x; o[4] = rd.y; o[5] = rd.z; o[6] = c.x; o[7] = c.y; o[8] = c.z;
+                            stored++;
+                        }
+                        hits++;
+                    } else hitspec++;
+                    bounce--;
+                    h = nh;
+                }
+            }
+        } else
         if (trace<false, RT_SHADE_FIN>(S, rp, rd, BIGFLOAT, h, stack, cnt)) {
             const rt_blinn *m = &S.materials[S.node_material[h.node]];
             if (gray(ld3(m->diffuse)) > 0) {                             // IsPhotonSurface, materials.h:97
@@ -1464,13 +1507,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_photon_trace(DevScene S, PhotonArg
             }
         }
     }
-    A.count[i] = stored;
+    A.count[i] = stored | (hits << 16);
 }
 
 void rtk_launch_photon_trace(hipStream_t st, const DevScene &S, unsigned long long first_attempt, uint32_t n_attempts,
-                             uint32_t seed, int max_bounce, float *out, uint32_t *count)
+                             uint32_t seed, int max_bounce, float *out, uint32_t *count, int mode)
 {
-    PhotonArgs A; A.first_attempt = first_attempt; A.n_attempts = n_attempts; A.seed = seed; A.max_bounce = max_bounce; A.out = out; A.count = count;
+    PhotonArgs A; A.first_attempt = first_attempt; A.n_attempts = n_attempts; A.seed = seed; A.max_bounce = max_bounce; A.out = out; A.count = count; A.mode = mode;
     hipLaunchKernelGGL(k_photon_trace, dim3((n_attempts + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, A);
 }
 
