@@ -250,7 +250,9 @@ def main():
                 "k_gather": {"ms": P["ms_gather"], "launches": P["launches_gather"],
                              "alg": P["photon_queries"] * 48.0 + P["photons_visited"] * 24.0,
                              "l2": P["photon_queries"] * 48.0 + P["gather_leaf_reads"] * 32.0 * 32.0},      # 32-slot sub-leaf reads of 32-B slots
-                "k_primary+k_bounce": {"ms": P["ms_primary"] + P["ms_bounce"], "launches": P["launches_primary"] + P["launches_bounce"],
+                # the tracer: k_wavefront (whole ray tree, LDS ray stacks) + the k_bounce launches behind it (rays that did not
+                # fit the LDS stacks: normally none); with RT_TRACER=levels: k_primary + one k_bounce per level
+                "k_wavefront+k_bounce": {"ms": P["ms_primary"] + P["ms_bounce"], "launches": P["launches_primary"] + P["launches_bounce"],
                                        "alg": p_rays * 48.0 + P["instance_visits"] * 84.0 + P["bvh_nodes_visited"] * 28.0 + P["tris_tested"] * 48.0,
                                        "l2": (P["rays_reflect"] + P["rays_refract"]) * 128.0 + P["instance_visits"] * 96.0 +
                                              P["bvh_nodes_visited"] * 64.0 + P["tris_tested"] * 48.0 + P["photon_queries"] * 48.0 + P["samples"] * 17.0},
@@ -267,10 +269,12 @@ def main():
                        "l2_GBps": round(c["l2"] / sec / 1e9, 1) if sec > 0 else None,
                        "l2_frac": round(c["l2"] / sec / 1e9 / L2_PEAK_GBS, 4) if sec > 0 else None}
                 parts = name.split("+")
+                if "k_wavefront" in parts and "k_wavefront" not in figs["hbm"] and "k_primary" in figs["hbm"]:
+                    parts = ["k_primary" if q == "k_wavefront" else q for q in parts]
                 if all(q in figs["hbm"] for q in parts) and sec > 0:
                     # PMC bytes are per launch of each kernel; launches per frame of each kernel from the stats
-                    per = {"k_gather": P["launches_gather"], "k_primary": P["launches_primary"], "k_bounce": P["launches_bounce"],
-                           "k_resolve": P["launches_resolve"]}
+                    per = {"k_gather": P["launches_gather"], "k_primary": P["launches_primary"], "k_wavefront": P["launches_primary"],
+                           "k_bounce": P["launches_bounce"], "k_resolve": P["launches_resolve"]}
                     hb = sum(figs["hbm"][q] * per[q] for q in parts)
                     row["hbm_bytes_per_frame"] = int(hb)
                     row["hbm_frac"] = round(hb / sec / 1e9 / HBM_PEAK_GBS, 4)
