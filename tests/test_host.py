@@ -312,3 +312,15 @@ def test_image_reader_low_bit_depths_and_hostile_headers(tmp_path):
     with open(ppm, "wb") as f:
         f.write(b"P6\n2 2\n255\n" + bytes(range(12)))
     assert capi.image_read_rgb(ppm).ravel().tolist() == list(range(12))
+
+
+def test_reference_side_binding_compiles_against_the_reference_headers():
+    """raytracing_folder_amd/binding/rt_binding.cpp (BeginRender / StopRender / saveImage on
+    the C ABI, with real LowerMaterials / LowerLights / LowerTextures) is syntax-checked with g++ against the
+    reference's own headers of both snapshots.  Only where the reference tree exists (the build container)."""
+    import subprocess
+    if not os.path.isdir("/root/reference/RayTracingFinal/RayTracingFinal/include"):
+        pytest.skip("reference tree absent (GPU box)")
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "binding-check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "syntax OK" in r.stdout
