@@ -151,6 +151,11 @@ struct DeviceState {
     // stats: `last_done` is recorded at its join and every later call orders its own stream behind it
     hipEvent_t last_done = nullptr;
     bool last_pending = false;
+    // How full the ray / photon-query queues of the last renders got, per sample of a chunk (device-side peaks,
+    // rt_stats.peak_*): the next render of the same kind sizes its queues from that instead of the 2^bounce worst case.
+    struct QueueHistory { bool valid = false; int model = -1, bounce = -1, fan = -1; bool photons = false, caustic = false;
+                          double rays_per_sample = 0, queries_per_sample = 0; } qhist;
+    bool qhist_used = false;            // the render in flight (or last finished) was sized from qhist / the first-frame guess
     // scratch for the single-stage entry points
     DevBuf t_in, t_out[6];
     hipStream_t stream = nullptr;
@@ -952,7 +957,10 @@ static int render_streams()
     return v < 1 ? 1 : (v > RT_STREAMS ? RT_STREAMS : v);
 }
 
-static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int bounce, size_t list_pixels, int fan = 2, bool caustic = false)
+// ray_factor / query_factor: queue entries per sample to provide (<= 0: the worst case, every hit spawning `fan` rays level
+// after level); an overflow is detected on the device and reported, never silent
+static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int bounce, size_t list_pixels, int fan = 2, bool caustic = false,
+                                  double ray_factor = 0, double query_factor = 0)
 {
     rt_status st;
     Workspace &w = D->ws[slot];
@@ -963,6 +971,8 @@ static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int 
     for (int b = 0; b < bounce; b++) grow *= fan;
     unsigned long long rq_cap = (unsigned long long)std::min(4.0e9, (double)samples * grow);
     unsigned long long pq_cap = (unsigned long long)std::min(4.0e9, (double)samples * grow * 2.0);    // hits on levels 1..bounce
+    if (ray_factor > 0) rq_cap = std::min<unsigned long long>(rq_cap, (unsigned long long)((double)samples * ray_factor) + 65536ull);
+    if (query_factor > 0) pq_cap = std::min<unsigned long long>(pq_cap, (unsigned long long)((double)samples * query_factor) + 65536ull);
     const unsigned long long lim = 1ull << 28;
     if (rq_cap > lim) rq_cap = lim;
     if (pq_cap > lim) pq_cap = lim;
@@ -1104,9 +1114,30 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
     return RT_OK;
 }
 
+#define RT_ERR_OVERFLOW_RETRY (-1000)     /* internal: queues sized from history overflowed; render again with worst-case queues */
+static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles, int device,
+                                   hipStream_t user_stream, bool use_user_stream, uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
+                                   bool sync, rt_stats *stats_out, rt_job *job, void *packed_dev, bool worst_case);
+
+// Queue sizing policy: the first render of a kind (shading model, bounce limit, fan-out, maps in use) provides two queue
+// entries per sample, later ones twice what the fullest chunk so far needed; if that ever overflows, a synchronous render
+// is repeated once with the worst-case size (2^bounce per sample) -- an asynchronous one cannot be repeated by the
+// library: it starts from the worst case unless there is history, and an overflow is reported by rt_render_check.
 static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles, int device,
                               hipStream_t user_stream, bool use_user_stream, uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
                               bool sync, rt_stats *stats_out, rt_job *job, void *packed_dev = nullptr)
+{
+    rt_status st = render_tiles_once(s, cam, p, tiles, device, user_stream, use_user_stream, rgb8_dev, z_dev, count_dev, sync, stats_out, job,
+                                     packed_dev, false);
+    if (st == RT_ERR_OVERFLOW_RETRY)
+        st = render_tiles_once(s, cam, p, tiles, device, user_stream, use_user_stream, rgb8_dev, z_dev, count_dev, sync, stats_out, job,
+                               packed_dev, true);
+    return st;
+}
+
+static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles, int device,
+                                   hipStream_t user_stream, bool use_user_stream, uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
+                                   bool sync, rt_stats *stats_out, rt_job *job, void *packed_dev, bool worst_case)
 {
     rt_status st = validate_render(s, cam, p, tiles);
     if (st) return st;
@@ -1140,6 +1171,16 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
     // overflow is reported as an error rather than silently dropped
     const uint64_t n_chunks = total_px ? (total_px + ppc - 1) / ppc : 0;
     int n_slots = (int)std::min<uint64_t>(std::max<uint64_t>(n_chunks, 1), (uint64_t)render_streams());
+    const int fan = p->shade_model == RT_SHADE_P12 && p->hemisphere_sample > 1 ? 1 + p->hemisphere_sample : 2;
+    const bool use_photons = D->scene.pm.n_leaves != 0, use_caustic = p->caustic_k > 0 && D->scene.cm.n_leaves != 0;
+    const DeviceState::QueueHistory &H = D->qhist;
+    const bool hist_ok = H.valid && H.model == p->shade_model && H.bounce == p->bounce && H.fan == fan && H.photons == use_photons && H.caustic == use_caustic;
+    double ray_factor = 0, query_factor = 0;           // 0 = worst case
+    if (!worst_case && getenv("RT_QUEUE_WORST_CASE") == nullptr) {
+        if (hist_ok) { ray_factor = 2.0 * H.rays_per_sample; query_factor = 2.0 * H.queries_per_sample; }
+        else if (sync || job) { ray_factor = 2.0; query_factor = 2.0; }
+    }
+    D->qhist_used = ray_factor > 0 || query_factor > 0;
     DevWork Ws[RT_STREAMS];
     int n_ready = 0;
     for (int i = 0; i < n_slots; i++) {
@@ -1152,9 +1193,7 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
                                  3 * D->ws[0].pq[0].bytes;
             if (free_b < first + first / 4 + (total_b >> 3)) break;
         }
-        if ((st = ensure_workspace(D, i, (size_t)ppc * p->max_sample, p->bounce, (size_t)ppc,
-                                   p->shade_model == RT_SHADE_P12 && p->hemisphere_sample > 1 ? 1 + p->hemisphere_sample : 2,
-                                   p->caustic_k > 0 && D->scene.cm.n_leaves != 0))) return st;
+        if ((st = ensure_workspace(D, i, (size_t)ppc * p->max_sample, p->bounce, (size_t)ppc, fan, use_caustic, ray_factor, query_factor))) return st;
         Ws[i] = make_work(D, i);
         n_ready++;
     }
@@ -1170,6 +1209,7 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
         // the drop counter is read back after every synchronous render (below) and by rt_render_check after
         // asynchronous ones; consecutive asynchronous renders accumulate into it until it is checked
         HIP_TRY(hipMemsetAsync(Ws[0].stats + ST_QUEUE_OVERFLOW, 0, 8, stream));
+        HIP_TRY(hipMemsetAsync(Ws[0].stats + ST_PEAK_RAYS, 0, 16, stream));
     }
     // slot 0 runs on `stream` itself; the other slots' streams start after everything already queued on
     // `stream` (fork) and `stream` waits for them at the end (join), so the call keeps stream-order semantics
@@ -1187,6 +1227,7 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
     // chunks in flight (job mode): finished oldest-first for progress and the band copy
     struct InFlight { uint64_t q0; uint32_t npix; hipEvent_t done; };
     std::vector<InFlight> flight;
+    int attempt_progress = 0;
     auto finish_oldest = [&]() -> rt_status {
         const InFlight f = flight.front();
         flight.erase(flight.begin());
@@ -1213,7 +1254,10 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
                 HIP_TRY(hipMemcpy(job->host_count + o, count_dev + o, n, hipMemcpyDeviceToHost));
             }
         }
-        job->progress.fetch_add(done);
+        // monotone also when the frame is rendered a second time with larger queues (RT_ERR_OVERFLOW_RETRY)
+        attempt_progress += done;
+        int seen = job->progress.load();
+        while (attempt_progress > seen && !job->progress.compare_exchange_weak(seen, attempt_progress)) {}
         return RT_OK;
     };
     uint64_t chunk_index = 0;
@@ -1263,11 +1307,22 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
     if (sync || want_stats) {
         HIP_TRY(hipStreamSynchronize(stream));
         D->last_pending = false;
-        if (!want_stats) {
+        {
             // a dropped ray or photon query means a wrong image: never RT_OK, whether or not statistics were asked for
-            unsigned long long drops = 0;
-            if ((st = read_overflow(D, &drops))) return st;
-            if (drops) return fail(RT_ERR_LIMIT, "render: a ray/photon queue overflowed (%llu drops); lower RT_CHUNK_SAMPLES or the bounce limit", drops);
+            unsigned long long tail[ST_COUNT - ST_QUEUE_OVERFLOW];
+            HIP_TRY(hipMemcpy(tail, (unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, sizeof tail, hipMemcpyDeviceToHost));
+            const unsigned long long drops = tail[0], peak_r = tail[ST_PEAK_RAYS - ST_QUEUE_OVERFLOW], peak_q = tail[ST_PEAK_QUERIES - ST_QUEUE_OVERFLOW];
+            if (drops) {
+                D->qhist.valid = false;
+                if (D->qhist_used && !(job && job->stop.load())) return RT_ERR_OVERFLOW_RETRY;      // sized from history: once more, worst case
+                return fail(RT_ERR_LIMIT, "render: a ray/photon queue overflowed (%llu drops); lower RT_CHUNK_SAMPLES or the bounce limit", drops);
+            }
+            const double per = (double)std::max<uint64_t>(1, ppc * (uint64_t)p->max_sample);
+            DeviceState::QueueHistory &Hn = D->qhist;
+            const double r = (double)peak_r / per, q = (double)peak_q / per;
+            if (hist_ok) { Hn.rays_per_sample = std::max(Hn.rays_per_sample, r); Hn.queries_per_sample = std::max(Hn.queries_per_sample, q); }
+            else { Hn.valid = true; Hn.model = p->shade_model; Hn.bounce = p->bounce; Hn.fan = fan; Hn.photons = use_photons; Hn.caustic = use_caustic;
+                   Hn.rays_per_sample = r; Hn.queries_per_sample = q; }
         }
     } else {
         HIP_TRY(hipEventRecord(D->last_done, stream));
@@ -1316,7 +1371,6 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
             const int w = std::min(dt.tile_w, cam->width - tx * dt.tile_w), h = std::min(dt.tile_h, cam->height - ty * dt.tile_h);
             if (w > 0 && h > 0) R.pixels += (uint64_t)w * h;
         }
-        if (hs[ST_QUEUE_OVERFLOW]) return fail(RT_ERR_LIMIT, "render: a ray/photon queue overflowed (%llu drops); raise RT_CHUNK_SAMPLES granularity", hs[ST_QUEUE_OVERFLOW]);
         if (stats_out) *stats_out = R;
         if (job) job->stats = R;
     }
@@ -1394,6 +1448,7 @@ extern "C" rt_status rt_render_check(rt_scene *s, int device)
     rt_status st = read_overflow(D, &drops);
     if (st) return st;
     if (drops) {
+        D->qhist.valid = false;                             // the next render starts from the worst case again
         HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 0, 8));
         return fail(RT_ERR_LIMIT, "rt_render_check: a ray/photon queue overflowed (%llu drops) in an asynchronous render", drops);
     }

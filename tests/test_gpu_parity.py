@@ -663,6 +663,9 @@ def test_render_fixed_spp_with_photon_map_and_tile_sharding(cornell):
     orgb, oz, ocnt = orc.render(scenes.oracle_scene(e, bal), scenes.oracle_camera(cam), scenes.oracle_params(p))
     _frame_gate(rgb, orgb, z, oz, cnt, ocnt)
     assert st.photon_queries > 0 and st.photons_visited > 0
+    # the device reports how full its queues got (the host sizes the next render's queues from it): the whole
+    # frame is one chunk here, so the fullest photon queue holds every query of the frame
+    assert st.peak_queries == st.photon_queries and st.peak_rays <= st.rays_reflect + st.rays_refract
     assert (cnt == 0).all() and (ocnt == 0).all()         # colorlist.size() <= MIN_SAMPLE -> 0 (FIN/main.cpp:312)
     # two interleaved tile sets (rank t mod 2) reproduce the single-call frame
     parts = []
@@ -828,6 +831,28 @@ def test_packed_tile_render_and_hip_unpack_match_the_torch_reference():
         assert (np.abs(o_rgb.cpu().numpy().astype(int) - ref.astype(int)) <= 1).all()
     with pytest.raises(capi.RtError):                                                      # too few slots for the frame's tiles
         capi.tiles_unpack_device(0, None, gathered.data_ptr(), 8, 1, 100, 37, 32, 8, o_rgb.data_ptr(), o_z.data_ptr(), o_cnt.data_ptr())
+
+
+def test_queues_sized_from_history_are_retried_at_worst_case_when_a_heavier_view_overflows():
+    """Queue sizing: twice what the fullest chunk of the previous render of the same kind needed.  A first render looking at
+    a bare wall needs next to nothing; the same call on a view full of glass and mirror then overflows those queues -- and is
+    repeated by the library with worst-case queues, so the caller still gets the right frame (RT_TRACER=levels builds every
+    secondary ray through the global queues, the wavefront tracer only those that did not fit its LDS stacks)."""
+    import ctypes as C
+    s, cam = scenes.load_cornell(400, 300)
+    bal = photons.synth_cornell_photon_map(8000, seed=12)
+    s.set_photons(bal)
+    e = s.export()
+    p = capi.default_params(min_sample=8, max_sample=8, threshold=-1.0)
+    wall = capi.Camera()
+    C.memmove(C.byref(wall), C.byref(cam), C.sizeof(cam))
+    wall.pos[:] = [0.0, 10.0, 20.0]; wall.dir[:] = [0.0, 0.0, 1.0]; wall.up[:] = [0.0, 1.0, 0.0]      # straight up at the ceiling
+    _, _, _, st_wall, _ = s.render(wall, p)
+    assert st_wall.peak_queries == 0 and st_wall.rays_refract == 0
+    rgb, z, cnt, st, _ = s.render(cam, p)                          # sized for "nothing": overflows, retried, correct
+    orgb, oz, ocnt = orc.render(scenes.oracle_scene(e, bal), scenes.oracle_camera(cam), scenes.oracle_params(p))
+    assert st.peak_queries > 65536 + 8                             # more than the history-based size (2 x 0 + 64 Ki) could hold
+    _frame_gate(rgb, orgb, z, oz, cnt, ocnt)
 
 
 def test_queue_overflow_is_an_error_with_or_without_stats(monkeypatch):
