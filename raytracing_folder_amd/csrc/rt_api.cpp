@@ -1120,7 +1120,8 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
                                    bool sync, rt_stats *stats_out, rt_job *job, void *packed_dev, bool worst_case);
 
 // Queue sizing policy: the first render of a kind (shading model, bounce limit, fan-out, maps in use) provides two queue
-// entries per sample, later ones twice what the fullest chunk so far needed; if that ever overflows, a synchronous render
+// entries per sample, later ones twice what the fullest chunk so far needed (at least 1 ray and 0.25 queries per sample);
+// if that ever overflows, a synchronous render
 // is repeated once with the worst-case size (2^bounce per sample) -- an asynchronous one cannot be repeated by the
 // library: it starts from the worst case unless there is history, and an overflow is reported by rt_render_check.
 static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles, int device,
@@ -1177,7 +1178,9 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     const bool hist_ok = H.valid && H.model == p->shade_model && H.bounce == p->bounce && H.fan == fan && H.photons == use_photons && H.caustic == use_caustic;
     double ray_factor = 0, query_factor = 0;           // 0 = worst case
     if (!worst_case && getenv("RT_QUEUE_WORST_CASE") == nullptr) {
-        if (hist_ok) { ray_factor = 2.0 * H.rays_per_sample; query_factor = 2.0 * H.queries_per_sample; }
+        // floors: how many rays k_wavefront cannot keep in LDS depends on timing, and a view change can bring glass into a
+        // frame that had none -- one ray and a quarter of a query per sample cost 1.4 GB per working set and cover both
+        if (hist_ok) { ray_factor = std::max(2.0 * H.rays_per_sample, 1.0); query_factor = std::max(2.0 * H.queries_per_sample, 0.25); }
         else if (sync || job) { ray_factor = 2.0; query_factor = 2.0; }
     }
     D->qhist_used = ray_factor > 0 || query_factor > 0;

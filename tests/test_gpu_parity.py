@@ -833,11 +833,11 @@ def test_packed_tile_render_and_hip_unpack_match_the_torch_reference():
         capi.tiles_unpack_device(0, None, gathered.data_ptr(), 8, 1, 100, 37, 32, 8, o_rgb.data_ptr(), o_z.data_ptr(), o_cnt.data_ptr())
 
 
-def test_queues_sized_from_history_are_retried_at_worst_case_when_a_heavier_view_overflows():
-    """Queue sizing: twice what the fullest chunk of the previous render of the same kind needed.  A first render looking at
-    a bare wall needs next to nothing; the same call on a view full of glass and mirror then overflows those queues -- and is
-    repeated by the library with worst-case queues, so the caller still gets the right frame (RT_TRACER=levels builds every
-    secondary ray through the global queues, the wavefront tracer only those that did not fit its LDS stacks)."""
+def test_queues_sized_from_history_survive_a_heavier_view():
+    """Queue sizing: twice what the fullest chunk of the previous render of the same kind needed, with floors.  A first
+    render looking at a bare wall needs nothing; the same call on a view full of glass and mirror must still come out right
+    (inside the floors, or by the library repeating the frame with worst-case queues -- the P12 test, whose 31 rays per hit
+    overflow the first-frame guess, takes that path every time)."""
     import ctypes as C
     s, cam = scenes.load_cornell(400, 300)
     bal = photons.synth_cornell_photon_map(8000, seed=12)
@@ -851,7 +851,7 @@ def test_queues_sized_from_history_are_retried_at_worst_case_when_a_heavier_view
     assert st_wall.peak_queries == 0 and st_wall.rays_refract == 0
     rgb, z, cnt, st, _ = s.render(cam, p)                          # sized for "nothing": overflows, retried, correct
     orgb, oz, ocnt = orc.render(scenes.oracle_scene(e, bal), scenes.oracle_camera(cam), scenes.oracle_params(p))
-    assert st.peak_queries > 65536 + 8                             # more than the history-based size (2 x 0 + 64 Ki) could hold
+    assert st.peak_queries > 65536 + 8                             # more than twice the history (0) + the 64 Ki margin alone could hold
     _frame_gate(rgb, orgb, z, oz, cnt, ocnt)
 
 
