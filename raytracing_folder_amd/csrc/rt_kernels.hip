@@ -1248,7 +1248,10 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
 // (normally empty).  FIN and P13 models (at most two children per hit); the others keep the per-level kernels.
 // ------------------------------------------------------------------------------------------------
 #ifndef RT_WF_STACK
-#define RT_WF_STACK 640        // rays per workgroup stack: 4 x 16 B x 640 = 40 KB next to the 32 KB of BVH stacks -> 2 workgroups per CU
+#define RT_WF_STACK 704        // rays per workgroup stack: 4 x 16 B x 704 = 44 KB next to the 32 KB of BVH stacks -> 2 workgroups per CU (79.9 KB each)
+#endif
+#ifndef RT_WF_POP
+#define RT_WF_POP (RT_WF_STACK - 2 * RT_BLOCK + 1 < RT_BLOCK ? RT_WF_STACK - 2 * RT_BLOCK + 1 : RT_BLOCK)    // 193 for a 704-ray stack
 #endif
 #ifndef RT_WF_WAVES
 #define RT_WF_WAVES 2          // waves per SIMD = workgroups per CU the kernel is built for
@@ -1276,7 +1279,10 @@ __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES, RT_WF_WAVES))) __global__ __laun
         __syncthreads();                                  // last round's pushes are complete
         uint32_t waiting = s_count;
         if (waiting > RT_WF_STACK) waiting = RT_WF_STACK; // the excess went to the global queue
-        const bool pop = waiting >= RT_BLOCK || (!more_primaries && waiting > 0);
+        // pop a full workgroup's worth when there is one -- and already earlier when a round of primary rays (up to two
+        // children each) could no longer be sure to fit: rays that do not fit go through the global queue and the
+        // per-level launches, the slow path (measured: 5 ms per Cornell frame before this rule)
+        const bool pop = waiting >= RT_WF_POP || (!more_primaries && waiting > 0);
         if (!pop && !more_primaries) break;
         __syncthreads();                                  // everyone has read s_count
         PathIn in;
