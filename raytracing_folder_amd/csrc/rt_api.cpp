@@ -888,12 +888,19 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D, bool caustic)
     // heap node ids of a complete binary tree do not depend on its depth: the first 2*n_leaves boxes ARE the tree
     // over the leaves, the last n_sub ones the sub-leaf boxes
     const std::vector<float> tbox(hbox.begin(), hbox.begin() + 6 * 2 * (size_t)n_leaves);
+    // device form of a box: two aligned 16-byte words (lo.xyz, 0), (hi.xyz, 0)
+    auto pad_boxes = [](const float *b6, size_t n) {
+        std::vector<float4> out(2 * n);
+        for (size_t i = 0; i < n; i++) { out[2 * i] = make_float4(b6[6 * i], b6[6 * i + 1], b6[6 * i + 2], 0.f); out[2 * i + 1] = make_float4(b6[6 * i + 3], b6[6 * i + 4], b6[6 * i + 5], 0.f); }
+        return out;
+    };
+    const std::vector<float4> tbox4 = pad_boxes(tbox.data(), 2 * (size_t)n_leaves), sbox4 = pad_boxes(&hbox[6 * (size_t)n_sub], n_sub);
     rt_status st;
     if ((st = b_pa.upload(pa.data(), pa.size() * sizeof(float4)))) return st;
     if ((st = b_pb.upload(pb.data(), pb.size() * sizeof(float4)))) return st;
-    if ((st = b_tbox.upload(tbox.data(), tbox.size() * 4))) return st;
-    if ((st = b_sbox.upload(&hbox[6 * (size_t)n_sub], 6 * (size_t)n_sub * 4))) return st;
-    pm.pa = (const float4 *)b_pa.p; pm.pb = (const float4 *)b_pb.p; pm.tbox = (const float *)b_tbox.p; pm.sbox = (const float *)b_sbox.p;
+    if ((st = b_tbox.upload(tbox4.data(), tbox4.size() * sizeof(float4)))) return st;
+    if ((st = b_sbox.upload(sbox4.data(), sbox4.size() * sizeof(float4)))) return st;
+    pm.pa = (const float4 *)b_pa.p; pm.pb = (const float4 *)b_pb.p; pm.tbox = (const float4 *)b_tbox.p; pm.sbox = (const float4 *)b_sbox.p;
     pm.n_leaves = n_leaves; pm.n_photons = (uint32_t)recs.size();
     {   // density grid over the photons' bounding box, at most 64 cells along the longest axis
         const float *rb = &tbox[6];
@@ -935,16 +942,17 @@ static rt_status prepare_device(rt_scene *s, int device, DeviceState **out)
 }
 
 // ---- render orchestration ---------------------------------------------------------------------------------
-// Samples per pipeline pass.  8 Mi is the largest chunk whose worst case (every hit spawning two rays
-// for 4 bounces: 16 rays and 32 photon queries per sample) still fits the queue caps of
-// ensure_workspace, so nothing can overflow; it needs about 35 GB of the 288 GB.  Smaller chunks leave
-// the deeper bounce levels with too few rays to fill 256 CUs (measured: 4 Mi -> 96 ms, 8 Mi -> 89 ms
-// per 1080p x 64 spp frame; 16-32 Mi no better).
-static size_t chunk_samples_limit()
+// Samples per pipeline pass.  The kernels are persistent grids that take their work from device-side counters, so a
+// bigger chunk means fewer launches, fewer drain phases and longer-lived LDS ray stacks: measured on MI355X (Cornell
+// 1080p x 64 spp, two chunks in flight) 4 Mi: 77.4 ms, 8 Mi: 72.3, 32 Mi: 68.9, 64 Mi: 67.7 per frame.  A device-side
+// render (rt_render_tiles_device: bench, multi-GPU) therefore takes 64 Mi samples at a time -- 1.1 GB of per-sample
+// buffers; the queues are sized from measurement, not from 2^bounce -- while a job (rt_render_begin) keeps 8 Mi chunks:
+// its caller watches the image fill band by band, and a band is a chunk.
+static size_t chunk_samples_limit(bool job)
 {
     const char *e = getenv("RT_CHUNK_SAMPLES");
     long long v = e ? atoll(e) : 0;
-    if (v < 4096) v = 8LL << 20;
+    if (v < 4096) v = job ? (8LL << 20) : (64LL << 20);
     return (size_t)v;
 }
 
@@ -953,7 +961,9 @@ static size_t chunk_samples_limit()
 static int render_streams()
 {
     const char *e = getenv("RT_STREAMS");
-    const int v = e ? atoi(e) : 3;         // measured on MI355X (Cornell / 100 k-triangle frame): 1: 89 / 60 ms, 2: 79 / 43, 3: 78 / 39, 4: 80 / 43
+    // measured on MI355X, round 2 (Cornell frame, 16 chunks): 1: 74.9 ms, 2: 71.8, 3: 73.5, 4: 71.7 -- three slots leave the
+    // sixteenth chunk alone at the end; two need the least memory
+    const int v = e ? atoi(e) : 2;
     return v < 1 ? 1 : (v > RT_STREAMS ? RT_STREAMS : v);
 }
 
@@ -1119,8 +1129,8 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
                                    hipStream_t user_stream, bool use_user_stream, uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev,
                                    bool sync, rt_stats *stats_out, rt_job *job, void *packed_dev, bool worst_case);
 
-// Queue sizing policy: the first render of a kind (shading model, bounce limit, fan-out, maps in use) provides two queue
-// entries per sample, later ones twice what the fullest chunk so far needed (at least 1 ray and 0.25 queries per sample);
+// Queue sizing policy: the first render of a kind (shading model, bounce limit, fan-out, maps in use) provides one ray and
+// half a photon query per sample, later ones twice what the fullest chunk so far needed (at least 1 ray and 0.25 queries per sample);
 // if that ever overflows, a synchronous render
 // is repeated once with the worst-case size (2^bounce per sample) -- an asynchronous one cannot be repeated by the
 // library: it starts from the worst case unless there is history, and an overflow is reported by rt_render_check.
@@ -1163,7 +1173,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     const uint64_t tile_px = (uint64_t)dt.tile_w * dt.tile_h;
     const uint64_t total_px = tile_px * (uint64_t)dt.n_tiles;
 
-    const size_t limit = chunk_samples_limit();
+    const size_t limit = chunk_samples_limit(job != nullptr);
     uint64_t ppc = std::max<uint64_t>(1, limit / (uint64_t)p->max_sample);
     ppc = std::max<uint64_t>(tile_px, ppc / tile_px * tile_px);
     ppc = std::min<uint64_t>(ppc, std::max<uint64_t>(total_px, 1));
@@ -1181,7 +1191,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         // floors: how many rays k_wavefront cannot keep in LDS depends on timing, and a view change can bring glass into a
         // frame that had none -- one ray and a quarter of a query per sample cost 1.4 GB per working set and cover both
         if (hist_ok) { ray_factor = std::max(2.0 * H.rays_per_sample, 1.0); query_factor = std::max(2.0 * H.queries_per_sample, 0.25); }
-        else if (sync || job) { ray_factor = 2.0; query_factor = 2.0; }
+        else if (sync || job) { ray_factor = 1.0; query_factor = 0.5; }
     }
     D->qhist_used = ray_factor > 0 || query_factor > 0;
     DevWork Ws[RT_STREAMS];
@@ -1604,7 +1614,7 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
     DeviceClaim claim(D);
     if (!claim.ok) return fail(RT_ERR_STATE, "rt_shade_rays: another call on this scene is using device %d", device);
     if ((st = order_after_pending(D, D->stream))) return st;
-    const size_t limit = chunk_samples_limit();
+    const size_t limit = chunk_samples_limit(true);
     const size_t chunk = (size_t)std::min<int64_t>(n, (int64_t)limit);
     if ((st = ensure_workspace(D, 0, chunk, pv.bounce, 1, 2, pv.caustic_k > 0 && D->scene.cm.n_leaves != 0))) return st;
     const DevWork W = make_work(D, 0);

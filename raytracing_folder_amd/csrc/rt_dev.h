@@ -70,8 +70,8 @@ struct DevMesh {
 struct DevPhotonMap {
     const float4 *pa;            // [n_sub*32]  position.xyz, direction.x
     const float4 *pb;            //             direction.yz, GetMaxPower(), colour bytes r|g<<8|b<<16 (as uint bits)
-    const float  *tbox;          // [2*n_leaves][6]
-    const float  *sbox;          // [n_sub][6], n_sub = 4 * n_leaves: sub-leaf j of leaf l is 4*l + j
+    const float4 *tbox;          // [2*n_leaves][2]: (lo.xyz, -), (hi.xyz, -)
+    const float4 *sbox;          // [n_sub][2], n_sub = 4 * n_leaves: sub-leaf j of leaf l is 4*l + j
     uint32_t n_leaves;           // power of two, 0 = no photon map
     uint32_t n_photons;          // photons stored in the leaves
     // coarse density grid (photon count per cubic cell of side `cell`) used only to pick the first

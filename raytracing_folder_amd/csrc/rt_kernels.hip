@@ -1605,11 +1605,13 @@ __device__ __forceinline__ float wave_max0(float x) { return __int_as_float(__bu
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ uint32_t lane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
-__device__ __forceinline__ float box_dist2(const float *b, float px, float py, float pz)
+// boxes are two aligned 16-byte words (lo.xyz, -), (hi.xyz, -): one visit = two dwordx4 loads
+__device__ __forceinline__ float box_dist2(const float4 *b, float px, float py, float pz)
 {
-    const float dx = fmaxf(fmaxf(b[0] - px, px - b[3]), 0.0f);
-    const float dy = fmaxf(fmaxf(b[1] - py, py - b[4]), 0.0f);
-    const float dz = fmaxf(fmaxf(b[2] - pz, pz - b[5]), 0.0f);
+    const float4 lo = b[0], hi = b[1];
+    const float dx = fmaxf(fmaxf(lo.x - px, px - hi.x), 0.0f);
+    const float dy = fmaxf(fmaxf(lo.y - py, py - hi.y), 0.0f);
+    const float dz = fmaxf(fmaxf(lo.z - pz, pz - hi.z), 0.0f);
     return dx * dx + dy * dy + dz * dz;
 }
 
@@ -1795,7 +1797,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 uint32_t node = 1;
                 while (node) {
                     bool descend = false;
-                    if (box_dist2(G.pm.tbox + 6 * (size_t)node, a.x, a.y, a.z) < r2cur) {
+                    if (box_dist2(G.pm.tbox + 2 * (size_t)node, a.x, a.y, a.z) < r2cur) {
                         if (node >= n_leaves) {
                             if (nl < RT_LEAFLIST_CAP) L.leaves[lane][nl] = (uint16_t)(node - n_leaves);
                             nl++;
@@ -1835,7 +1837,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         const uint32_t e = base + (uint32_t)lane;
                         const bool have_e = (e >> 2) < qnl;
                         const uint32_t sub = have_e ? (uint32_t)L.leaves[q][e >> 2] * RT_LEAF_SUBS + (e & 3u) : 0u;
-                        const bool in = have_e && box_dist2(G.pm.sbox + 6 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
+                        const bool in = have_e && box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
                         const unsigned long long m = __ballot(in);
                         if (in) L.subs[n_sub + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)sub;
                         n_sub += (uint32_t)__popcll(m);
@@ -1849,7 +1851,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     // list too long for LDS: every pass walks ALL sub-leaf boxes instead (64 per step) -- no list is kept
                     for (uint32_t base = 0; base < n_sub_total; base += 64u) {
                         const uint32_t sub = base + (uint32_t)lane;
-                        const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 6 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
+                        const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
                         n_sub += (uint32_t)__popcll(__ballot(in));
                     }
                 }
@@ -1857,16 +1859,22 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 // run one pass over the query's sub-leaves
                 auto for_each = [&](auto &&f) {
                     if (!slow) {
-                        scan_subleaves(G.pm, [&](uint32_t e) {
-                            return e < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)my_sub0, (int)e)
-                                 : e < 128u ? (uint32_t)__builtin_amdgcn_readlane((int)my_sub1, (int)(e - 64u))
-                                            : (uint32_t)__builtin_amdgcn_readlane((int)my_sub2, (int)(e - 128u));
-                        }, n_sub, lane, Q, f);
+                        // one loop per list register (26 entries on average: the second and third loops are rare): inside
+                        // a loop the entry comes from ONE register by v_readlane, no selection between registers -- that
+                        // selection cost more scalar instructions per step than the photon arithmetic cost vector ones
+                        scan_subleaves(G.pm, [&](uint32_t e) { return (uint32_t)__builtin_amdgcn_readlane((int)my_sub0, (int)e); },
+                                       min(n_sub, 64u), lane, Q, f);
+                        if (n_sub > 64u)
+                            scan_subleaves(G.pm, [&](uint32_t e) { return (uint32_t)__builtin_amdgcn_readlane((int)my_sub1, (int)e); },
+                                           min(n_sub - 64u, 64u), lane, Q, f);
+                        if (n_sub > 128u)
+                            scan_subleaves(G.pm, [&](uint32_t e) { return (uint32_t)__builtin_amdgcn_readlane((int)my_sub2, (int)e); },
+                                           n_sub - 128u, lane, Q, f);
                         return;
                     }
                     for (uint32_t base = 0; base < n_sub_total; base += 64u) {
                         const uint32_t sub = base + (uint32_t)lane;
-                        const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 6 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
+                        const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
                         unsigned long long m = __ballot(in);
                         while (m) {
                             const uint32_t s0 = base + (uint32_t)(__ffsll((long long)m) - 1);
