@@ -37,10 +37,17 @@
 #define RT_GATHER_LUT 0        // 1: byte / 255.0f from a 256-entry LDS table instead of the two-fma form
 #endif
 #ifndef RT_GATHER_GUESS
-#define RT_GATHER_GUESS 1.3f   // photons expected inside the first trial radius, in units of k (1.2-1.6 measured flat)
+#define RT_GATHER_GUESS 1.2f   // photons expected inside the first trial radius, in units of k (round 2, sub-leaves: 1.1: 42.0 ms, 1.15: 40.8, 1.2: 40.7, 1.3: 41.7, 1.45: 43.3)
 #endif
 #ifndef RT_GATHER_RING
 #define RT_GATHER_RING 144     // LDS entries for the photons around the predicted k-th distance (0: always re-read in pass 2)
+#endif
+#ifndef RT_GATHER_BAND_LO
+#define RT_GATHER_BAND_LO 0.92f   // the ring keeps the photons between BAND_LO and BAND_HI times the predicted k-th squared distance
+                                  // (0.85-1.18: 40.7 ms, 0.88-1.15: 39.7, 0.92-1.10: 39.4, 0.94-1.08: 39.3)
+#endif
+#ifndef RT_GATHER_BAND_HI
+#define RT_GATHER_BAND_HI 1.10f
 #endif
 #ifndef RT_GATHER_BATCH
 #define RT_GATHER_BATCH 32     // queries a wave lists per phase A (40 leaf ids each: lists + ring keep 5 waves/SIMD)
@@ -1793,19 +1800,40 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
         while (__ballot(pending)) {
             // ---------------- phase A: pending lanes list the leaves inside their trial radius ----
             uint32_t nl = 0;
+            auto list_leaf = [&](uint32_t leaf) {
+                if (nl < RT_LEAFLIST_CAP) L.leaves[lane][nl] = (uint16_t)leaf;
+                nl++;
+            };
             if (pending && n_leaves) {
-                uint32_t node = 1;
-                while (node) {
-                    bool descend = false;
-                    if (box_dist2(G.pm.tbox + 2 * (size_t)node, a.x, a.y, a.z) < r2cur) {
-                        if (node >= n_leaves) {
-                            if (nl < RT_LEAFLIST_CAP) L.leaves[lane][nl] = (uint16_t)(node - n_leaves);
-                            nl++;
-                        } else { node = 2 * node; descend = true; }
-                    }
-                    if (!descend) {
-                        while (node & 1u) node >>= 1;      // climb while we are a right child
-                        if (node) node += 1;               // then step to the right sibling
+                // Depth-first, left to right (ascending leaf ids), one visit per INTERNAL node whose box the ball cuts: a
+                // visit reads the boxes of both children (heap order: they are adjacent, one aligned 64-byte line) and
+                // remembers a right child that passed in a bit per depth, so no box is fetched twice and the chain of
+                // dependent loads -- what phase A waits for -- is about half as long as one load per tested node.
+                if (box_dist2(G.pm.tbox + 2, a.x, a.y, a.z) < r2cur) {
+                    if (n_leaves == 1) list_leaf(0u);
+                    else {
+                        uint32_t node = 1, depth = 0, right_pending = 0;
+                        for (;;) {
+                            const float4 *cb = G.pm.tbox + 4 * (size_t)node;          // boxes of 2*node and 2*node + 1
+                            const bool pl = box_dist2(cb, a.x, a.y, a.z) < r2cur, pr = box_dist2(cb + 2, a.x, a.y, a.z) < r2cur;
+                            const uint32_t l = 2u * node;
+                            if (l >= n_leaves) {
+                                if (pl) list_leaf(l - n_leaves);
+                                if (pr) list_leaf(l + 1u - n_leaves);
+                            } else if (pl) {
+                                if (pr) right_pending |= 1u << depth;
+                                node = l; depth++;
+                                continue;
+                            } else if (pr) {
+                                node = l + 1u; depth++;
+                                continue;
+                            }
+                            if (!right_pending) break;
+                            const uint32_t d = 31u - (uint32_t)__clz((int)right_pending);   // deepest level with a right child to do
+                            right_pending &= ~(1u << d);
+                            node = ((node >> (depth - d)) << 1) | 1u;                       // that ancestor's right child
+                            depth = d + 1u;
+                        }
                     }
                 }
             }
@@ -1916,8 +1944,8 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 // the k-th distance is expected in, are parked in the LDS ring with all their data.
 #if RT_GATHER_RING
                 const float pk = (pred_rk2 > 0.0f && pred_rk2 < rq2) ? pred_rk2 : rq2 * (1.0f / RT_GATHER_GUESS);
-                const float t_lo = 0.85f * pk;
-                const float t_hi = final_round ? rq2 : fminf(1.18f * pk, rq2);
+                const float t_lo = RT_GATHER_BAND_LO * pk;
+                const float t_hi = final_round ? rq2 : fminf(RT_GATHER_BAND_HI * pk, rq2);
                 uint32_t n_ring = 0;                       // wave-uniform (ballot popcounts)
                 for_each([&](const Cand &cd, size_t) {
                     const bool lo = cd.ok && cd.d2 < t_lo;
