@@ -460,7 +460,7 @@ def gen_illum():
 PB_IN = np.dtype([("diffuse", "<f4", 3), ("specular", "<f4", 3), ("reflection", "<f4", 3), ("refraction", "<f4", 3),
                   ("absorption", "<f4", 3), ("glossiness", "<f4"), ("ior", "<f4"), ("ray", "<f4", 6),
                   ("hit_p", "<f4", 3), ("hit_N", "<f4", 3), ("hit_z", "<f4"), ("front", "<i4"), ("c", "<f4", 3),
-                  ("seed", "<u4")])
+                  ("seed", "<u4"), ("reflection_glossiness", "<f4"), ("refraction_glossiness", "<f4")])
 PB_OUT = np.dtype([("ret", "<i4"), ("ray", "<f4", 6), ("c", "<f4", 3), ("rand", "<i4", 8)])
 
 
@@ -480,6 +480,10 @@ def gen_pbounce():
     a["absorption"][tinted] = rng.uniform(0.0, 0.3, (tinted.sum(), 3))
     a["reflection"][tinted] = rng.uniform(0, 0.3, (tinted.sum(), 3))
     a["diffuse"][black] = 0; a["absorption"][black] = 0.2                     # nothing but absorption
+    # glossy branches (materials.h:183-213): a third of the mirror / glass / tinted cases sample a hemisphere instead
+    glossy = (mirror | glass | tinted) & (rng.random(n) < 0.35)
+    a["reflection_glossiness"][glossy] = rng.choice([0.5, 5.0, 40.0], glossy.sum())
+    a["refraction_glossiness"][glossy & (rng.random(n) < 0.6)] = rng.choice([0.5, 5.0, 40.0], 1)
     N = rng.normal(size=(n, 3)); N /= np.linalg.norm(N, axis=1, keepdims=True)
     d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
     a["front"] = (rng.random(n) < 0.7).astype(np.int32)
@@ -498,6 +502,30 @@ def gen_pbounce():
     cs = np.frombuffer(out, "<f4", 6 * n, off).reshape(n, 6)
     np.savez_compressed(os.path.join(GOLD, "pbounce.npz"), cases=a, out=recs, attenuation=att, coord=cs)
     print(f"pbounce: {int(recs['ret'].sum())}/{n} bounced")
+
+
+LIGHTS_IN = np.dtype([("type", "<i4"), ("intensity", "<f4", 3), ("vec", "<f4", 3), ("p", "<f4", 3), ("shadow", "<f4")])
+LIGHTS_OUT = np.dtype([("illum", "<f4", 3), ("dir", "<f4", 3), ("ncalls", "<i4"), ("log", "<f4", 7)])
+
+
+def gen_lights():
+    """AmbientLight / DirectLight::Illuminate and Light::Direction of all three lights (lights.h:28-57, 159)."""
+    rng = np.random.default_rng(404)
+    n = 192
+    a = np.zeros(n, LIGHTS_IN)
+    a["type"] = rng.integers(0, 3, n)
+    a["intensity"] = rng.uniform(0.05, 3.0, (n, 3))
+    a["vec"] = rng.normal(size=(n, 3)) * rng.choice([0.3, 1.0, 20.0], (n, 1))       # SetDirection normalises; positions as they are
+    a["p"] = rng.uniform(-15, 15, (n, 3))
+    a["shadow"] = rng.choice([0.0, 1.0], n)
+    res = {"cases": a}
+    for model in ("fin", "p13"):
+        out = np.frombuffer(run(model, "lights", struct.pack("<i", n) + a.tobytes()), LIGHTS_OUT)
+        assert len(out) == n
+        res[f"out_{model}"] = out
+    assert res["out_fin"].tobytes() == res["out_p13"].tobytes()
+    np.savez_compressed(os.path.join(GOLD, "lights.npz"), cases=a, out=res["out_fin"])
+    print("lights:", n, "cases")
 
 
 def gen_refimages():
@@ -533,6 +561,7 @@ def main():
     gen_zimage()
     gen_illum()
     gen_pbounce()
+    gen_lights()
     gen_refimages()
     print("fixtures written to", GOLD)
 

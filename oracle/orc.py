@@ -460,3 +460,19 @@ def caustic_pass(scene, max_diffuse_hits, max_bounce=5, seed=20171203):
     n = lib().orc_caustic_pass(C.byref(scene.c), C.c_uint32(int(seed)), C.c_uint32(int(max_diffuse_hits)), int(max_bounce),
                                _p(out), C.byref(att))
     return out[: n + 1].copy(), att.value
+
+
+def light_illuminate_scripted(light, p, shadow_value, model=0):
+    """AmbientLight / DirectLight / PointLight: (Illuminate result, Direction(p), shadow-call log) with Shadow scripted"""
+    light = _c(light, LIGHT).reshape(1)
+    scene = Scene(np.zeros(0, NODE), lights=light)
+    params = default_params(shade_model=int(model))
+    sc = np.array([shadow_value], np.float32)
+    log = np.zeros((8, 7), np.float32)
+    out, d = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    pp, nn = _c(p, np.float32), np.array([0, 0, 1], np.float32)
+    lib().orc_script_begin(None, 0, _p(sc), 1, _p(log), len(log))
+    lib().orc_illuminate(C.byref(scene.c), C.byref(params), _p(scene.lights), _p(pp), _p(nn), _p(out))
+    n = lib().orc_script_end(None)
+    lib().orc_light_direction(_p(scene.lights), _p(pp), _p(d))
+    return out, d, log[:n]

@@ -487,10 +487,38 @@ static int cmd_illum(const char *in, const char *out)
     return 0;
 }
 
+// lights <in.bin> <out.bin>: AmbientLight / DirectLight::Illuminate and every Light::Direction (lights.h:28-57, :159)
+// in: int32 n; n x {int32 type (0 ambient, 1 direct, 2 point); float intensity[3], vec[3] (direction or position), p[3], shadow}
+// out: n x {float illum[3] (point lights: zeros, see `illum`), dir[3]; int32 ncalls; float log[7]}
+static int cmd_lights(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    const char *c = b.data();
+    int32_t n = *(int32_t *)c; c += 4;
+    Out o(out);
+    for (int i = 0; i < n; i++) {
+        int32_t type = *(int32_t *)c; c += 4;
+        const float *f = (const float *)c; c += 40;
+        g_shadow_log.clear(); g_shadow_calls = 0;
+        g_shadow_script.assign(1, f[9]);
+        Color r(0, 0, 0); Point3 d(0, 0, 0);
+        const Point3 p(f[6], f[7], f[8]), N(0, 0, 1);
+        if (type == 0) { AmbientLight l; l.SetIntensity(Color(f[0], f[1], f[2])); r = l.AmbientLight::Illuminate(p, N); d = l.AmbientLight::Direction(p); }
+        else if (type == 1) { DirectLight l; l.SetIntensity(Color(f[0], f[1], f[2])); l.SetDirection(Point3(f[3], f[4], f[5])); r = l.DirectLight::Illuminate(p, N); d = l.DirectLight::Direction(p); }
+        else { PointLight l; l.SetPosition(Point3(f[3], f[4], f[5])); d = l.PointLight::Direction(p); }
+        o.put(r.r); o.put(r.g); o.put(r.b); o.put(d.x); o.put(d.y); o.put(d.z);
+        int32_t nc = (int32_t)g_shadow_calls; o.put(nc);
+        g_shadow_log.resize(7, 0.0f);
+        o.bytes(g_shadow_log.data(), 28);
+    }
+    return 0;
+}
+
 #ifdef REF_FIN
 // pbounce <in.bin> <out.bin>   (RayTracingFinal only: P13's materials.h has no body for it)
 // in: int32 n; n x {float diffuse[3], specular[3], reflection[3], refraction[3], absorption[3], glossiness, ior;
-//                   float ray_p[3], ray_dir[3]; float hit_p[3], hit_N[3], hit_z; int32 front; float c[3]; uint32 seed}
+//                   float ray_p[3], ray_dir[3]; float hit_p[3], hit_N[3], hit_z; int32 front; float c[3]; uint32 seed;
+//                   float reflectionGlossiness, refractionGlossiness}
 // out: n x {int32 ret; float ray_p[3], ray_dir[3], c[3]; int32 rand[8]}; then n x float atten[3] =
 //      Attenuation(absorption, hit_z); then n x float Nt[3], Nb[3] = createCoordinateSystem(hit_N)
 static int cmd_pbounce(const char *in, const char *out)
@@ -498,7 +526,7 @@ static int cmd_pbounce(const char *in, const char *out)
     std::vector<char> b = slurp(in);
     const char *c0 = b.data();
     int32_t n = *(int32_t *)c0;
-    const size_t rec = 17 * 4 + 6 * 4 + 7 * 4 + 4 + 3 * 4 + 4;
+    const size_t rec = 17 * 4 + 6 * 4 + 7 * 4 + 4 + 3 * 4 + 4 + 8;
     Out o(out);
     std::vector<float> att, cs;
     for (int i = 0; i < n; i++) {
@@ -508,8 +536,10 @@ static int cmd_pbounce(const char *in, const char *out)
         const float *ht = (const float *)c; c += 28;
         int32_t front = *(int32_t *)c; c += 4;
         const float *col = (const float *)c; c += 12;
-        uint32_t seed = *(uint32_t *)c;
+        uint32_t seed = *(uint32_t *)c; c += 4;
+        const float *gl = (const float *)c;
         MtlBlinn mtl;
+        mtl.SetReflectionGlossiness(gl[0]); mtl.SetRefractionGlossiness(gl[1]);
         mtl.SetDiffuse(Color(m[0], m[1], m[2])); mtl.SetSpecular(Color(m[3], m[4], m[5]));
         mtl.SetReflection(Color(m[6], m[7], m[8])); mtl.SetRefraction(Color(m[9], m[10], m[11]));
         mtl.SetAbsorption(Color(m[12], m[13], m[14])); mtl.SetGlossiness(m[15]); mtl.SetRefractionIndex(m[16]);
@@ -560,6 +590,7 @@ int main(int argc, char **argv)
     if (cmd == "tex") { if (argc < 5) return 1; return cmd_tex(argv[2], argv[3], argv[4]); }
     if (cmd == "zimg") return cmd_zimg(argv[2], argv[3]);
     if (cmd == "illum") return cmd_illum(argv[2], argv[3]);
+    if (cmd == "lights") return cmd_lights(argv[2], argv[3]);
 #ifdef REF_FIN
     if (cmd == "pbounce") return cmd_pbounce(argv[2], argv[3]);
 #endif

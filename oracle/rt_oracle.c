@@ -513,6 +513,8 @@ static v3 light_direction(const rt_light *l, v3 p)
     return V3(0, 0, 0);
 }
 
+void orc_light_direction(const rt_light *l, const float p[3], float out[3]) { st3(out, light_direction(l, v3p(p))); }
+
 /* Light::Illuminate.
  *   Ambient: intensity (FIN/include/lights.h:34)
  *   Direct : Shadow(Ray(p,-direction)) * intensity, t_max = BIGFLOAT (lights.h:50)
@@ -1672,7 +1674,7 @@ static float philox_next(philox_t *g)     /* stands in for rand() / (float) RAND
 }
 static float gray3(v3 c) { return (c.x + c.y + c.z) / 3.0f; }      /* Color::Gray, cyColor.h */
 
-/* MtlBlinn::RandomPhotonBounce, FIN/include/materials.h:99-256 (glossiness 0 branches).
+/* MtlBlinn::RandomPhotonBounce, FIN/include/materials.h:99-256 (all branches, incl. the glossy ones).
  * sqrtf(1-cosI^2) is clamped at 0 like in the Shade restatement. */
 static int random_photon_bounce(const rt_blinn *m, const orc_hit *h, float ray[6], v3 *c, philox_t *rng)
 {
@@ -1712,9 +1714,29 @@ static int random_photon_bounce(const rt_blinn *m, const orc_hit *h, float ray[6
     else if (select > refractionProb + reflectionProb && select < refractionProb + reflectionProb + diffuseProb && diffuseProb > luma) { selected = 2; scale = diffuseProb * rcp; }
     else selected = 3;
     v3 dir, BxDF;
-    if (selected == 0) { dir = tDir; BxDF = sRefr; }
-    else if (selected == 1) { dir = rDir; BxDF = sRefl; }
-    else if (selected == 2) {
+    if (selected == 0) {
+        if (m->refraction_glossiness > 0.f) {              /* :183-190: SampleHemisphere (:40-48), in ITS frame, used as is */
+            float u1 = philox_next(rng), u2 = philox_next(rng);
+            const float r = sqrtf(1.0f - u1 * u1);
+            const float phi = (float)(2 * M_PI * (double)u2);
+            dir = V3(cosf(phi) * r, sinf(phi) * r, u1);
+            const v3 L = vnorm(dir);
+            const v3 H = vnorm(vadd(V, L));
+            const float cosVH = RMAX(0.f, vdot(V, H));
+            BxDF = vscale(sRefr, powf(cosVH, m->refraction_glossiness));
+        } else { dir = tDir; BxDF = sRefr; }
+    } else if (selected == 1) {
+        if (m->reflection_glossiness > 0.f) {              /* :200-207: CosineSampleHemisphere (:27-38) */
+            float u1 = philox_next(rng), u2 = philox_next(rng);
+            const float r = sqrtf(u1);
+            const float theta = (float)(2 * M_PI * (double)u2);
+            dir = V3(r * cosf(theta), r * sinf(theta), sqrtf(fmaxf(0.0f, 1 - u1)));
+            const v3 L = vnorm(dir);
+            const v3 H = vnorm(vadd(V, L));
+            const float cosNH = RMAX(0.f, vdot(N, H));
+            BxDF = vscale(sRefl, powf(cosNH, m->reflection_glossiness));
+        } else { dir = rDir; BxDF = sRefl; }
+    } else if (selected == 2) {
         if (!h->front) return 0;
         v3 Nt = vdot(N, V3(1, 0, 0)) < 0.4f ? vcross(N, V3(1, 0, 0)) : vcross(N, V3(0, 0, 1));   /* createCoordinateSystem :50-59 */
         Nt = vnorm(Nt);

@@ -88,6 +88,7 @@ void  orc_from_node_coords(const rt_node *n, orc_hit *hit);
 /* TraceNode(rootNode, ray, hit); returns 1 on hit (hit initialised by the callee) */
 int   orc_trace(const orc_scene *s, int model, const float ray[6], orc_hit *hit);
 float orc_shadow(const orc_scene *s, int model, const float ray[6], float t_max);
+void  orc_light_direction(const rt_light *l, const float p[3], float out[3]);   /* Light::Direction */
 void  orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
                      const float p[3], const float N[3], float out[3]);
 void  orc_shade(const orc_scene *s, const rt_params *P, const float ray[6], const orc_hit *h,

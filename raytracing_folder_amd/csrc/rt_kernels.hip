@@ -1387,7 +1387,7 @@ struct PhotonArgs {
 };
 
 
-// MtlBlinn::RandomPhotonBounce, FIN/include/materials.h:99-256 (glossiness 0 branches)
+// MtlBlinn::RandomPhotonBounce, FIN/include/materials.h:99-256 (all branches, incl. the glossy ones)
 __device__ bool random_photon_bounce(const rt_blinn &m, const Hit &h, V3 &rp, V3 &rd, V3 &c, Philox &rng)
 {
     const V3 V = -rd;
@@ -1426,9 +1426,29 @@ __device__ bool random_photon_bounce(const rt_blinn &m, const Hit &h, V3 &rp, V3
     else if (select > refractionProb + reflectionProb && select < refractionProb + reflectionProb + diffuseProb && diffuseProb > luma) { selected = 2; scale = diffuseProb * rcp; }
     else selected = 3;
     V3 dir, BxDF;
-    if (selected == 0) { dir = tDir; BxDF = sRefr; }
-    else if (selected == 1) { dir = rDir; BxDF = sRefl; }
-    else if (selected == 2) {
+    if (selected == 0) {
+        if (m.refraction_glossiness > 0.f) {               // :183-190: SampleHemisphere (:40-48), in ITS frame, used as is
+            const float u1 = rng.next(), u2 = rng.next();
+            const float r = sqrtf(1.0f - u1 * u1);
+            const float phi = (float)(2 * M_PI * (double)u2);
+            dir = mk(cosf(phi) * r, sinf(phi) * r, u1);
+            const V3 L = normalize(dir);
+            const V3 H = normalize(V + L);
+            const float cosVH = RMAX(0.f, dot(V, H));
+            BxDF = sRefr * powf(cosVH, m.refraction_glossiness);
+        } else { dir = tDir; BxDF = sRefr; }
+    } else if (selected == 1) {
+        if (m.reflection_glossiness > 0.f) {               // :200-207: CosineSampleHemisphere (:27-38)
+            const float u1 = rng.next(), u2 = rng.next();
+            const float r = sqrtf(u1);
+            const float theta = (float)(2 * M_PI * (double)u2);
+            dir = mk(r * cosf(theta), r * sinf(theta), sqrtf(fmaxf(0.0f, 1 - u1)));
+            const V3 L = normalize(dir);
+            const V3 H = normalize(V + L);
+            const float cosNH = RMAX(0.f, dot(N, H));
+            BxDF = sRefl * powf(cosNH, m.reflection_glossiness);
+        } else { dir = rDir; BxDF = sRefl; }
+    } else if (selected == 2) {
         if (!h.front) return false;
         // createCoordinateSystem, materials.h:50-59
         V3 Nt = dot(N, mk(1, 0, 0)) < 0.4f ? cross(N, mk(1, 0, 0)) : cross(N, mk(0, 0, 1));

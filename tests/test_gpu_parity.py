@@ -307,6 +307,29 @@ def test_photon_pass_matches_oracle(cornell):
         s.set_photons(None)
 
 
+def test_photon_pass_with_glossy_materials_matches_oracle(cornell):
+    """RandomPhotonBounce's hemisphere-sampling branches (reflectionGlossiness / refractionGlossiness > 0,
+    FIN/include/materials.h:183-213; pinned to the reference in tests/golden/pbounce.npz) in the GPU photon pass"""
+    s, cam, e = cornell
+    mats = e["materials"].copy()
+    mats["reflection_glossiness"][mats["reflection"].sum(axis=1) > 0] = 5.0
+    mats["refraction_glossiness"][mats["refraction"].sum(axis=1) > 0] = 0.5
+    assert (mats["reflection_glossiness"] > 0).any() and (mats["refraction_glossiness"] > 0).any()
+    s2 = scenes.rebuild(e, materials=mats)
+    e2 = dict(e, materials=mats)
+    got, att = s2.photon_pass(20000, 8, seed=33)
+    ref, oatt = orc.photon_pass(scenes.oracle_scene(e2), 20000, 8, seed=33)
+    assert int(att) == int(oatt) and len(got) == len(ref)
+    a, b = got[1:], ref[1:]
+    dpos = np.abs(a["position"] - b["position"]).max(axis=1)
+    assert (dpos < 2e-3).mean() > 0.95 and (dpos < 0.1).mean() > 0.99
+    assert abs(a["power"].sum() / b["power"].sum() - 1) < 0.02
+    # and they differ from the mirror-like map: the glossy branches were really taken
+    plain, _ = s.photon_pass(20000, 8, seed=33)
+    n = min(len(plain), len(got)) - 1
+    assert (np.abs(plain["position"][1:n + 1] - got["position"][1:n + 1]).max(axis=1) > 0.1).mean() > 0.05
+
+
 def _close(a, b, rel=2e-5, abs_=1e-6):
     return np.abs(a - b) <= rel * np.maximum(np.abs(a), np.abs(b)) + abs_
 
