@@ -28,8 +28,10 @@
 #define RT_MAX_OBJECTS    4096
 #define RT_BVH_STACK      32     // per-lane traversal stack entries (LDS)
 #define RT_BLOCK          256    // threads per workgroup of the trace/shade kernels
-#define RT_SUB_PHOTONS    32     // photon slots per sub-leaf: a wavefront examines two sub-leaves per step
-#define RT_LEAF_SUBS      4      // sub-leaves per leaf of the walked tree (128 photon slots)
+#ifndef RT_SUB_PHOTONS
+#define RT_SUB_PHOTONS    32     // photon slots per sub-leaf (16 or 32): a wavefront examines 64 / RT_SUB_PHOTONS sub-leaves per step
+#endif
+#define RT_LEAF_SUBS      (128 / RT_SUB_PHOTONS)     // sub-leaves per leaf of the walked tree (128 photon slots)
 #define RT_GATHER_WAVES   4      // waves per gather workgroup
 #define RT_LEAFLIST_CAP   40     // leaf ids kept per query in LDS before the slow path (40 leaves = 5120 slots)
 

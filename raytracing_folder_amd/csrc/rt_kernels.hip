@@ -52,7 +52,8 @@
 #ifndef RT_GATHER_BATCH
 #define RT_GATHER_BATCH 32     // queries a wave lists per phase A (40 leaf ids each: lists + ring keep 5 waves/SIMD)
 #endif
-#define RT_SUBLIST_CAP 192     // sub-leaf ids of one query (three per lane), from at most RT_LEAFLIST_CAP * RT_LEAF_SUBS = 160
+#define RT_SUBLIST_REGS ((RT_LEAFLIST_CAP * RT_LEAF_SUBS + 63) / 64)     // list registers: lane i keeps entries i, 64 + i, ...
+#define RT_SUBLIST_CAP (64 * RT_SUBLIST_REGS)     // sub-leaf ids of one query, from at most RT_LEAFLIST_CAP * RT_LEAF_SUBS
 
 // ------------------------------------------------------------------------------------------------
 // float3 algebra in the reference's evaluation order (cyPoint.h:259-350, cyMatrix.h:542-546)
@@ -1657,8 +1658,10 @@ __device__ __forceinline__ void wave_sync()
 
 struct GatherLds {
     uint16_t leaves[RT_GATHER_BATCH][RT_LEAFLIST_CAP];   // per query (lane) leaf ids
-    uint16_t subs[RT_SUBLIST_CAP];                       // the current query's sub-leaf ids (compaction scratch)
-    uint32_t hist[256];
+    union {                                              // never live at the same time:
+        uint16_t subs[RT_SUBLIST_CAP];                   //   the current query's sub-leaf ids (compaction scratch before the passes)
+        uint32_t hist[256];                              //   the distance-key histogram of the passes
+    };
     float    sel_d[64];
     uint32_t sel_i[64];
     uint32_t sel_n;
@@ -1700,27 +1703,33 @@ __device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuer
     return c;
 }
 
-// Visit every photon slot of the query's sub-leaves, TWO sub-leaves of 32 slots per step (lanes 0-31 the first,
-// lanes 32-63 the second; an odd last one leaves the upper half idle): f(candidate, slot) is called wave-uniformly
+// Visit every photon slot of the query's sub-leaves, 64 / RT_SUB_PHOTONS sub-leaves per step (lanes 0-15 the first,
+// 16-31 the second, ...; a short last step leaves part of the wave idle): f(candidate, slot) is called wave-uniformly
 // (all 64 lanes) so it may use ballots.  The loads of step it+1 are issued before step it is processed (two
 // coalesced 16-byte loads per lane, nothing else is fetched per photon), so a wave always has a step in flight
 // while it works: measured on MI355X the un-pipelined version spent 78 % of its wave cycles parked on s_waitcnt
 // (SQ_WAIT_ANY / SQ_WAVE_CYCLES).  sub_at(e) returns the e-th sub-leaf id as a wave-uniform value.
 #define SUB_NONE 0xFFFFFFFFu
+#define RT_SUBS_PER_STEP (64 / RT_SUB_PHOTONS)
 template <class L, class F>
 __device__ __forceinline__ void scan_subleaves(const DevPhotonMap &pm, L &&sub_at, uint32_t n_sub, int lane,
                                                const GatherQuery &Q, F &&f)
 {
     if (n_sub == 0) return;
-    const uint32_t n_iter = (n_sub + 1u) >> 1;
-    const bool upper = lane >= 32;
-    const uint32_t l32 = (uint32_t)lane & 31u;
+    const uint32_t n_iter = (n_sub + RT_SUBS_PER_STEP - 1u) / RT_SUBS_PER_STEP;
+    const uint32_t part = (uint32_t)lane / RT_SUB_PHOTONS;          // which of the step's sub-leaves this lane reads
+    const uint32_t lsub = (uint32_t)lane % RT_SUB_PHOTONS;
     auto ld = [&](uint32_t it, float4 &a, float4 &b, uint32_t &slot, bool &valid) {
-        const uint32_t s0 = sub_at(2u * it);
-        const uint32_t s1 = (2u * it + 1u < n_sub) ? sub_at(2u * it + 1u) : SUB_NONE;
-        valid = !upper || s1 != SUB_NONE;
-        const uint32_t sub = upper ? (s1 != SUB_NONE ? s1 : s0) : s0;       // idle lanes re-read the first one's line
-        slot = sub * RT_SUB_PHOTONS + l32;
+        const uint32_t e0 = RT_SUBS_PER_STEP * it;
+        const uint32_t s0 = sub_at(e0);
+        uint32_t mine = s0;
+        valid = true;
+#pragma unroll
+        for (uint32_t j = 1; j < RT_SUBS_PER_STEP; j++) {
+            const uint32_t sj = (e0 + j < n_sub) ? sub_at(e0 + j) : SUB_NONE;                  // wave-uniform
+            if (part == j) { valid = sj != SUB_NONE; mine = sj != SUB_NONE ? sj : s0; }       // idle lanes re-read the first one's lines
+        }
+        slot = mine * RT_SUB_PHOTONS + lsub;
         a = pm.pa[slot];
         b = pm.pb[slot];
     };
@@ -1829,34 +1838,45 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 nl++;
             };
             if (pending && n_leaves) {
-                // Depth-first, left to right (ascending leaf ids), one visit per INTERNAL node whose box the ball cuts: a
-                // visit reads the boxes of both children (heap order: they are adjacent, one aligned 64-byte line) and
-                // remembers a right child that passed in a bit per depth, so no box is fetched twice and the chain of
-                // dependent loads -- what phase A waits for -- is about half as long as one load per tested node.
+                // Depth-first, left to right (ascending leaf ids).  Phase A waits for a chain of dependent box reads, so a
+                // visit reads as much as one aligned line pair gives: the boxes of all four GRANDCHILDREN of an internal node
+                // (heap order: nodes 4n..4n+3, 128 contiguous bytes) -- a grandchild the ball cuts implies its parent is cut,
+                // so the level between needs no test of its own.  Which grandchildren are still to be visited is kept as a
+                // 4-bit mask per pair of levels; no box is fetched twice.  An odd last level is a two-child visit.
                 if (box_dist2(G.pm.tbox + 2, a.x, a.y, a.z) < r2cur) {
                     if (n_leaves == 1) list_leaf(0u);
                     else {
-                        uint32_t node = 1, depth = 0, right_pending = 0;
+                        uint32_t node = 1, pd = 0;              // current internal node and its pair-depth (tree depth = 2 * pd)
+                        unsigned long long todo_mask = 0;       // nibble pd: grandchildren of the path's node at pair-depth pd still to visit
                         for (;;) {
-                            const float4 *cb = G.pm.tbox + 4 * (size_t)node;          // boxes of 2*node and 2*node + 1
-                            const bool pl = box_dist2(cb, a.x, a.y, a.z) < r2cur, pr = box_dist2(cb + 2, a.x, a.y, a.z) < r2cur;
-                            const uint32_t l = 2u * node;
-                            if (l >= n_leaves) {
-                                if (pl) list_leaf(l - n_leaves);
-                                if (pr) list_leaf(l + 1u - n_leaves);
-                            } else if (pl) {
-                                if (pr) right_pending |= 1u << depth;
-                                node = l; depth++;
-                                continue;
-                            } else if (pr) {
-                                node = l + 1u; depth++;
-                                continue;
+                            if (4u * node < 2u * n_leaves && 2u * node < n_leaves) {
+                                // grandchildren exist (they are internal nodes, or the leaves themselves)
+                                const float4 *gb = G.pm.tbox + 8 * (size_t)node;      // boxes of 4*node .. 4*node + 3
+                                uint32_t m4 = 0;
+#pragma unroll
+                                for (int i = 0; i < 4; i++) if (box_dist2(gb + 2 * i, a.x, a.y, a.z) < r2cur) m4 |= 1u << i;
+                                if (4u * node >= n_leaves) {     // the grandchildren are leaves
+                                    for (int i = 0; i < 4; i++) if ((m4 >> i) & 1u) list_leaf(4u * node + (uint32_t)i - n_leaves);
+                                } else if (m4) {
+                                    const uint32_t i = (uint32_t)__ffs((int)m4) - 1u;
+                                    todo_mask |= (unsigned long long)(m4 & ~(1u << i)) << (4u * pd);
+                                    node = 4u * node + i; pd++;
+                                    continue;
+                                }
+                            } else {
+                                // one level left: the children are leaves
+                                const float4 *cb = G.pm.tbox + 4 * (size_t)node;
+                                if (box_dist2(cb, a.x, a.y, a.z) < r2cur) list_leaf(2u * node - n_leaves);
+                                if (box_dist2(cb + 2, a.x, a.y, a.z) < r2cur) list_leaf(2u * node + 1u - n_leaves);
                             }
-                            if (!right_pending) break;
-                            const uint32_t d = 31u - (uint32_t)__clz((int)right_pending);   // deepest level with a right child to do
-                            right_pending &= ~(1u << d);
-                            node = ((node >> (depth - d)) << 1) | 1u;                       // that ancestor's right child
-                            depth = d + 1u;
+                            if (!todo_mask) break;
+                            const uint32_t bit = 63u - (uint32_t)__clzll((long long)todo_mask);     // deepest pair-depth with work left
+                            const uint32_t d = bit >> 2;
+                            const uint32_t nib = (uint32_t)(todo_mask >> (4u * d)) & 15u;
+                            const uint32_t i = (uint32_t)__ffs((int)nib) - 1u;                    // its leftmost grandchild not yet visited
+                            todo_mask &= ~(1ull << (4u * d + i));
+                            node = ((node >> (2u * (pd - d))) << 2) + i;                          // that ancestor's grandchild i
+                            pd = d + 1u;
                         }
                     }
                 }
@@ -1883,21 +1903,22 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 // (a leaf holds 128 photon slots; most query balls cut only part of one: testing its four 32-slot
                 // sub-boxes examines about a fifth fewer photons than reading whole 64-slot leaves did)
                 uint32_t n_sub = 0;
-                uint32_t my_sub0 = 0, my_sub1 = 0, my_sub2 = 0;     // lane i keeps list entries i, 64 + i and 128 + i
+                uint32_t my_sub[RT_SUBLIST_REGS];          // lane i keeps list entries i, 64 + i, 128 + i, ...
+#pragma unroll
+                for (int r = 0; r < RT_SUBLIST_REGS; r++) my_sub[r] = 0;
                 if (!slow) {
                     for (uint32_t base = 0; base < qnl * RT_LEAF_SUBS; base += 64u) {
                         const uint32_t e = base + (uint32_t)lane;
-                        const bool have_e = (e >> 2) < qnl;
-                        const uint32_t sub = have_e ? (uint32_t)L.leaves[q][e >> 2] * RT_LEAF_SUBS + (e & 3u) : 0u;
+                        const bool have_e = (e / RT_LEAF_SUBS) < qnl;
+                        const uint32_t sub = have_e ? (uint32_t)L.leaves[q][e / RT_LEAF_SUBS] * RT_LEAF_SUBS + (e % RT_LEAF_SUBS) : 0u;
                         const bool in = have_e && box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
                         const unsigned long long m = __ballot(in);
                         if (in) L.subs[n_sub + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)sub;
                         n_sub += (uint32_t)__popcll(m);
                     }
                     wave_sync();
-                    my_sub0 = (uint32_t)lane < n_sub ? (uint32_t)L.subs[lane] : 0u;
-                    my_sub1 = (uint32_t)lane + 64u < n_sub ? (uint32_t)L.subs[lane + 64] : 0u;
-                    my_sub2 = (uint32_t)lane + 128u < n_sub ? (uint32_t)L.subs[lane + 128] : 0u;
+#pragma unroll
+                    for (int r = 0; r < RT_SUBLIST_REGS; r++) my_sub[r] = (uint32_t)lane + 64u * r < n_sub ? (uint32_t)L.subs[lane + 64 * r] : 0u;
                     wave_sync();                           // L.subs is reused by the next query
                 } else {
                     // list too long for LDS: every pass walks ALL sub-leaf boxes instead (64 per step) -- no list is kept
@@ -1914,14 +1935,13 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         // one loop per list register (26 entries on average: the second and third loops are rare): inside
                         // a loop the entry comes from ONE register by v_readlane, no selection between registers -- that
                         // selection cost more scalar instructions per step than the photon arithmetic cost vector ones
-                        scan_subleaves(G.pm, [&](uint32_t e) { return (uint32_t)__builtin_amdgcn_readlane((int)my_sub0, (int)e); },
-                                       min(n_sub, 64u), lane, Q, f);
-                        if (n_sub > 64u)
-                            scan_subleaves(G.pm, [&](uint32_t e) { return (uint32_t)__builtin_amdgcn_readlane((int)my_sub1, (int)e); },
-                                           min(n_sub - 64u, 64u), lane, Q, f);
-                        if (n_sub > 128u)
-                            scan_subleaves(G.pm, [&](uint32_t e) { return (uint32_t)__builtin_amdgcn_readlane((int)my_sub2, (int)e); },
-                                           n_sub - 128u, lane, Q, f);
+#pragma unroll
+                        for (int r = 0; r < RT_SUBLIST_REGS; r++) {
+                            if (n_sub <= 64u * r) break;
+                            const uint32_t reg = my_sub[r];
+                            scan_subleaves(G.pm, [&](uint32_t e) { return (uint32_t)__builtin_amdgcn_readlane((int)reg, (int)e); },
+                                           min(n_sub - 64u * r, 64u), lane, Q, f);
+                        }
                         return;
                     }
                     for (uint32_t base = 0; base < n_sub_total; base += 64u) {
@@ -1929,11 +1949,19 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
                         unsigned long long m = __ballot(in);
                         while (m) {
-                            const uint32_t s0 = base + (uint32_t)(__ffsll((long long)m) - 1);
-                            m &= m - 1;
-                            uint32_t s1 = SUB_NONE;
-                            if (m) { s1 = base + (uint32_t)(__ffsll((long long)m) - 1); m &= m - 1; }
-                            scan_subleaves(G.pm, [&](uint32_t e) { return e == 0u ? s0 : s1; }, s1 == SUB_NONE ? 1u : 2u, lane, Q, f);
+                            uint32_t sl[RT_SUBS_PER_STEP];
+                            uint32_t cnt = 0;
+#pragma unroll
+                            for (uint32_t j = 0; j < RT_SUBS_PER_STEP; j++) {
+                                sl[j] = SUB_NONE;
+                                if (m) { sl[j] = base + (uint32_t)(__ffsll((long long)m) - 1); m &= m - 1; cnt++; }
+                            }
+                            scan_subleaves(G.pm, [&](uint32_t e) {
+                                uint32_t v = sl[0];
+#pragma unroll
+                                for (uint32_t j = 1; j < RT_SUBS_PER_STEP; j++) if (e == j) v = sl[j];
+                                return v;
+                            }, cnt, lane, Q, f);
                         }
                     }
                 };
