@@ -854,7 +854,10 @@ static rt_status upload_photons(rt_scene *s, DeviceState *D, bool caustic)
     if (n_leaves > 65536) return fail(RT_ERR_LIMIT, "photon map too large for the gather structure (%zu photons, at most 8 Mi)", recs.size());
     const uint32_t n_sub = n_leaves * RT_LEAF_SUBS;
     std::vector<float> hbox(6 * 2 * (size_t)n_sub);                     // boxes of the whole heap down to the sub-leaves
-    std::vector<float4> pa((size_t)n_sub * RT_SUB_PHOTONS), pb(pa.size());
+    // one more sub-leaf than the tree has, every slot empty: the kernel pads its sub-leaf lists with it; slots are
+    // addressed by 32-bit byte offsets (at most 2^18 + 1 sub-leaves of 512 bytes)
+    std::vector<float4> pa(((size_t)n_sub + 1) * RT_SUB_PHOTONS), pb(pa.size());
+    static_assert((65536ull * RT_LEAF_SUBS + 1) * RT_SUB_PHOTONS * sizeof(float4) <= 0xFFFFFFFFull, "photon slots are addressed by 32-bit byte offsets");
     for (size_t i = 0; i < pa.size(); i++) { pa[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0); pb[i] = make_float4(0, 0, 0, 0); }
     struct Build {
         std::vector<PRec> &r; std::vector<float> &hbox; std::vector<float4> &pa, &pb; uint32_t n_sub;

@@ -52,8 +52,8 @@
 #ifndef RT_GATHER_BATCH
 #define RT_GATHER_BATCH 32     // queries a wave lists per phase A (40 leaf ids each: lists + ring keep 5 waves/SIMD)
 #endif
-#define RT_SUBLIST_REGS ((RT_LEAFLIST_CAP * RT_LEAF_SUBS + 63) / 64)     // list registers: lane i keeps entries i, 64 + i, ...
-#define RT_SUBLIST_CAP (64 * RT_SUBLIST_REGS)     // sub-leaf ids of one query, from at most RT_LEAFLIST_CAP * RT_LEAF_SUBS
+#define RT_SUBS_PER_STEP (64 / RT_SUB_PHOTONS)                  // sub-leaves a wavefront examines per step
+#define RT_SUBLIST_CAP (RT_LEAFLIST_CAP * RT_LEAF_SUBS)         // sub-leaf ids of one query
 
 // ------------------------------------------------------------------------------------------------
 // float3 algebra in the reference's evaluation order (cyPoint.h:259-350, cyMatrix.h:542-546)
@@ -418,11 +418,17 @@ __device__ __forceinline__ void rng2(const RngCtx &c, uint32_t purpose, uint32_t
 __host__ __device__ inline uint32_t child_node(uint32_t node, uint32_t kind) { return node * 0x9E3779B1u + kind * 0x85EBCA6Bu + 0x27D4EB2Fu; }
 
 // ------------------------------------------------------------------------------------------------
+// the lanes where a condition holds: the builtin keeps the condition a lane mask (one s_and with exec); HIP's
+// __ballot(int) round-trips it through a 0/1 register (v_cndmask + v_cmp_ne per call, on the VALU the gather is bound by)
+__device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+// how many lanes of a mask lie below this one: v_mbcnt_lo + v_mbcnt_hi
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
 // queues: wave-aggregated append (one atomic per wave, __ballot + popcount for the lane offset)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_push(bool pred, uint32_t *counter)
 {
-    const unsigned long long mask = __ballot(pred);
+    const unsigned long long mask = ballot64(pred);
     if (mask == 0) return 0xFFFFFFFFu;
     const int lane = __lane_id();
     const int leader = __ffsll((long long)mask) - 1;
@@ -1658,13 +1664,11 @@ __device__ __forceinline__ void wave_sync()
 
 struct GatherLds {
     uint16_t leaves[RT_GATHER_BATCH][RT_LEAFLIST_CAP];   // per query (lane) leaf ids
+    uint32_t subs[RT_SUBLIST_CAP + RT_SUBS_PER_STEP];    // the current query's sub-leaf ids, padded to whole steps with the dummy sub-leaf
     union {                                              // never live at the same time:
-        uint16_t subs[RT_SUBLIST_CAP];                   //   the current query's sub-leaf ids (compaction scratch before the passes)
-        uint32_t hist[256];                              //   the distance-key histogram of the passes
+        uint32_t hist[256];                              //   the distance-key histogram while the k-th photon's bin is located
+        struct { float sel_d[64]; uint32_t sel_i[64]; uint32_t sel_n; };   //   then that bin's photons for the exact rank selection
     };
-    float    sel_d[64];
-    uint32_t sel_i[64];
-    uint32_t sel_n;
 #if RT_GATHER_RING
     // everything pass 1 read about a photon whose distance lies in the band around the predicted k-th one,
     // so that the exact selection does not have to read the leaves a second time
@@ -1687,57 +1691,54 @@ __device__ __forceinline__ float byte_over_255(uint32_t c)
     return __fmaf_rn(e, r, q);
 }
 
-// one lane's photon of one leaf against one query (the test of LocatePhotons :383-392)
-struct Cand { bool ok; float d2; uint32_t key; float4 pa, pb; };
+// one lane's photon of one sub-leaf against one query (the test of LocatePhotons :383-392).  d2 is the squared distance
+// for a photon that faces the surface and +infinity for one that does not (or for an empty slot, whose position is
+// 3e38): "accepted" is then the single compare d2 < rq2, and every narrower test (below t_lo, inside the band) is one
+// compare as well -- a compare's lane mask is its ballot, while a ballot of a combined condition costs two more
+// vector instructions, on the unit this kernel is bound by.
+struct Cand { float d2; float4 pa, pb; };
 struct GatherQuery { float px, py, pz, nx, ny, nz, rq2, kscale; };
-__device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuery &Q, bool valid)
+__device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuery &Q)
 {
     Cand c;
     c.pa = pa; c.pb = pb;
     const float dfx = pa.x - Q.px, dfy = pa.y - Q.py, dfz = pa.z - Q.pz;       // dif = p.position - np.pos
-    c.d2 = dfx * dfx + dfy * dfy + dfz * dfz;                                   // LengthSquared
-    c.ok = valid && (c.d2 < Q.rq2) && !((pa.w * Q.nx + pb.x * Q.ny + pb.y * Q.nz) >= 0);   // dist2 < dist2[0]; dir.N >= 0 rejects
-    // 24-bit fixed-point distance key: kscale = 16777000 / rq2, so an accepted photon (d2 < rq2) gives
-    // at most 16777000 * (1 + 2^-22) < 2^24 whatever the roundings; rejected ones are never looked at
-    c.key = (uint32_t)(c.d2 * Q.kscale);
+    const float d2 = dfx * dfx + dfy * dfy + dfz * dfz;                         // LengthSquared
+    const bool away = (pa.w * Q.nx + pb.x * Q.ny + pb.y * Q.nz) >= 0;           // dir.N >= 0 rejects
+    c.d2 = away ? __builtin_inff() : d2;                                        // dist2 < dist2[0] is tested by the caller
     return c;
 }
+// 24-bit fixed-point distance key of an ACCEPTED photon: kscale = 16777000 / rq2, so d2 < rq2 gives at most
+// 16777000 * (1 + 2^-22) < 2^24 whatever the roundings
+__device__ __forceinline__ uint32_t cand_key(const Cand &c, const GatherQuery &Q) { return (uint32_t)(c.d2 * Q.kscale); }
 
-// Visit every photon slot of the query's sub-leaves, 64 / RT_SUB_PHOTONS sub-leaves per step (lanes 0-15 the first,
-// 16-31 the second, ...; a short last step leaves part of the wave idle): f(candidate, slot) is called wave-uniformly
-// (all 64 lanes) so it may use ballots.  The loads of step it+1 are issued before step it is processed (two
-// coalesced 16-byte loads per lane, nothing else is fetched per photon), so a wave always has a step in flight
-// while it works: measured on MI355X the un-pipelined version spent 78 % of its wave cycles parked on s_waitcnt
-// (SQ_WAIT_ANY / SQ_WAVE_CYCLES).  sub_at(e) returns the e-th sub-leaf id as a wave-uniform value.
-#define SUB_NONE 0xFFFFFFFFu
-#define RT_SUBS_PER_STEP (64 / RT_SUB_PHOTONS)
-template <class L, class F>
-__device__ __forceinline__ void scan_subleaves(const DevPhotonMap &pm, L &&sub_at, uint32_t n_sub, int lane,
+// Visit every photon slot of the n_sub sub-leaves listed in LDS (ids[]; padded to whole steps with the dummy sub-leaf,
+// whose slots are all empty), 64 / RT_SUB_PHOTONS sub-leaves per step (lanes 0-31 the first, 32-63 the second):
+// f(candidate, slot) is called wave-uniformly (all 64 lanes) so it may use ballots.  A lane's share of a step is one LDS
+// read (its sub-leaf id), one shift-or (the byte offset, 32 bits) and two coalesced 16-byte loads from scalar bases --
+// nothing else is fetched per photon.  The loads of step it+1 are issued before step it is processed, so a wave
+// always has a step in flight while it works: measured on MI355X the un-pipelined version spent 78 % of its wave
+// cycles parked on s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES).
+template <class F>
+__device__ __forceinline__ void scan_subleaves(const DevPhotonMap &pm, const uint32_t *ids, uint32_t n_sub, int lane,
                                                const GatherQuery &Q, F &&f)
 {
     if (n_sub == 0) return;
     const uint32_t n_iter = (n_sub + RT_SUBS_PER_STEP - 1u) / RT_SUBS_PER_STEP;
-    const uint32_t part = (uint32_t)lane / RT_SUB_PHOTONS;          // which of the step's sub-leaves this lane reads
-    const uint32_t lsub = (uint32_t)lane % RT_SUB_PHOTONS;
-    auto ld = [&](uint32_t it, float4 &a, float4 &b, uint32_t &slot, bool &valid) {
-        const uint32_t e0 = RT_SUBS_PER_STEP * it;
-        const uint32_t s0 = sub_at(e0);
-        uint32_t mine = s0;
-        valid = true;
-#pragma unroll
-        for (uint32_t j = 1; j < RT_SUBS_PER_STEP; j++) {
-            const uint32_t sj = (e0 + j < n_sub) ? sub_at(e0 + j) : SUB_NONE;                  // wave-uniform
-            if (part == j) { valid = sj != SUB_NONE; mine = sj != SUB_NONE ? sj : s0; }       // idle lanes re-read the first one's lines
-        }
-        slot = mine * RT_SUB_PHOTONS + lsub;
-        a = pm.pa[slot];
-        b = pm.pb[slot];
+    const uint32_t *mine = ids + (uint32_t)lane / RT_SUB_PHOTONS;           // which of a step's sub-leaves this lane reads
+    const uint32_t lane_off = ((uint32_t)lane % RT_SUB_PHOTONS) * 16u;
+    const char *pa = (const char *)pm.pa, *pb = (const char *)pm.pb;
+    auto ld = [&](uint32_t it, float4 &a, float4 &b, uint32_t &slot) {
+        const uint32_t off = (mine[RT_SUBS_PER_STEP * it] * (RT_SUB_PHOTONS * 16u)) | lane_off;   // < 2^32: checked at upload
+        slot = off;
+        a = *(const float4 *)(pa + off);
+        b = *(const float4 *)(pb + off);
     };
 #if RT_GATHER_AHEAD == 0
     for (uint32_t it = 0; it < n_iter; it++) {
-        float4 a, b; uint32_t sl; bool v;
-        ld(it, a, b, sl, v);
-        f(make_cand(a, b, Q, v), (size_t)sl);
+        float4 a, b; uint32_t sl;
+        ld(it, a, b, sl);
+        f(make_cand(a, b, Q), sl);
     }
 #else
     // two register sets used alternately, each refilled right after it was consumed; the reload index
@@ -1745,20 +1746,22 @@ __device__ __forceinline__ void scan_subleaves(const DevPhotonMap &pm, L &&sub_a
     // is a loop-carried copy of the other
     float4 a0, b0, a1, b1;
     uint32_t s0, s1;
-    bool v0, v1;
-    ld(0u, a0, b0, s0, v0);
+    ld(0u, a0, b0, s0);
     uint32_t it = 0;
     for (; it + 1 < n_iter; it += 2) {
-        ld(it + 1, a1, b1, s1, v1);
-        f(make_cand(a0, b0, Q, v0), (size_t)s0);
-        ld(min(it + 2, n_iter - 1), a0, b0, s0, v0);
-        f(make_cand(a1, b1, Q, v1), (size_t)s1);
+        ld(it + 1, a1, b1, s1);
+        f(make_cand(a0, b0, Q), s0);
+        ld(min(it + 2, n_iter - 1), a0, b0, s0);
+        f(make_cand(a1, b1, Q), s1);
     }
-    if (it < n_iter) f(make_cand(a0, b0, Q, v0), (size_t)s0);
+    if (it < n_iter) f(make_cand(a0, b0, Q), s0);
 #endif
 }
 
-#ifdef RT_GATHER_WAVES_PER_EU
+#ifndef RT_GATHER_WAVES_PER_EU
+#define RT_GATHER_WAVES_PER_EU 5     // 96 registers: five waves per SIMD is what the LDS footprint allows too
+#endif
+#if RT_GATHER_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(RT_GATHER_WAVES_PER_EU, RT_GATHER_WAVES_PER_EU)))
 #endif
 __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
@@ -1830,7 +1833,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
             r2cur = fminf(fmaxf(guess_c / (float)(cnt > 0u ? cnt : 1u), r2 * 1.0e-4f), r2);
         }
 
-        while (__ballot(pending)) {
+        while (ballot64(pending)) {
             // ---------------- phase A: pending lanes list the leaves inside their trial radius ----
             uint32_t nl = 0;
             auto list_leaf = [&](uint32_t leaf) {
@@ -1886,7 +1889,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
             pending = false;
 #endif
             // ---------------- phase B: the wave takes the pending queries one by one --------------
-            unsigned long long todo = __ballot(pending);
+            unsigned long long todo = ballot64(pending);
             while (todo) {
                 const int q = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
@@ -1899,75 +1902,52 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 const uint32_t qnl = lane_u(nl, q);
                 const bool final_round = rq2 >= r2;
                 const bool slow = qnl > RT_LEAFLIST_CAP;   // the LDS list overflowed
-                // ---- the query's sub-leaves: four boxes per listed leaf, tested 64 at a time, kept in registers ----
+                // ---- the query's sub-leaves: RT_LEAF_SUBS boxes per listed leaf, tested 64 at a time, ids compacted in LDS ----
                 // (a leaf holds 128 photon slots; most query balls cut only part of one: testing its four 32-slot
                 // sub-boxes examines about a fifth fewer photons than reading whole 64-slot leaves did)
+                const uint32_t dummy_sub = n_sub_total;    // one more sub-leaf after the real ones, every slot empty
                 uint32_t n_sub = 0;
-                uint32_t my_sub[RT_SUBLIST_REGS];          // lane i keeps list entries i, 64 + i, 128 + i, ...
-#pragma unroll
-                for (int r = 0; r < RT_SUBLIST_REGS; r++) my_sub[r] = 0;
+                wave_sync();                               // the previous query's passes are done with L.subs
                 if (!slow) {
                     for (uint32_t base = 0; base < qnl * RT_LEAF_SUBS; base += 64u) {
                         const uint32_t e = base + (uint32_t)lane;
                         const bool have_e = (e / RT_LEAF_SUBS) < qnl;
                         const uint32_t sub = have_e ? (uint32_t)L.leaves[q][e / RT_LEAF_SUBS] * RT_LEAF_SUBS + (e % RT_LEAF_SUBS) : 0u;
-                        const bool in = have_e && box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
-                        const unsigned long long m = __ballot(in);
-                        if (in) L.subs[n_sub + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)sub;
+                        const float bd = have_e ? box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) : __builtin_inff();
+                        const unsigned long long m = ballot64(bd < rq2);
+                        if (bd < rq2) L.subs[n_sub + lanes_below(m)] = sub;
                         n_sub += (uint32_t)__popcll(m);
                     }
+                    if (lane < RT_SUBS_PER_STEP) L.subs[n_sub + lane] = dummy_sub;
                     wave_sync();
-#pragma unroll
-                    for (int r = 0; r < RT_SUBLIST_REGS; r++) my_sub[r] = (uint32_t)lane + 64u * r < n_sub ? (uint32_t)L.subs[lane + 64 * r] : 0u;
-                    wave_sync();                           // L.subs is reused by the next query
                 } else {
                     // list too long for LDS: every pass walks ALL sub-leaf boxes instead (64 per step) -- no list is kept
                     for (uint32_t base = 0; base < n_sub_total; base += 64u) {
                         const uint32_t sub = base + (uint32_t)lane;
-                        const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
-                        n_sub += (uint32_t)__popcll(__ballot(in));
+                        const float bd = sub < n_sub_total ? box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) : __builtin_inff();
+                        n_sub += (uint32_t)__popcll(ballot64(bd < rq2));
                     }
                 }
                 n_rounds++; n_slow += slow ? 1u : 0u; n_reads += n_sub;
                 // run one pass over the query's sub-leaves
                 auto for_each = [&](auto &&f) {
-                    if (!slow) {
-                        // one loop per list register (26 entries on average: the second and third loops are rare): inside
-                        // a loop the entry comes from ONE register by v_readlane, no selection between registers -- that
-                        // selection cost more scalar instructions per step than the photon arithmetic cost vector ones
-#pragma unroll
-                        for (int r = 0; r < RT_SUBLIST_REGS; r++) {
-                            if (n_sub <= 64u * r) break;
-                            const uint32_t reg = my_sub[r];
-                            scan_subleaves(G.pm, [&](uint32_t e) { return (uint32_t)__builtin_amdgcn_readlane((int)reg, (int)e); },
-                                           min(n_sub - 64u * r, 64u), lane, Q, f);
-                        }
-                        return;
-                    }
+                    if (!slow) { scan_subleaves(G.pm, L.subs, n_sub, lane, Q, f); return; }
                     for (uint32_t base = 0; base < n_sub_total; base += 64u) {
                         const uint32_t sub = base + (uint32_t)lane;
-                        const bool in = sub < n_sub_total && box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) < rq2;
-                        unsigned long long m = __ballot(in);
-                        while (m) {
-                            uint32_t sl[RT_SUBS_PER_STEP];
-                            uint32_t cnt = 0;
-#pragma unroll
-                            for (uint32_t j = 0; j < RT_SUBS_PER_STEP; j++) {
-                                sl[j] = SUB_NONE;
-                                if (m) { sl[j] = base + (uint32_t)(__ffsll((long long)m) - 1); m &= m - 1; cnt++; }
-                            }
-                            scan_subleaves(G.pm, [&](uint32_t e) {
-                                uint32_t v = sl[0];
-#pragma unroll
-                                for (uint32_t j = 1; j < RT_SUBS_PER_STEP; j++) if (e == j) v = sl[j];
-                                return v;
-                            }, cnt, lane, Q, f);
-                        }
+                        const float bd = sub < n_sub_total ? box_dist2(G.pm.sbox + 2 * (size_t)sub, Q.px, Q.py, Q.pz) : __builtin_inff();
+                        const unsigned long long m = ballot64(bd < rq2);
+                        if (!m) continue;
+                        wave_sync();
+                        if (bd < rq2) L.subs[lanes_below(m)] = sub;
+                        const uint32_t cnt = (uint32_t)__popcll(m);
+                        if (lane < RT_SUBS_PER_STEP) L.subs[cnt + lane] = dummy_sub;
+                        wave_sync();
+                        scan_subleaves(G.pm, L.subs, cnt, lane, Q, f);
                     }
                 };
                 float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // pass 1: sums over ALL candidates
 #ifdef RT_EXP_LOADONLY          /* cost attribution build: phase A + the leaf reads, nothing else; results are garbage */
-                for_each([&](const Cand &cd, size_t) { s_pr += cd.pa.x + cd.pb.x; });
+                for_each([&](const Cand &cd, uint32_t) { s_pr += cd.pa.x + cd.pb.x; });
                 visited += n_sub;
                 if (G.mode == 1 && s_pr == 12345.678f && lane == 0) G.out_irr[0] = s_pr;
                 if (lane == q) pending = false;
@@ -1994,21 +1974,24 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 // pass 1: count + histogram of every accepted photon.  Photons closer than t_lo (safely inside the
                 // k nearest if the prediction holds) are summed right away; those between t_lo and t_hi, the band
                 // the k-th distance is expected in, are parked in the LDS ring with all their data.
+                // The histogram bin is the top 8 bits of the 24-bit key: (uint)(d2 * kscale) >> 16 == (uint)(d2 * (kscale / 65536)),
+                // the scaling by a power of two being exact.
+                const float kscale_bin = Q.kscale * (1.0f / 65536.0f);
 #if RT_GATHER_RING
                 const float pk = (pred_rk2 > 0.0f && pred_rk2 < rq2) ? pred_rk2 : rq2 * (1.0f / RT_GATHER_GUESS);
                 const float t_lo = RT_GATHER_BAND_LO * pk;
-                const float t_hi = final_round ? rq2 : fminf(RT_GATHER_BAND_HI * pk, rq2);
+                const float t_hi = final_round ? rq2 : fminf(RT_GATHER_BAND_HI * pk, rq2);     // <= rq2: inside the band implies accepted
                 uint32_t n_ring = 0;                       // wave-uniform (ballot popcounts)
-                for_each([&](const Cand &cd, size_t) {
-                    const bool lo = cd.ok && cd.d2 < t_lo;
-                    const bool rg = cd.ok && !lo && cd.d2 < t_hi;
-                    M += (uint32_t)__popcll(__ballot(cd.ok));
-                    if (cd.ok) atomicAdd(&L.hist[cd.key >> 16], 1u);
-                    accumulate(cd.pa, cd.pb, lo);
-                    const unsigned long long mr = __ballot(rg);
+                for_each([&](const Cand &cd, uint32_t) {
+                    const unsigned long long m_ok = ballot64(cd.d2 < rq2);
+                    const unsigned long long m_lo = ballot64(cd.d2 < t_lo);
+                    const unsigned long long mr = ballot64(cd.d2 < t_hi) & ~m_lo;
+                    M += (uint32_t)__popcll(m_ok);
+                    if (cd.d2 < rq2) atomicAdd(&L.hist[(uint32_t)(cd.d2 * kscale_bin)], 1u);
+                    accumulate(cd.pa, cd.pb, cd.d2 < t_lo);
                     if (mr) {
-                        if (rg) {
-                            const uint32_t at = n_ring + (uint32_t)__popcll(mr & ((1ull << lane) - 1ull));
+                        if (cd.d2 < t_hi && !(cd.d2 < t_lo)) {
+                            const uint32_t at = n_ring + lanes_below(mr);
                             if (at < (uint32_t)RT_GATHER_RING) {
                                 L.ring_a[at] = make_float4(cd.d2, cd.pa.w, cd.pb.x, cd.pb.y);
                                 L.ring_b[at] = make_float2(cd.pb.z, cd.pb.w);
@@ -2018,10 +2001,10 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     }
                 });
 #else
-                for_each([&](const Cand &cd, size_t) {
-                    accumulate(cd.pa, cd.pb, cd.ok);
-                    M += (uint32_t)__popcll(__ballot(cd.ok));
-                    if (cd.ok) atomicAdd(&L.hist[cd.key >> 16], 1u);
+                for_each([&](const Cand &cd, uint32_t) {
+                    accumulate(cd.pa, cd.pb, cd.d2 < rq2);
+                    M += (uint32_t)__popcll(ballot64(cd.d2 < rq2));
+                    if (cd.d2 < rq2) atomicAdd(&L.hist[(uint32_t)(cd.d2 * kscale_bin)], 1u);
                 });
 #endif
                 visited += n_sub;
@@ -2045,7 +2028,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         const uint32_t mine = h0 + h1 + h2 + h3;
                         const uint32_t incl = wave_scan_add_u(mine);
                         const uint32_t excl = incl - mine;
-                        const unsigned long long m = __ballot(incl >= need);
+                        const unsigned long long m = ballot64(incl >= need);
                         const int owner = __ffsll((long long)m) - 1;      // first lane whose range reaches `need`
                         uint32_t digit = 0, before = 0, cntb = 0;
                         if (lane == owner) {
@@ -2066,11 +2049,13 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
                         wave_sync();
                         const uint32_t hi_mask = ~((1u << (shift + 8)) - 1u) & 0xFFFFFFu;
-                        for_each([&](const Cand &cd, size_t) {
-                            if (cd.ok && (cd.key & hi_mask) == prefix) atomicAdd(&L.hist[(cd.key >> shift) & 255u], 1u);
+                        for_each([&](const Cand &cd, uint32_t) {
+                            const uint32_t key = cand_key(cd, Q);
+                            if (cd.d2 < rq2 && (key & hi_mask) == prefix) atomicAdd(&L.hist[(key >> shift) & 255u], 1u);
                         });
                     }
                     const uint32_t bin_mask = ~((1u << shift) - 1u) & 0xFFFFFFu;
+                    wave_sync();                           // the histogram is dead from here on: its LDS now holds the selection
                     if (lane == 0) L.sel_n = 0;
                     wave_sync();
                     uint32_t tie_taken = 0;                // only used when in_bin > 64 (identical keys)
@@ -2095,11 +2080,11 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                             const uint32_t kb = (uint32_t)(ra.x * Q.kscale) & bin_mask;
                             const bool take = have && kb < prefix;
                             const bool inb = have && kb == prefix;
-                            const unsigned long long mb = __ballot(inb);
+                            const unsigned long long mb = ballot64(inb);
                             if (mb) {
                                 const uint32_t sbase = lane_u(L.sel_n, 0);
                                 if (inb) {
-                                    const uint32_t at = sbase + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                                    const uint32_t at = sbase + lanes_below(mb);
                                     if (at < 64u) { L.sel_d[at] = ra.x; L.sel_i[at] = idx; }
                                 }
                                 wave_sync();
@@ -2114,11 +2099,12 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     n_reads += n_sub;
                     // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
                     s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
-                    for_each([&](const Cand &cd, size_t s) {
-                        const uint32_t kb = cd.key & bin_mask;
-                        bool take = cd.ok && kb < prefix;
-                        const bool inb = cd.ok && kb == prefix;
-                        const unsigned long long mb = __ballot(inb);
+                    for_each([&](const Cand &cd, uint32_t s) {
+                        const bool ok = cd.d2 < rq2;
+                        const uint32_t kb = cand_key(cd, Q) & bin_mask;
+                        bool take = ok && kb < prefix;
+                        const bool inb = ok && kb == prefix;
+                        const unsigned long long mb = ballot64(inb);
                         if (in_bin <= 64u) {
                             if (mb) {
                                 uint32_t base = 0;
@@ -2126,13 +2112,13 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                                 if (lane == leader) { base = L.sel_n; L.sel_n = base + (uint32_t)__popcll(mb); }
                                 base = lane_u(base, leader);
                                 if (inb) {
-                                    const uint32_t at = base + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-                                    if (at < 64u) { L.sel_d[at] = cd.d2; L.sel_i[at] = (uint32_t)s; }
+                                    const uint32_t at = base + lanes_below(mb);
+                                    if (at < 64u) { L.sel_d[at] = cd.d2; L.sel_i[at] = s; }
                                 }
                             }
                         } else {
                             // more than 64 photons share all 24 key bits: take the first `need` in scan order
-                            const uint32_t rank = tie_taken + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
+                            const uint32_t rank = tie_taken + lanes_below(mb);
                             if (inb && rank < need) { take = true; tmax = fmaxf(tmax, cd.d2); }
                             tie_taken += (uint32_t)__popcll(mb);
                         }
@@ -2159,7 +2145,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                                 accumulate5(ra.y, ra.z, ra.w, rb.x, __float_as_uint(rb.y), true);
                             } else
 #endif
-                                accumulate(G.pm.pa[si], G.pm.pb[si], true);
+                                accumulate(*(const float4 *)((const char *)G.pm.pa + si), *(const float4 *)((const char *)G.pm.pb + si), true);   // si: byte offset of the slot
                             tmax = md;
                         }
                     }
@@ -2182,7 +2168,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     } else {
                         n_reads += n_sub;
                         s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0;
-                        for_each([&](const Cand &cd, size_t) { accumulate(cd.pa, cd.pb, cd.ok); });
+                        for_each([&](const Cand &cd, uint32_t) { accumulate(cd.pa, cd.pb, cd.d2 < rq2); });
                     }
                 }
 #endif
