@@ -33,7 +33,9 @@
 #endif
 #define RT_LEAF_SUBS      (128 / RT_SUB_PHOTONS)     // sub-leaves per leaf of the walked tree (128 photon slots)
 #define RT_GATHER_WAVES   4      // waves per gather workgroup
+#ifndef RT_LEAFLIST_CAP
 #define RT_LEAFLIST_CAP   40     // leaf ids kept per query in LDS before the slow path (40 leaves = 5120 slots)
+#endif
 
 struct DevNodeXf { float itm[9]; float pos[3]; float tm[9]; float pad[3]; };
 
