@@ -193,7 +193,7 @@ typedef struct rt_stats {
     uint64_t launches_trace, launches_gather, launches_resolve;
     uint64_t gather_rounds;         /* (query, trial radius) pairs processed by the gather          */
     uint64_t gather_slow;           /* of those, how many overflowed the LDS leaf list               */
-    uint64_t gather_leaf_reads;     /* 32-slot sub-leaf reads, all passes                            */
+    uint64_t gather_leaf_reads;     /* photon slots read by the gather, all passes, in units of 32 slots (1 KiB) */
     /* ABI 2: the trace+shade time by kernel (ms_trace = ms_primary + ms_bounce).  Every ms_* field is a sum
      * of HIP-event intervals on the stream that ran the kernels.  With `streams` == 1 one chunk is in
      * flight at a time and the intervals are EXCLUSIVE kernel times; with more, a kernel shares the GPU

@@ -29,7 +29,7 @@
 #define RT_BVH_STACK      32     // per-lane traversal stack entries (LDS)
 #define RT_BLOCK          256    // threads per workgroup of the trace/shade kernels
 #ifndef RT_SUB_PHOTONS
-#define RT_SUB_PHOTONS    32     // photon slots per sub-leaf (16 or 32): a wavefront examines 64 / RT_SUB_PHOTONS sub-leaves per step
+#define RT_SUB_PHOTONS    16     // photon slots per sub-leaf (16 or 32): a wavefront examines 64 / RT_SUB_PHOTONS sub-leaves per step
 #endif
 #define RT_LEAF_SUBS      (128 / RT_SUB_PHOTONS)     // sub-leaves per leaf of the walked tree (128 photon slots)
 #define RT_GATHER_WAVES   4      // waves per gather workgroup

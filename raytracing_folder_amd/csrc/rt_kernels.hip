@@ -40,7 +40,7 @@
 #define RT_GATHER_GUESS 1.2f   // photons expected inside the first trial radius, in units of k (round 2, sub-leaves: 1.1: 42.0 ms, 1.15: 40.8, 1.2: 40.7, 1.3: 41.7, 1.45: 43.3)
 #endif
 #ifndef RT_GATHER_RING
-#define RT_GATHER_RING 144     // LDS entries for the photons around the predicted k-th distance (0: always re-read in pass 2)
+#define RT_GATHER_RING 128     // LDS entries for the photons around the predicted k-th distance (0: always re-read in pass 2)
 #endif
 #ifndef RT_GATHER_BAND_LO
 #define RT_GATHER_BAND_LO 0.92f   // the ring keeps the photons between BAND_LO and BAND_HI times the predicted k-th squared distance
@@ -1740,6 +1740,25 @@ __device__ __forceinline__ void scan_subleaves(const DevPhotonMap &pm, const uin
         ld(it, a, b, sl);
         f(make_cand(a, b, Q), sl);
     }
+#elif RT_GATHER_AHEAD == 2
+    // three register sets in rotation: two steps in flight while one is processed; reload indices are clamped (the last
+    // step may be fetched again) instead of branched over
+    float4 a0, b0, a1, b1, a2, b2;
+    uint32_t s0, s1, s2;
+    const uint32_t last = n_iter - 1;
+    ld(0u, a0, b0, s0);
+    ld(min(1u, last), a1, b1, s1);
+    uint32_t it = 0;
+    for (; it + 2 < n_iter; it += 3) {
+        ld(it + 2, a2, b2, s2);
+        f(make_cand(a0, b0, Q), s0);
+        ld(min(it + 3, last), a0, b0, s0);
+        f(make_cand(a1, b1, Q), s1);
+        ld(min(it + 4, last), a1, b1, s1);
+        f(make_cand(a2, b2, Q), s2);
+    }
+    if (it < n_iter) f(make_cand(a0, b0, Q), s0);
+    if (it + 1 < n_iter) f(make_cand(a1, b1, Q), s1);
 #else
     // two register sets used alternately, each refilled right after it was consumed; the reload index
     // is clamped instead of branched over (the last step may be fetched twice) so that neither set
@@ -2207,7 +2226,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
         atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * (unsigned long long)RT_SUB_PHOTONS);
         atomicAdd(&G.stats[ST_GATHER_ROUNDS], (unsigned long long)n_rounds);
         atomicAdd(&G.stats[ST_GATHER_SLOW], (unsigned long long)n_slow);
-        atomicAdd(&G.stats[ST_GATHER_LEAF_READS], (unsigned long long)n_reads);
+        atomicAdd(&G.stats[ST_GATHER_LEAF_READS], (unsigned long long)n_reads * RT_SUB_PHOTONS / 32ull);     // in units of 32 slots = 1 KiB
     }
     if (G.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&G.stats[ST_PHOTON_QUERIES], (unsigned long long)nq);
 }

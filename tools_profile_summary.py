@@ -70,7 +70,7 @@ if hbm:
     print({k: v.get("hbm_bytes_per_launch") for k, v in hbm.items()})
 
 sq = {}
-for passname in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_l2"):
+for passname in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_l2", "pmc_ta1", "pmc_ta2"):
     c = counters(passname)
     if not c:
         continue
