@@ -304,6 +304,23 @@ __device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN,
     return true;
 }
 
+// Scene tables (objects, node transforms, lights) are written before a launch and only read by it, and the loops over
+// them are wave-uniform: read through the constant address space such a table entry comes over the scalar data cache
+// into SGPRs (s_load, merged to x4/x8/x16) -- one short-latency read per wave instead of a 64-lane vector load of one
+// address, and no vector registers held for data every lane shares.  (With a lane-varying index the same code falls
+// back to a vector load.)
+template <class T> __device__ __forceinline__ T cld(const T *p) { return *(const __attribute__((address_space(4))) T *)(uintptr_t)p; }
+__device__ __forceinline__ V3 cld3(const float *p) { return mk(cld(p), cld(p + 1), cld(p + 2)); }
+struct M9 { float m[9]; };
+__device__ __forceinline__ rt_light cld_light(const rt_light *p)
+{
+    rt_light l;
+    l.type = cld(&p->type); l.size = cld(&p->size);
+    for (int i = 0; i < 3; i++) { l.intensity[i] = cld(p->intensity + i); l.position[i] = cld(p->position + i); l.direction[i] = cld(p->direction + i); }
+    return l;
+}
+__device__ __forceinline__ M9 cld9(const float *p) { M9 r; for (int i = 0; i < 9; i++) r.m[i] = cld(p + i); return r; }
+
 // ------------------------------------------------------------------------------------------------
 // TraceNode(rootNode, ray, hit), FIN/main.cpp:108-130, flattened: for every node that carries an
 // Object (in the recursion's visiting order) the ray is taken through ToNodeCoords of each
@@ -323,10 +340,11 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
     V3 uvw = mk(0.5f, 0.5f, 0.5f);
     // Node::ToNodeCoords (scene.h:502-508) of one level; the direction is the image of p+d minus the image of p
     auto to_node = [&](int node, V3 &lp, V3 &ldir) {
-        const DevNodeXf &X = S.nodes[node];
-        const V3 pos = ld3(X.pos);
-        const V3 rp = mmul(X.itm, lp - pos);
-        ldir = mmul(X.itm, (lp + ldir) - pos) - rp;
+        const DevNodeXf *X = S.nodes + node;
+        const V3 pos = cld3(X->pos);
+        const M9 itm = cld9(X->itm);
+        const V3 rp = mmul(itm.m, lp - pos);
+        ldir = mmul(itm.m, (lp + ldir) - pos) - rp;
         lp = rp;
     };
     // Every chain starts at the root (node 0) and siblings share their parent: the ray in the root's and
@@ -341,31 +359,33 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
     // bounds are inflated
     const V3 winv = mk(__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y), __builtin_amdgcn_rcpf(d0.z));
     for (int oi = 0; oi < S.n_objects; oi++) {
-        const DevObject &ob = S.objects[oi];
+        const DevObject *obp = S.objects + oi;
         // skip the object when no lane's ray can reach its bounds before that lane's closest hit so far
-        if (!__any(box_entry(ob.wlo, ob.whi, p0, winv, z) < 2.0e30f)) continue;
+        const float wlo[3] = {cld(obp->wlo), cld(obp->wlo + 1), cld(obp->wlo + 2)}, whi[3] = {cld(obp->whi), cld(obp->whi + 1), cld(obp->whi + 2)};
+        if (!__any(box_entry(wlo, whi, p0, winv, z) < 2.0e30f)) continue;
+        const int ob_type = cld(&obp->type), ob_chain_len = cld(&obp->chain_len);
         V3 lp = p0, ldir = d0;
         int c = 1;
-        if (ob.chain_len > 2) {
-            const int n1 = ob.chain[1];
+        if (ob_chain_len > 2) {
+            const int n1 = cld(&obp->chain[1]);
             if (n1 != cached1) { p1 = p0; d1 = d0; to_node(n1, p1, d1); cached1 = n1; }
             lp = p1; ldir = d1; c = 2;
         }
-        for (; c < ob.chain_len; c++) to_node(ob.chain[c], lp, ldir);
+        for (; c < ob_chain_len; c++) to_node(cld(&obp->chain[c]), lp, ldir);
         cnt.inst++;
         V3 hp, hN;
         int fr = 1;
         bool hit = false;
-        if (ob.type == RT_OBJ_SPHERE) hit = (MODEL == RT_SHADE_P3) ? sphere_hit_p3(lp, ldir, z, hp, hN) : sphere_hit(lp, ldir, z, hp, hN, fr);
-        else if (ob.type == RT_OBJ_PLANE) hit = plane_hit(MODEL, lp, ldir, z, hp, hN, fr);
-        else if (ob.type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes[ob.mesh], lp, ldir, z, hp, hN, fr, stack, cnt, (TEX && S.use_uvw) ? &uvw : nullptr);
+        if (ob_type == RT_OBJ_SPHERE) hit = (MODEL == RT_SHADE_P3) ? sphere_hit_p3(lp, ldir, z, hp, hN) : sphere_hit(lp, ldir, z, hp, hN, fr);
+        else if (ob_type == RT_OBJ_PLANE) hit = plane_hit(MODEL, lp, ldir, z, hp, hN, fr);
+        else if (ob_type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes[cld(&obp->mesh)], lp, ldir, z, hp, hN, fr, stack, cnt, (TEX && S.use_uvw) ? &uvw : nullptr);
         if (hit) {
             if (ANY) return true;
             best = oi; bp = hp; bN = hN; bfront = fr;
             if (TEX && S.use_uvw) {
-                if (ob.type == RT_OBJ_SPHERE)               // objects.h:49-51, atan2/asin in double
+                if (ob_type == RT_OBJ_SPHERE)               // objects.h:49-51, atan2/asin in double
                     uvw = mk((float)(0.5 - atan2((double)hp.x, (double)hp.y) / (2 * M_PI)), (float)(0.5 + asin((double)hp.z) / M_PI), 0);
-                else if (ob.type == RT_OBJ_PLANE) uvw = mk((hp.x + 1) / 2, (hp.y + 1) / 2, 0);    // objects.h:103
+                else if (ob_type == RT_OBJ_PLANE) uvw = mk((hp.x + 1) / 2, (hp.y + 1) / 2, 0);    // objects.h:103
             }
         }
     }
@@ -717,7 +737,7 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
     const float ior = m.ior;
     const float coef = S.n_lights == 0 ? 1.0f : 1.0f / S.n_lights;      // :545
     for (int li = 0; li < S.n_lights; li++) {
-        const rt_light &light = S.lights[li];
+        const rt_light light = cld_light(S.lights + li);
         // the reference still calls Illuminate (its shadow rays) for a back-face hit but uses the
         // result only for front hits (:551-553): nothing to add, nothing traced
         if (!h.front) continue;
@@ -787,7 +807,7 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
     uint32_t spec = spec_in;
     int n_caustic = 0;
     for (int i = 0; i < S.n_lights; i++) {
-        const rt_light &l = S.lights[i];
+        const rt_light l = cld_light(S.lights + i);
         const V3 Il = illuminate<MODEL>(S, P, l, i, Pp, rc, stack, cnt);
         if (l.type == RT_LIGHT_AMBIENT) ambient = ambient + Il * Kd;                     // :510
         else {
@@ -890,7 +910,7 @@ __device__ void shade_p3(const DevScene &S, const rt_params &P, const Hit &h, V3
     material_colors<TEX>(S, h, m, Kd, Ks);
     V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
     for (int i = 0; i < S.n_lights; i++) {
-        const rt_light &l = S.lights[i];
+        const rt_light l = cld_light(S.lights + i);
         const V3 Il = illuminate<RT_SHADE_P3>(S, P, l, i, Pp, rc, stack, cnt);
         if (l.type == RT_LIGHT_AMBIENT) ambient = ambient + Il * Kd;
         else {
@@ -925,7 +945,7 @@ __device__ void shade_p6(const DevScene &S, const rt_params &P, const Hit &h, V3
     const V3 reflection = ld3(m.reflection), refraction = ld3(m.refraction);
     V3 ambient = mk(0, 0, 0), diffuse = mk(0, 0, 0);
     for (int i = 0; i < S.n_lights; i++) {
-        const rt_light &l = S.lights[i];
+        const rt_light l = cld_light(S.lights + i);
         const V3 Il = illuminate<RT_SHADE_P6>(S, P, l, i, Pp, rc, stack, cnt);
         if (l.type == RT_LIGHT_AMBIENT) ambient = ambient + Il * Kd;                          // :199
         else {
