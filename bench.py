@@ -33,7 +33,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0        # aggregate L2 rate of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
-VALU_PEAK_GINST = 1024 * 2.4 / 2      # wave64 VALU instructions per ns: 256 CUs x 4 SIMD-32 at 2.4 GHz, 2 cycles each
+VALU_PEAK_GINST = 1024 * 2.4 / 4      # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs at 2.4 GHz, 4 cycles each (16 lanes per cycle:
+                                      # the 157.3 TF f32 vector peak is v_pk_fma_f32 at that rate; SQ_ACTIVE_INST_VALU counts one quad-cycle
+                                      # per VALU instruction)
 PARITY_NOTE = ("geometry half of RenderPixel pinned to the reference's own z images and compiled headers; "
                "MtlBlinn::Shade, GenLight::Shadow, TraceNode and RenderPixel's loop are restated from main.cpp "
                "(unbuildable here: needs GL/glut.h): Shade parity UNPINNED, GPU == oracle only")
@@ -123,7 +125,9 @@ def profile_figures(default_workload):
                 if key == "hbm":
                     out["hbm"][name] = float(v["hbm_bytes_per_launch"])
                 elif "SQ_INSTS_VALU" in v and v.get("avg_launch_us"):
-                    out["valu"][name] = float(v["SQ_INSTS_VALU"]) / (float(v["avg_launch_us"]) * 1e3) / VALU_PEAK_GINST
+                    # clipped at 1: the count can come out a few percent above it (the peak assumes 2.4 GHz and 4 cycles for
+                    # every VALU instruction) -- the vector pipe is then simply full
+                    out["valu"][name] = min(1.0, float(v["SQ_INSTS_VALU"]) / (float(v["avg_launch_us"]) * 1e3) / VALU_PEAK_GINST)
             out[key + "_source"] = os.path.basename(files[-1])
         except Exception:
             pass
@@ -249,7 +253,7 @@ def main():
                 # transforms, 64-B ray-queue records (written once, read once), 17 B/sample + 8 B/pixel in the resolve
                 "k_gather": {"ms": P["ms_gather"], "launches": P["launches_gather"],
                              "alg": P["photon_queries"] * 48.0 + P["photons_visited"] * 24.0,
-                             "l2": P["photon_queries"] * 48.0 + P["gather_leaf_reads"] * 32.0 * 32.0},      # 32-slot sub-leaf reads of 32-B slots
+                             "l2": P["photon_queries"] * 48.0 + P["gather_leaf_reads"] * 32.0 * 32.0},      # slots read, counted in units of 32 slots of 32 B
                 # the tracer: k_wavefront (whole ray tree, LDS ray stacks) + the k_bounce launches behind it (rays that did not
                 # fit the LDS stacks: normally none); with RT_TRACER=levels: k_primary + one k_bounce per level
                 "k_wavefront+k_bounce": {"ms": P["ms_primary"] + P["ms_bounce"], "launches": P["launches_primary"] + P["launches_bounce"],
