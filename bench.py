@@ -203,10 +203,12 @@ def main():
         R.step()
     barrier()
     t0 = time.perf_counter()
-    stats = []
+    stats, step_ms = [], []
     for _ in range(a.steps):
+        t_step = time.perf_counter()
         st, frame = R.step()
         stats.append(st.as_dict())
+        step_ms.append(round((time.perf_counter() - t_step) * 1e3, 2))      # this rank's steps as it saw them (R.step() returns with its statistics)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -322,6 +324,7 @@ def main():
                                    f"k=400 r=1, bounce 4",
                        "tiles": "32x8 interleaved, tile t -> rank t mod N", "exchange": "one all_gather of 8 B/pixel per frame"},
             "frame_ms": round(dt / a.steps * 1e3, 2),
+            "step_ms_rank0": step_ms,
             "gather_ms": round(gather_ms, 3),
             "parity_note": PARITY_NOTE,
             **({"rehearsal": "all ranks on device 0, gloo gather -- not a scaling measurement"} if rehearsal else {}),
