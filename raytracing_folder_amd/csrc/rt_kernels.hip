@@ -1861,6 +1861,8 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
         float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
         if (have) { a = G.qa[qi]; b = G.qb[qi]; c = G.qc[qi]; }
         bool pending = have;
+        float f_pr = 0, f_pg = 0, f_pb = 0, f_dx = 0, f_dy = 0, f_dz = 0, f_area = -1.0f;     // a finished query's sums, in its lane
+        bool finish = false;
         // first trial radius from the density grid: about RT_GATHER_GUESS * k photons expected inside (count ~ r^2
         // on a surface through a cell of side h: c photons per h^2)
         float r2cur = r2;
@@ -1936,8 +1938,8 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 Q.px = lane_f(a.x, q); Q.py = lane_f(a.y, q); Q.pz = lane_f(a.z, q);
                 Q.nx = lane_f(a.w, q); Q.ny = lane_f(b.x, q); Q.nz = lane_f(b.y, q);
                 Q.rq2 = lane_f(r2cur, q);
-                Q.kscale = 16777000.0f / Q.rq2;            // 24-bit fixed-point distance key (see make_cand)
-                const float rq2 = Q.rq2, nx = Q.nx, ny = Q.ny, nz = Q.nz;
+                Q.kscale = 16777000.0f / Q.rq2;            // 24-bit fixed-point distance key (see cand_key)
+                const float rq2 = Q.rq2;
                 const uint32_t qnl = lane_u(nl, q);
                 const bool final_round = rq2 >= r2;
                 const bool slow = qnl > RT_LEAFLIST_CAP;   // the LDS list overflowed
@@ -2047,6 +2049,11 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 });
 #endif
                 visited += n_sub;
+#ifdef RT_EXP_PASS1ONLY         /* cost attribution build: nothing after pass 1; results are garbage */
+                if (G.mode == 1 && s_pr == 12345.678f && lane == 0) G.out_irr[0] = s_pr + (float)M + (float)n_ring;
+                if (lane == q) pending = false;
+                continue;
+#endif
                 if (!final_round && M <= K) {
                     // not enough inside the trial radius: grow it (count ~ r^2 on a surface) and retry
                     float grow = 1.5f * (float)K / (float)(M > 0 ? M : 1u);
@@ -2211,33 +2218,44 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     }
                 }
 #endif
-                float irr_r = wave_sum(s_pr), irr_g = wave_sum(s_pg), irr_b = wave_sum(s_pb);
-                float dx = wave_sum(s_dx), dy = wave_sum(s_dy), dz = wave_sum(s_dz);
-                if (M > 0) {
-                    const float area = (float)M_PI * area_d2;              // :326
+                // the query is done: its six sums and r_k^2 go to ITS lane; what follows from them (area, normalisation, the
+                // weighted add into the sample) is the same scalar arithmetic for every query, so it is done for all the
+                // queries a round finished at once, one per lane, after the loop -- not 64 lanes wide per query
+                {
+                    const float t_pr = wave_sum(s_pr), t_pg = wave_sum(s_pg), t_pb = wave_sum(s_pb);
+                    const float t_dx = wave_sum(s_dx), t_dy = wave_sum(s_dy), t_dz = wave_sum(s_dz);
+                    if (lane == q) {
+                        f_pr = t_pr; f_pg = t_pg; f_pb = t_pb; f_dx = t_dx; f_dy = t_dy; f_dz = t_dz;
+                        f_area = M > 0 ? area_d2 : -1.0f;      // dist2[0] >= 0; negative: no photon at all
+                        finish = true;
+                        pending = false;
+                    }
+                }
+            }
+            if (finish) {
+                float irr_r = f_pr, irr_g = f_pg, irr_b = f_pb, dx = f_dx, dy = f_dy, dz = f_dz;
+                if (f_area >= 0.0f) {
+                    const float area = (float)M_PI * f_area;               // :326
                     if (area > 0) { const float inv = 1.0f / area; irr_r *= inv; irr_g *= inv; irr_b *= inv; }
                     const float l = sqrtf(dx * dx + dy * dy + dz * dz);    // direction.Normalize() :334
                     dx /= l; dy /= l; dz /= l;
                 }
                 if (G.mode == 1) {
-                    if (lane == 0) {
-                        const size_t qq = (size_t)qbase + (size_t)q;
-                        G.out_irr[3 * qq] = irr_r; G.out_irr[3 * qq + 1] = irr_g; G.out_irr[3 * qq + 2] = irr_b;
-                        G.out_dir[3 * qq] = dx; G.out_dir[3 * qq + 1] = dy; G.out_dir[3 * qq + 2] = dz;
-                    }
+                    const size_t qq = (size_t)qi;
+                    G.out_irr[3 * qq] = irr_r; G.out_irr[3 * qq + 1] = irr_g; G.out_irr[3 * qq + 2] = irr_b;
+                    G.out_dir[3 * qq] = dx; G.out_dir[3 * qq + 1] = dy; G.out_dir[3 * qq + 2] = dz;
                 } else {
                     // idr_Color += kd * photonrad * max(0, N.(-dir)) (FIN/main.cpp:701-704), times the ray weight
-                    const float wr = lane_f(b.z, q), wg = lane_f(b.w, q), wb = lane_f(c.x, q);
-                    const uint32_t slot = __float_as_uint(lane_f(c.y, q));
+                    const float nx = a.w, ny = b.x, nz = b.y, wr = b.z, wg = b.w, wb = c.x;
+                    const uint32_t slot = __float_as_uint(c.y);
                     float theta = nx * (-dx) + ny * (-dy) + nz * (-dz);
                     theta = theta > 0.0f ? theta : 0.0f;
-                    if (lane < 3) {
-                        const float w = lane == 0 ? wr : (lane == 1 ? wg : wb);
-                        const float ir = lane == 0 ? irr_r : (lane == 1 ? irr_g : irr_b);
-                        atomicAdd(G.sample_rgb + 3 * (size_t)slot + lane, (w * ir) * theta);
-                    }
+                    float *dst = G.sample_rgb + 3 * (size_t)slot;
+                    atomicAdd(dst, (wr * irr_r) * theta);
+                    atomicAdd(dst + 1, (wg * irr_g) * theta);
+                    atomicAdd(dst + 2, (wb * irr_b) * theta);
                 }
-                if (lane == q) pending = false;
+                finish = false;
             }
             wave_sync();
         }
