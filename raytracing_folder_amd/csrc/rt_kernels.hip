@@ -244,12 +244,34 @@ __device__ __forceinline__ bool tri_hit_p13(const DevTri &T, V3 rp, V3 rd, float
     return true;
 }
 
+// Scene tables (objects, node transforms, lights) are written before a launch and only read by it, and the loops over
+// them are wave-uniform: read through the constant address space such a table entry comes over the scalar data cache
+// into SGPRs (s_load, merged to x4/x8/x16) -- one short-latency read per wave instead of a 64-lane vector load of one
+// address, and no vector registers held for data every lane shares.  (With a lane-varying index the same code falls
+// back to a vector load.)
+template <class T> __device__ __forceinline__ T cld(const T *p) { return *(const __attribute__((address_space(4))) T *)(uintptr_t)p; }
+__device__ __forceinline__ V3 cld3(const float *p) { return mk(cld(p), cld(p + 1), cld(p + 2)); }
+struct M9 { float m[9]; };
+__device__ __forceinline__ rt_light cld_light(const rt_light *p)
+{
+    rt_light l;
+    l.type = cld(&p->type); l.size = cld(&p->size);
+    for (int i = 0; i < 3; i++) { l.intensity[i] = cld(p->intensity + i); l.position[i] = cld(p->position + i); l.direction[i] = cld(p->direction + i); }
+    return l;
+}
+__device__ __forceinline__ M9 cld9(const float *p) { M9 r; for (int i = 0; i < 9; i++) r.m[i] = cld(p + i); return r; }
+
 // TriObj::IntersectRay -> TraceBVHNode (FIN/include/objects.h:127-133, 271-302) as an iterative,
 // near-first traversal with a per-lane stack in LDS.  ANY: stop at the first accepted triangle.
 template <bool ANY, int MODEL>
-__device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN, int &front,
+__device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN, int &front,
                          uint32_t *stack, Counters &cnt, V3 *uvw = nullptr)
 {
+    // the mesh record is the same for every lane: over the scalar cache (see cld), so that the array bases live in SGPRs
+    DevMesh M;
+    M.nodes = cld(&Mp->nodes); M.tris = cld(&Mp->tris); M.tri_face = cld(&Mp->tri_face); M.nrm = cld(&Mp->nrm); M.tex = cld(&Mp->tex);
+    for (int i = 0; i < 6; i++) M.root_box[i] = cld(Mp->root_box + i);
+    M.root_ref = cld(&Mp->root_ref);
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (box_entry(M.root_box, M.root_box + 3, o, inv, z) > 2.0e30f) return false;
     uint32_t cur = M.root_ref;
@@ -303,23 +325,6 @@ __device__ bool mesh_hit(const DevMesh &M, V3 o, V3 d, float &z, V3 &hp, V3 &hN,
     }
     return true;
 }
-
-// Scene tables (objects, node transforms, lights) are written before a launch and only read by it, and the loops over
-// them are wave-uniform: read through the constant address space such a table entry comes over the scalar data cache
-// into SGPRs (s_load, merged to x4/x8/x16) -- one short-latency read per wave instead of a 64-lane vector load of one
-// address, and no vector registers held for data every lane shares.  (With a lane-varying index the same code falls
-// back to a vector load.)
-template <class T> __device__ __forceinline__ T cld(const T *p) { return *(const __attribute__((address_space(4))) T *)(uintptr_t)p; }
-__device__ __forceinline__ V3 cld3(const float *p) { return mk(cld(p), cld(p + 1), cld(p + 2)); }
-struct M9 { float m[9]; };
-__device__ __forceinline__ rt_light cld_light(const rt_light *p)
-{
-    rt_light l;
-    l.type = cld(&p->type); l.size = cld(&p->size);
-    for (int i = 0; i < 3; i++) { l.intensity[i] = cld(p->intensity + i); l.position[i] = cld(p->position + i); l.direction[i] = cld(p->direction + i); }
-    return l;
-}
-__device__ __forceinline__ M9 cld9(const float *p) { M9 r; for (int i = 0; i < 9; i++) r.m[i] = cld(p + i); return r; }
 
 // ------------------------------------------------------------------------------------------------
 // TraceNode(rootNode, ray, hit), FIN/main.cpp:108-130, flattened: for every node that carries an
@@ -378,7 +383,7 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
         bool hit = false;
         if (ob_type == RT_OBJ_SPHERE) hit = (MODEL == RT_SHADE_P3) ? sphere_hit_p3(lp, ldir, z, hp, hN) : sphere_hit(lp, ldir, z, hp, hN, fr);
         else if (ob_type == RT_OBJ_PLANE) hit = plane_hit(MODEL, lp, ldir, z, hp, hN, fr);
-        else if (ob_type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes[cld(&obp->mesh)], lp, ldir, z, hp, hN, fr, stack, cnt, (TEX && S.use_uvw) ? &uvw : nullptr);
+        else if (ob_type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes + cld(&obp->mesh), lp, ldir, z, hp, hN, fr, stack, cnt, (TEX && S.use_uvw) ? &uvw : nullptr);
         if (hit) {
             if (ANY) return true;
             best = oi; bp = hp; bN = hN; bfront = fr;
