@@ -2067,7 +2067,11 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     continue;
                 }
                 float area_d2 = rq2;                       // dist2[0]; only reached with rq2 == r2 when M <= K
+#ifdef RT_EXP_NOSELECT          /* cost attribution build: no bin search, ring, selection or fallback pass; results are garbage */
+                if (false) {
+#else
                 if (M > K) {
+#endif
                     // ---- locate the k-th smallest: refine 8 bits of the key per level --------------
                     uint32_t need = K;                     // rank (1-based) inside the current range
                     uint32_t prefix = 0;                   // key bits fixed so far
@@ -2203,7 +2207,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     area_d2 = wave_max0(tmax);                        // np.dist2[0] = largest kept distance
                     pred_rk2 = area_d2;
                 }
-#if RT_GATHER_RING
+#if RT_GATHER_RING && !defined(RT_EXP_NOSELECT)
                 else if (M > 0) {
                     // at most k inside the full radius: all of them count.  Pass 1 summed those below t_lo and, in the
                     // final round, parked every other one in the ring; if that overflowed, sum them with one more pass
