@@ -1702,18 +1702,17 @@ struct GatherLds {
 #endif
 };
 
-// Color24 -> Color (cyColor.h): byte / 255.0f, correctly rounded, without the ~10-instruction IEEE
-// division and without a table: q = c * RN(1/255) is off by at most one ulp, one Newton step
-// (e = c - q*255 exactly by fma, q + e/255) lands on the correctly rounded quotient for every byte
-// value (all 256 checked against the division on the host: tests/test_host.py, and on the device:
-// test_gpu_parity.py::test_irradiance_single_photon_colour_bytes).
+// Color24 -> Color (cyColor.h): byte / 255.0f, correctly rounded, without the ~10-instruction IEEE division and without
+// a table: 1/255 as a two-term constant, r_hi = RN(1/255) and r_lo = RN(1/255 - r_hi); fma(c, r_hi, RN(c * r_lo)) adds the
+// exact product c * r_hi to a correction that is itself good to 2^-48 of the result, and lands on the correctly rounded
+// quotient for every byte value (all 256 checked exactly, in rational arithmetic: tests/test_host.py; on the device:
+// test_gpu_parity.py::test_irradiance_single_photon_colour_bytes).  Two instructions; c * RN(1/255) alone is wrong for
+// 121 of the 256 bytes, and the Newton form used before took three.
 __device__ __forceinline__ float byte_over_255(uint32_t c)
 {
-    const float r = 1.0f / 255.0f;
+    const float r_hi = 0x1.010102p-8f, r_lo = -0x1.fdfdfep-33f;
     const float x = (float)c;
-    const float q = x * r;
-    const float e = __fmaf_rn(-q, 255.0f, x);
-    return __fmaf_rn(e, r, q);
+    return __fmaf_rn(x, r_hi, x * r_lo);
 }
 
 // one lane's photon of one sub-leaf against one query (the test of LocatePhotons :383-392).  d2 is the squared distance

@@ -144,16 +144,33 @@ def test_photon_dat_round_trip_and_reference_dump(gold, tmp_path):
     assert hashlib.sha256(bal[1:].tobytes()).hexdigest() == str(g["balanced_sha256"])
 
 
-def test_byte_over_255_newton_step_is_the_correctly_rounded_quotient():
-    """the device forms Color24 -> Color (byte / 255.0f) as q = c*RN(1/255), e = fma(-q, 255, c),
-    q + e*RN(1/255): emulated here with exact products in float64 and one rounding per fma"""
-    c = np.arange(256, dtype=np.float32)
-    r = np.float32(1) / np.float32(255)
-    q = (c * r).astype(np.float64)
-    e = np.float32(c.astype(np.float64) - q * 255.0)                 # exact, then rounded once
-    q2 = np.float32(q + e.astype(np.float64) * np.float64(r))
-    assert (q2 == c / np.float32(255)).all()
-    assert ((c * r) != c / np.float32(255)).sum() > 100              # the plain product is NOT enough
+def test_byte_over_255_two_term_constant_gives_the_correctly_rounded_quotient():
+    """the device forms Color24 -> Color (byte / 255.0f) as fma(c, r_hi, RN(c * r_lo)) with r_hi = RN(1/255),
+    r_lo = RN(1/255 - r_hi): checked here for all 256 bytes in exact rational arithmetic (one rounding per operation)"""
+    from fractions import Fraction as Fr
+    f = np.float32
+    r_hi, r_lo = f(float.fromhex("0x1.010102p-8")), f(float.fromhex("-0x1.fdfdfep-33"))
+    assert r_hi == f(1) / f(255) and r_lo == f(1.0 / 255.0 - float(r_hi))
+
+    def rn32(F):                                           # correctly rounded float32 of a Fraction, no ties allowed
+        if F == 0:
+            return f(0)
+        sign = -1 if F < 0 else 1
+        F = abs(F)
+        g = f(float(F))
+        cands = [np.nextafter(g, f(-np.inf)), g, np.nextafter(g, f(np.inf))]
+        d = sorted((abs(Fr(float(c)) - F), i) for i, c in enumerate(cands))
+        assert d[0][0] != d[1][0]
+        return f(sign * float(cands[d[0][1]]))
+
+    wrong_plain = 0
+    for c in range(256):
+        x = Fr(c)
+        t = rn32(x * Fr(float(r_lo)))
+        q = rn32(x * Fr(float(r_hi)) + Fr(float(t)))      # the fma: exact product + t, rounded once
+        assert q == f(c) / f(255) == rn32(Fr(c, 255))
+        wrong_plain += int(f(c) * r_hi != f(c) / f(255))
+    assert wrong_plain > 100                               # the plain product is NOT enough
 
 
 def test_xml_errors_are_reported(tmp_path):
