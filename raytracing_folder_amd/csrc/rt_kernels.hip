@@ -1664,6 +1664,41 @@ __device__ __forceinline__ float wave_sum(float x) { return __int_as_float(__bui
 __device__ __forceinline__ uint32_t wave_sum_u(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add_u(x), 63); }
 __device__ __forceinline__ float wave_max0(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan_max0(x)), 63)); }
 
+// Six wave totals at once.  v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / odd-even rows of TWO
+// registers, so one swap + one add folds two values at a time: after the 32-lane and the 16-lane fold four values share
+// one register (a row of 16 lanes each), and the last four steps (row_shr 8, 4, 2, 1) run on two registers instead of
+// six: 25 vector instructions instead of 48 for six separate scans.  Fixed order => deterministic.
+__device__ __forceinline__ void fold32(float a, float b, float &ab)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    ab = __uint_as_float(r[0]) + __uint_as_float(r[1]);          // lanes 0-31: a folded, lanes 32-63: b folded
+}
+__device__ __forceinline__ void fold16(float x, float y, float &xy)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    xy = __uint_as_float(r[0]) + __uint_as_float(r[1]);          // rows 0..3: x.lo, y.lo, x.hi, y.hi folded to 16 lanes
+}
+__device__ __forceinline__ float row_total(float x)               // lane 15 of every row: the row's sum
+{
+    x += dpp_f<DPP_ROW_SHR(8), 0xF>(0.0f, x); x += dpp_f<DPP_ROW_SHR(4), 0xF>(0.0f, x);
+    x += dpp_f<DPP_ROW_SHR(2), 0xF>(0.0f, x); x += dpp_f<DPP_ROW_SHR(1), 0xF>(0.0f, x);
+    return x;
+}
+__device__ __forceinline__ void wave_sum6(float v0, float v1, float v2, float v3, float v4, float v5, float out[6])
+{
+    float s01, s23, s45, t0123, t45;
+    fold32(v0, v1, s01); fold32(v2, v3, s23); fold32(v4, v5, s45);
+    fold16(s01, s23, t0123);          // rows: v0, v2, v1, v3
+    fold16(s45, s45, t45);            // rows: v4, v4, v5, v5
+    t0123 = row_total(t0123); t45 = row_total(t45);
+    out[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t0123), 15));
+    out[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t0123), 31));
+    out[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t0123), 47));
+    out[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t0123), 63));
+    out[4] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t45), 15));
+    out[5] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t45), 47));
+}
+
 // value of lane l (wave-uniform l) as a scalar: v_readlane, no LDS traffic, result lives in an SGPR
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ uint32_t lane_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -2230,10 +2265,10 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 // weighted add into the sample) is the same scalar arithmetic for every query, so it is done for all the
                 // queries a round finished at once, one per lane, after the loop -- not 64 lanes wide per query
                 {
-                    const float t_pr = wave_sum(s_pr), t_pg = wave_sum(s_pg), t_pb = wave_sum(s_pb);
-                    const float t_dx = wave_sum(s_dx), t_dy = wave_sum(s_dy), t_dz = wave_sum(s_dz);
+                    float t[6];
+                    wave_sum6(s_pr, s_pg, s_pb, s_dx, s_dy, s_dz, t);
                     if (lane == q) {
-                        f_pr = t_pr; f_pg = t_pg; f_pb = t_pb; f_dx = t_dx; f_dy = t_dy; f_dz = t_dz;
+                        f_pr = t[0]; f_pg = t[1]; f_pb = t[2]; f_dx = t[3]; f_dy = t[4]; f_dz = t[5];
                         f_area = M > 0 ? area_d2 : -1.0f;      // dist2[0] >= 0; negative: no photon at all
                         finish = true;
                         pending = false;
