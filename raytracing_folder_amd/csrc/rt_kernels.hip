@@ -2184,6 +2184,10 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         }
                     }
 #endif
+#ifdef RT_EXP_COUNT_FALLBACK    /* tuning build: ST_GATHER_SLOW counts fallbacks by ring overflow, ST_GATHER_ROUNDS the other fallbacks */
+                    n_rounds--;
+                    if (!from_ring) { if (n_ring > (uint32_t)RT_GATHER_RING) n_slow++; else n_rounds++; }
+#endif
                     if (!from_ring) {
                     n_reads += n_sub;
                     // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
