@@ -1930,7 +1930,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     if (n_leaves == 1) list_leaf(0u);
                     else {
                         uint32_t node = 1, pd = 0;              // current internal node and its pair-depth (tree depth = 2 * pd)
-                        unsigned long long todo_mask = 0;       // nibble pd: grandchildren of the path's node at pair-depth pd still to visit
+                        uint32_t todo_mask = 0;                 // nibble pd: grandchildren of the path's node at pair-depth pd still to visit (at most 65536 leaves: 8 nibbles)
                         for (;;) {
                             if (4u * node < 2u * n_leaves && 2u * node < n_leaves) {
                                 // grandchildren exist (they are internal nodes, or the leaves themselves)
@@ -1942,7 +1942,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                                     for (int i = 0; i < 4; i++) if ((m4 >> i) & 1u) list_leaf(4u * node + (uint32_t)i - n_leaves);
                                 } else if (m4) {
                                     const uint32_t i = (uint32_t)__ffs((int)m4) - 1u;
-                                    todo_mask |= (unsigned long long)(m4 & ~(1u << i)) << (4u * pd);
+                                    todo_mask |= (m4 & ~(1u << i)) << (4u * pd);
                                     node = 4u * node + i; pd++;
                                     continue;
                                 }
@@ -1953,11 +1953,11 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                                 if (box_dist2(cb + 2, a.x, a.y, a.z) < r2cur) list_leaf(2u * node + 1u - n_leaves);
                             }
                             if (!todo_mask) break;
-                            const uint32_t bit = 63u - (uint32_t)__clzll((long long)todo_mask);     // deepest pair-depth with work left
+                            const uint32_t bit = 31u - (uint32_t)__clz((int)todo_mask);            // deepest pair-depth with work left
                             const uint32_t d = bit >> 2;
-                            const uint32_t nib = (uint32_t)(todo_mask >> (4u * d)) & 15u;
+                            const uint32_t nib = (todo_mask >> (4u * d)) & 15u;
                             const uint32_t i = (uint32_t)__ffs((int)nib) - 1u;                    // its leftmost grandchild not yet visited
-                            todo_mask &= ~(1ull << (4u * d + i));
+                            todo_mask &= ~(1u << (4u * d + i));
                             node = ((node >> (2u * (pd - d))) << 2) + i;                          // that ancestor's grandchild i
                             pd = d + 1u;
                         }
