@@ -26,6 +26,8 @@ void rtk_launch_primary(hipStream_t, const DevScene &, const DevWork &, const rt
 void rtk_launch_bounce(hipStream_t, const DevScene &, const DevWork &, const rt_params &, const DevRayQueue &,
                        const DevRayQueue &, uint32_t *, int, int);
 void rtk_launch_trace(hipStream_t, const DevScene &, int, const float *, long long, uint8_t *, float *, float *, float *, int32_t *, uint8_t *);
+bool rtk_launch_wavefront_queue(hipStream_t, const DevScene &, const DevWork &, const rt_params &, const DevRayQueue &, const uint32_t *,
+                                const DevRayQueue &, uint32_t *);
 void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const float4 *, const float4 *, const uint32_t *,
                        uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint32_t *);
 void rtk_launch_resolve(hipStream_t, const DevScene &, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
@@ -1109,7 +1111,11 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
     // P6: a side ray is spawned when its refraction ray ARRIVES, one queue level later than a sibling
     // would be, so a path can take up to two levels per bounce
     const int max_level = P.shade_model == RT_SHADE_P6 ? 2 * P.bounce : P.bounce;
-    for (int level = 1; level <= max_level && level < 15; level++)
+    // k_wavefront's overflow (level-1 queue) first goes through a second k_wavefront pass; what overflows again, and the
+    // models without that kernel, take one launch per level
+    int first_level = 1;
+    if (max_level >= 2 && rtk_launch_wavefront_queue(st, D->scene, W, P, W.rq[1], W.counts + 1, W.rq[0], W.counts + 2)) first_level = 2;
+    for (int level = first_level; level <= max_level && level < 15; level++)
         rtk_launch_bounce(st, D->scene, W, P, W.rq[level & 1], W.rq[(level + 1) & 1], W.counts + level + 1, level, max_blocks);
     if ((s = mark(1))) return s;
     if (D->scene.pm.n_leaves) {

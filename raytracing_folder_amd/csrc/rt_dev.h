@@ -189,7 +189,8 @@ struct DevWork {
 #define CNT_PRIMARY_NEXT 25    // work counter of k_wavefront: batches of 256 primary samples handed out so far
 #define CNT_CAUSTICQ 26        // caustic-map query count
 #define CNT_GATHER_NEXT2 27    // the eight work counters of the caustic gather
-#define CNT_RESET   35         // counters [0, CNT_RESET) are cleared before every pass
+#define CNT_WF2_NEXT 35        // work counter of k_wavefront's second pass (source: the overflow queue of the first)
+#define CNT_RESET   36         // counters [0, CNT_RESET) are cleared before every pass
 #define CNT_PIXLIST 46         // survives the passes of a chunk
 #define CNT_TOTAL   48
 

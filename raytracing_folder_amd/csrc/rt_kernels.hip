@@ -1152,6 +1152,8 @@ struct PrimaryArgs {
     int j0, ns, max_sample, mode;
     const float *rays;           // mode 2
     FastDiv div_ns;
+    DevRayQueue qsrc;            // mode 3 (k_wavefront only): the work is a ray queue (count in *qsrc_count), not primary samples
+    const uint32_t *qsrc_count;
 };
 
 // Register budget: the texture-free instantiations are held to 168 VGPRs (3 waves/SIMD; a few values
@@ -1307,9 +1309,13 @@ __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES, RT_WF_WAVES))) __global__ __laun
     Counters cnt = {0, 0, 0, 0};
     uint32_t nprim = 0, nrefl = 0, nrefr = 0;
     const uint32_t npix = (A.mode == 1) ? C.W.counts[CNT_PIXLIST] : A.npix;
-    const unsigned long long total = (unsigned long long)npix * (unsigned long long)A.ns;
+    // mode 3: the rays that did not fit the LDS stacks of the pass before (they sit in a global queue) are the work items;
+    // their descendants live on this pass's LDS stacks like everybody else's
+    const unsigned long long total = A.mode == 3 ? (unsigned long long)min(*A.qsrc_count, A.qsrc.cap)
+                                                 : (unsigned long long)npix * (unsigned long long)A.ns;
     const unsigned long long n_batches = (total + RT_BLOCK - 1) / RT_BLOCK;
-    const bool h_table = A.mode != 2 && A.ns <= RT_BLOCK;
+    const bool h_table = A.mode < 2 && A.ns <= RT_BLOCK;
+    uint32_t *next_batch = C.W.counts + (A.mode == 3 ? CNT_WF2_NEXT : CNT_PRIMARY_NEXT);
     if (h_table && (int)threadIdx.x < A.ns) { s_h2[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 2); s_h3[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 3); }
     if (threadIdx.x == 0) s_count = 0;
     C.lds_a = s_qa; C.lds_b = s_qb; C.lds_c = s_qc; C.lds_d = s_qd; C.lds_count = &s_count; C.lds_cap = RT_WF_STACK;
@@ -1348,12 +1354,28 @@ __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES, RT_WF_WAVES))) __global__ __laun
             __syncthreads();                              // all pops read before anything is pushed over them
             if (threadIdx.x == 0) s_count = waiting - n;
         } else {
-            if (threadIdx.x == 0) { s_batch = atomicAdd(C.W.counts + CNT_PRIMARY_NEXT, 1u); if (s_count > RT_WF_STACK) s_count = RT_WF_STACK; }
+            if (threadIdx.x == 0) { s_batch = atomicAdd(next_batch, 1u); if (s_count > RT_WF_STACK) s_count = RT_WF_STACK; }
             __syncthreads();
             const unsigned long long batch = s_batch;
             if (batch >= n_batches) { more_primaries = false; continue; }
-            active = primary_setup(C, A, batch * RT_BLOCK + threadIdx.x, total, h_table, s_h2, s_h3, in);
-            if (active) nprim++;
+            if (A.mode == 3) {
+                const unsigned long long src = batch * RT_BLOCK + threadIdx.x;
+                active = src < total;
+                in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
+                in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0; in.spec = 0;
+                in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
+                if (active) {
+                    const float4 a = A.qsrc.a[src], b = A.qsrc.b[src], c = A.qsrc.c[src];
+                    const uint4 dd = A.qsrc.d[src];
+                    in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
+                    in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
+                    in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.spec = (dd.y >> 16) & 0xFFu; in.node = dd.z; in.sample = dd.w;
+                    if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
+                }
+            } else {
+                active = primary_setup(C, A, batch * RT_BLOCK + threadIdx.x, total, h_table, s_h2, s_h3, in);
+                if (active) nprim++;
+            }
         }
         __syncthreads();                                  // s_count settled before this round's pushes
         shade_path<MODEL, TEX>(C, in, active, stack, cnt);
@@ -2510,6 +2532,33 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
     default: RT_LAUNCH_PRIMARY(RT_SHADE_FIN);
     }
 #undef RT_LAUNCH_PRIMARY
+}
+
+// The rays a k_wavefront pass could not keep on its LDS stacks, traced by a second pass of the same kernel with the
+// queue as its source (their whole subtrees stay in LDS; what does not fit THIS time goes on to qout and the per-level
+// launches).  Returns false when the model has no wavefront kernel (the caller then starts the level launches at qin).
+bool rtk_launch_wavefront_queue(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
+                                const DevRayQueue &qin, const uint32_t *qin_count, const DevRayQueue &qout, uint32_t *qout_count)
+{
+    static int wavefront = -1;
+    if (wavefront < 0) { const char *e = getenv("RT_TRACER"); const char *q = getenv("RT_WF_QUEUE_PASS"); wavefront = ((e && !strcmp(e, "levels")) || (q && q[0] == '0')) ? 0 : 1; }
+    if (!wavefront || !(P.shade_model == RT_SHADE_FIN || P.shade_model == RT_SHADE_P13)) return false;
+    ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
+    C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_d = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
+    PrimaryArgs A;
+    memset(&A, 0, sizeof A);
+    A.mode = 3; A.ns = 1; A.qsrc = qin; A.qsrc_count = qin_count;
+    A.div_ns = fastdiv_make(1u);
+    const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
+    const int wgrid = 256 * RT_WF_WAVES;       // the count is on the device: a full persistent grid, idle workgroups leave at once
+    if (P.shade_model == RT_SHADE_FIN) {
+        if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+        else hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+    } else {
+        if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_P13, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+        else hipLaunchKernelGGL((k_wavefront<RT_SHADE_P13, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+    }
+    return true;
 }
 
 void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
