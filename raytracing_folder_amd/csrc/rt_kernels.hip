@@ -1937,18 +1937,31 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
 
         while (ballot64(pending)) {
             // ---------------- phase A: pending lanes list the leaves inside their trial radius ----
+            // Two lanes walk for one query: lane l and lane l + 32 hold the same point and radius, keep the same walk state
+            // and split the box tests of every visit between them (grandchildren 0-1 / 2-3, child 0 / 1); one
+            // v_permlane32_swap per visit gives both the combined result.  The queries sit in lanes 0-31 only (32 per
+            // batch), so the upper half of the wave would otherwise idle through the phase.
+            static_assert(RT_GATHER_BATCH == 32, "phase A pairs lane l with lane l + 32");
+            const bool upper = lane >= 32;
+            auto from_lower = [](float v) { return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false)[0]); };
+            const float wx = from_lower(a.x), wy = from_lower(a.y), wz = from_lower(a.z), wr2 = from_lower(r2cur);
+            const bool walking = ((uint32_t)ballot64(pending) >> (lane & 31)) & 1u;
+            auto both_halves = [](uint32_t mine, int bits) {       // my half's result bits -> lower half's | upper half's << bits, in every lane
+                const auto r = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+                return r[0] | (r[1] << bits);
+            };
             uint32_t nl = 0;
             auto list_leaf = [&](uint32_t leaf) {
-                if (nl < RT_LEAFLIST_CAP) L.leaves[lane][nl] = (uint16_t)leaf;
+                if (!upper && nl < RT_LEAFLIST_CAP) L.leaves[lane][nl] = (uint16_t)leaf;
                 nl++;
             };
-            if (pending && n_leaves) {
+            if (walking && n_leaves) {
                 // Depth-first, left to right (ascending leaf ids).  Phase A waits for a chain of dependent box reads, so a
                 // visit reads as much as one aligned line pair gives: the boxes of all four GRANDCHILDREN of an internal node
                 // (heap order: nodes 4n..4n+3, 128 contiguous bytes) -- a grandchild the ball cuts implies its parent is cut,
                 // so the level between needs no test of its own.  Which grandchildren are still to be visited is kept as a
                 // 4-bit mask per pair of levels; no box is fetched twice.  An odd last level is a two-child visit.
-                if (box_dist2(G.pm.tbox + 2, a.x, a.y, a.z) < r2cur) {
+                if (box_dist2(G.pm.tbox + 2, wx, wy, wz) < wr2) {
                     if (n_leaves == 1) list_leaf(0u);
                     else {
                         uint32_t node = 1, pd = 0;              // current internal node and its pair-depth (tree depth = 2 * pd)
@@ -1956,10 +1969,11 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         for (;;) {
                             if (4u * node < 2u * n_leaves && 2u * node < n_leaves) {
                                 // grandchildren exist (they are internal nodes, or the leaves themselves)
-                                const float4 *gb = G.pm.tbox + 8 * (size_t)node;      // boxes of 4*node .. 4*node + 3
-                                uint32_t m4 = 0;
-#pragma unroll
-                                for (int i = 0; i < 4; i++) if (box_dist2(gb + 2 * i, a.x, a.y, a.z) < r2cur) m4 |= 1u << i;
+                                const float4 *gb = G.pm.tbox + 8 * (size_t)node + (upper ? 4 : 0);      // boxes of 4*node .. 4*node + 3: two of them for me
+                                uint32_t m2 = 0;
+                                if (box_dist2(gb, wx, wy, wz) < wr2) m2 |= 1u;
+                                if (box_dist2(gb + 2, wx, wy, wz) < wr2) m2 |= 2u;
+                                const uint32_t m4 = both_halves(m2, 2);
                                 if (4u * node >= n_leaves) {     // the grandchildren are leaves
                                     for (int i = 0; i < 4; i++) if ((m4 >> i) & 1u) list_leaf(4u * node + (uint32_t)i - n_leaves);
                                 } else if (m4) {
@@ -1970,9 +1984,10 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                                 }
                             } else {
                                 // one level left: the children are leaves
-                                const float4 *cb = G.pm.tbox + 4 * (size_t)node;
-                                if (box_dist2(cb, a.x, a.y, a.z) < r2cur) list_leaf(2u * node - n_leaves);
-                                if (box_dist2(cb + 2, a.x, a.y, a.z) < r2cur) list_leaf(2u * node + 1u - n_leaves);
+                                const float4 *cb = G.pm.tbox + 4 * (size_t)node + (upper ? 2 : 0);
+                                const uint32_t m2 = both_halves(box_dist2(cb, wx, wy, wz) < wr2 ? 1u : 0u, 1);
+                                if (m2 & 1u) list_leaf(2u * node - n_leaves);
+                                if (m2 & 2u) list_leaf(2u * node + 1u - n_leaves);
                             }
                             if (!todo_mask) break;
                             const uint32_t bit = 31u - (uint32_t)__clz((int)todo_mask);            // deepest pair-depth with work left
