@@ -249,6 +249,31 @@ def test_irradiance_single_photon_colour_bytes():
     assert dd[lit].tobytes() == od[lit].tobytes()
 
 
+def test_irradiance_on_a_map_with_more_than_65536_sub_leaves():
+    """2.6 M photons = 32768 leaves of eight 16-slot sub-leaves: sub-leaf ids and slot byte offsets beyond 16 bits
+    (the kernel's LDS lists carry 32-bit ids; leaf ids stay 16-bit up to the 8 Mi-photon limit)"""
+    bal = photons.synth_cornell_photon_map(2_600_000, seed=5)
+    s = capi.Scene()
+    s.set_nodes(scenes.identity_node())
+    s.set_photons(bal)
+    rng = np.random.default_rng(6)
+    raw = bal[1:]
+    n = 400
+    qi = rng.integers(0, len(raw), n)
+    pos = raw["position"][qi] + rng.normal(0, 0.05, (n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    for k, radius in ((400, 1.0), (100, 0.3)):
+        irr, dd = s.estimate_irradiance(k, radius, pos, nrm)
+        oirr, od = orc.estimate_irradiance(bal, k, radius, pos, nrm)
+        scale = np.abs(oirr).max(axis=1, keepdims=True) + 1e-30
+        rel = (np.abs(irr - oirr) / scale).max(axis=1)
+        tight = rel < 2e-5
+        assert tight.mean() > 0.9, rel
+        assert (rel[~tight] < 2.5 / k + 1e-4).all(), rel[~tight]      # the reference's heap quirk (see above)
+        assert (oirr.max(axis=1) > 0).mean() > 0.5
+
+
 def test_irradiance_sparse_dense_and_empty():
     bal = photons.synth_cornell_photon_map(30000, seed=11)
     s = capi.Scene()
