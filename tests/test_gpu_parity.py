@@ -295,6 +295,67 @@ def test_irradiance_sparse_dense_and_empty():
     assert (irr == 0).all() and (d == 0).all()
 
 
+def _exact_irradiance(bal, k, r, pos, nrm):
+    """EstimateIrradiance as the ALGORITHM defines it (the k nearest accepted photons inside the radius), by brute force in
+    numpy: no kd-tree, no heap -- so none of the reference heap's first-replacement quirk either"""
+    f = np.float32
+    n_stored = len(bal) - 1
+    half = n_stored // 2 - 1
+    reach = min(max(2 * half - 1, 1), n_stored)              # what LocatePhotons can reach (cyPhotonMap.h:217,371)
+    P = bal[1:reach + 1]
+    dx, dy = P["dir_x"].astype(np.int64), P["dir_y"].astype(np.int64)
+    z2 = 0x3FFF0001 - np.minimum(dx * dx + dy - dy, 0x3FFF0001)   # GetDirection incl. its dirY - dirY (:158-180)
+    dz = np.floor(np.sqrt(z2.astype(np.float64))).astype(np.int64)
+    dz = np.where((dz + 1) * (dz + 1) <= z2, dz + 1, dz)
+    dz = np.where(dz * dz > z2, dz - 1, dz)
+    D = np.stack([dx.astype(f) / f(0x7FFF), dy.astype(f) / f(0x7FFF),
+                  np.where(P["plane_and_dirz"] & 8, -1, 1).astype(f) * (dz.astype(f) / f(0x7FFF))], 1)
+    power = P["color"].astype(f) / f(255) * P["power"][:, None]
+    out = np.zeros((len(pos), 3), f)
+    for i in range(len(pos)):
+        d2 = ((P["position"] - pos[i]) ** 2).sum(1)
+        idx = np.nonzero((d2 < f(r) * f(r)) & ~((D * nrm[i]).sum(1) >= 0))[0]
+        if len(idx) == 0:
+            continue
+        if len(idx) > k:
+            idx = idx[np.argsort(d2[idx], kind="stable")[:k]]
+            area = d2[idx].max()
+        else:
+            area = f(r) * f(r)
+        out[i] = power[idx].sum(0) / (np.pi * area)
+    return out
+
+
+@pytest.mark.parametrize("n_photons", [3, 40, 130, 300, 700, 1500, 5000])
+def test_irradiance_on_tiny_maps(n_photons):
+    """photon maps of one leaf, two, four ... : every shape of the leaf tree the walk has a special case for (a single
+    leaf, a last level of two children, grandchildren that are leaves), with radii that cover the whole map.  Checked
+    against the brute-force k-nearest estimate: the GPU selects the k nearest exactly, so it must agree to summation
+    rounding for EVERY query, small k included (where the reference heap's quirk, which the oracle reproduces, moves
+    single queries by tens of percent) -- and against the oracle within that quirk's allowance"""
+    bal = photons.synth_cornell_photon_map(n_photons, seed=100 + n_photons)
+    s = capi.Scene()
+    s.set_nodes(scenes.identity_node())
+    s.set_photons(bal)
+    rng = np.random.default_rng(n_photons)
+    raw = bal[1:]
+    n = 96
+    pos = raw["position"][rng.integers(0, len(raw), n)] + rng.normal(0, 0.5, (n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    for k, r in ((400, 100.0), (8, 5.0), (50, 1.0)):
+        irr, d = s.estimate_irradiance(k, r, pos, nrm)
+        ex = _exact_irradiance(bal, k, r, pos, nrm)
+        scale = np.abs(ex).max(axis=1, keepdims=True) + 1e-30
+        assert ((np.abs(irr - ex) / scale).max(axis=1) < 2e-5).all(), (n_photons, k, r)
+        assert ((irr == 0).all(axis=1) == (ex == 0).all(axis=1)).all()
+        oirr, od = orc.estimate_irradiance(bal, k, r, pos, nrm)
+        rel = (np.abs(irr - oirr) / (np.abs(oirr).max(axis=1, keepdims=True) + 1e-30)).max(axis=1)
+        assert (rel < 2e-5).mean() > 0.9, (n_photons, k, r, rel.max())
+        if k >= 16:                                        # at k = 8 one wrongly dropped photon moves a query by more than half
+            assert (rel < 2.5 / k + 2e-5).all(), (n_photons, k, r, rel.max())
+
+
 def test_photon_pass_matches_oracle(cornell):
     """generatePhotonMap on the GPU vs the oracle's restatement with the same counter RNG: the same
     emission attempts must store the same photons (libm rounding may move a rare path)."""
