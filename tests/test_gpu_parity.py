@@ -151,6 +151,30 @@ def test_config5_stand_in_frame_and_full_size_properties():
     assert (acc_z == a_z).all() and (np.abs(acc_rgb.astype(int) - a_rgb.astype(int)) <= 1).all()
 
 
+def test_frame_that_overflows_the_lds_ray_stacks(cornell):
+    """the camera looks at the glass sphere from close by, 32 samples per pixel: every ray of a workgroup's 256-sample
+    round spawns a reflection and a refraction, so the 704-ray LDS stacks of k_wavefront overflow into the global queue
+    -- the second k_wavefront pass (queue as the source) and the per-level launches behind it all take part, and the
+    frame must still be the oracle's"""
+    s, cam0, e = cornell
+    s2, cam = scenes.load_cornell(48, 36)
+    target = np.array([-8.0, -6.0, 4.0])                    # sphere2: glass
+    pos = np.array([-8.0, -22.0, 6.0])
+    d = target - pos
+    d /= np.linalg.norm(d)
+    x = np.cross(d, np.array([0.0, 0.0, 1.0]))
+    up = np.cross(x / np.linalg.norm(x), d)
+    for i in range(3):
+        cam.pos[i], cam.dir[i], cam.up[i] = pos[i], d[i], up[i]
+    cam.fov = 24.0
+    p = capi.default_params(min_sample=32, max_sample=32, threshold=-1.0, bounce=5)
+    rgb, z, cnt, st, _ = s2.render(cam, p)
+    orgb, oz, ocnt = orc.render(scenes.oracle_scene(e), scenes.oracle_camera(cam), scenes.oracle_params(p))
+    _frame_gate(rgb, orgb, z, oz, cnt, ocnt)
+    assert st.rays_refract > 0.5 * st.rays_primary and st.rays_reflect > 0.2 * st.rays_primary
+    assert st.peak_rays > 0                                   # rays did go through the global queues
+
+
 def test_trace_empty_and_missing_everything():
     s = capi.Scene()
     s.set_nodes(scenes.identity_node())
