@@ -305,7 +305,7 @@ def main():
                     "fractions": fr,
                     "avg_launch_ms": round(sec_launch * 1e3, 4), "launches_per_frame": round(launches, 1),
                     "timing": f"exclusive: {len(prof)} frame(s) with one chunk in flight (RT_STREAMS=1) after the timed region, HIP events on the "
-                              "launch stream; the timed region itself overlaps chunks on 3 streams",
+                              f"launch stream; the timed region ran with {int(stats[-1]['streams'])} chunk(s) in flight",
                     "exclusive_kernel_ms_per_frame": round(exclusive_ms, 2), "frame_ms_one_stream": round(P["ms_total"], 2),
                     "algorithmic": {"bytes_per_launch": int(c["alg"] / launches), "GBps": d["algorithmic_GBps"],
                                     "frac_of_hbm_peak": round(d["algorithmic_GBps"] / HBM_PEAK_GBS, 3),

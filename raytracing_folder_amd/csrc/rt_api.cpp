@@ -961,14 +961,17 @@ static size_t chunk_samples_limit(bool job)
     return (size_t)v;
 }
 
-// Chunks of a frame in flight at once (each on its own stream with its own working set): 2 by default,
-// 1..RT_STREAMS with RT_STREAMS=n in the environment (tuning / debugging)
-static int render_streams()
+// Chunks of a frame in flight at once (each on its own stream with its own working set); RT_STREAMS=n in the
+// environment (1..RT_STREAMS) overrides the default (tuning / debugging).
+static int render_streams(uint64_t n_chunks)
 {
     const char *e = getenv("RT_STREAMS");
-    // measured on MI355X, round 2 (Cornell frame, 16 chunks): 1: 74.9 ms, 2: 71.8, 3: 73.5, 4: 71.7 -- three slots leave the
-    // sixteenth chunk alone at the end; two need the least memory
-    const int v = e ? atoi(e) : 2;
+    // measured on MI355X, round 2.  Many small chunks (Cornell frame in 16 chunks of 8 Mi samples): 1: 74.9 ms, 2: 71.8,
+    // 3: 73.5, 4: 71.7 -- a second chunk fills the first one's launch gaps and drain phases, three slots leave the
+    // sixteenth chunk alone at the end, two need the least memory.  One or two whole-frame chunks (64 Mi samples): the
+    // kernels are persistent grids that fill the GPU on their own and the frame is the sum of them -- a second chunk
+    // in flight only makes them share it: 1: 50.5 ms, 2: 51.2.
+    const int v = e ? atoi(e) : (n_chunks <= 2 ? 1 : 2);
     return v < 1 ? 1 : (v > RT_STREAMS ? RT_STREAMS : v);
 }
 
@@ -1190,7 +1193,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     // of the three classes dominates per material, so the queues are sized for a fan-out of 2 and an
     // overflow is reported as an error rather than silently dropped
     const uint64_t n_chunks = total_px ? (total_px + ppc - 1) / ppc : 0;
-    int n_slots = (int)std::min<uint64_t>(std::max<uint64_t>(n_chunks, 1), (uint64_t)render_streams());
+    int n_slots = (int)std::min<uint64_t>(std::max<uint64_t>(n_chunks, 1), (uint64_t)render_streams(n_chunks));
     const int fan = p->shade_model == RT_SHADE_P12 && p->hemisphere_sample > 1 ? 1 + p->hemisphere_sample : 2;
     const bool use_photons = D->scene.pm.n_leaves != 0, use_caustic = p->caustic_k > 0 && D->scene.cm.n_leaves != 0;
     const DeviceState::QueueHistory &H = D->qhist;
