@@ -2423,9 +2423,25 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
         const uint8_t *hitf = W.sample_hit + (size_t)ql * A.max_sample;
         const float *zs = W.sample_z + (size_t)ql * A.max_sample;
         const int ns = A.phase == 1 ? A.max_sample : A.min_sample;
+        // the hit flags of the pixel's samples (bytes 0 / 1): with rows of a multiple of 16 bytes they are read as 16-byte words
+        // and packed into one 64-bit mask (four loads instead of one byte load per sample and pass)
+        const bool packed_hits = (A.max_sample & 15) == 0 && ns <= 64;
+        unsigned long long hmask = 0;
+        if (packed_hits) {
+            const uint4 *h4 = (const uint4 *)hitf;
+            for (int t = 0; 16 * t < ns; t++) {
+                const uint4 w = h4[t];
+                const uint32_t b16 = (((w.x & 0x01010101u) * 0x01020408u) >> 24) | ((((w.y & 0x01010101u) * 0x01020408u) >> 24) << 4) |
+                                     ((((w.z & 0x01010101u) * 0x01020408u) >> 24) << 8) | ((((w.w & 0x01010101u) * 0x01020408u) >> 24) << 12);
+                hmask |= (unsigned long long)(b16 & 0xFFFFu) << (16 * t);
+            }
+            if (ns < 64) hmask &= (1ull << ns) - 1ull;
+        }
+        auto hit_at = [&](int j) { return packed_hits ? (bool)((hmask >> j) & 1ull) : hitf[j] != 0; };
         int n = 0;
         float hitz = 0;
-        { int last = -1; for (int j = 0; j < ns; j++) if (hitf[j]) { n++; last = j; } if (last >= 0) hitz = zs[last]; }
+        if (packed_hits) { n = __popcll(hmask); if (hmask) hitz = zs[63 - __clzll((long long)hmask)]; }
+        else { int last = -1; for (int j = 0; j < ns; j++) if (hitf[j]) { n++; last = j; } if (last >= 0) hitz = zs[last]; }
         // visit(j, r, g, b) for the hit samples in order, from LDS tiles (staged) or straight from memory
         auto for_hit_samples = [&](auto &&visit) {
             if (staged) {
@@ -2442,10 +2458,10 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const float *mine = tile + lane * (3 * RT_RESOLVE_TILE + 1);
-                    for (int j = 0; j < tn; j++) if (hitf[t0 + j]) visit(mine[3 * j], mine[3 * j + 1], mine[3 * j + 2]);
+                    for (int j = 0; j < tn; j++) if (hit_at(t0 + j)) visit(mine[3 * j], mine[3 * j + 1], mine[3 * j + 2]);
                 }
             } else {
-                for (int j = 0; j < ns; j++) if (hitf[j]) visit(rgb[3 * j], rgb[3 * j + 1], rgb[3 * j + 2]);
+                for (int j = 0; j < ns; j++) if (hit_at(j)) visit(rgb[3 * j], rgb[3 * j + 1], rgb[3 * j + 2]);
             }
         };
         bool over = false;
