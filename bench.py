@@ -33,9 +33,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0        # aggregate L2 rate of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
-VALU_PEAK_GINST = 1024 * 2.4 / 4      # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs at 2.4 GHz, 4 cycles each (16 lanes per cycle:
-                                      # the 157.3 TF f32 vector peak is v_pk_fma_f32 at that rate; SQ_ACTIVE_INST_VALU counts one quad-cycle
-                                      # per VALU instruction)
+VALU_PEAK_GINST = 1024 * 2.4 / 2      # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs at 2.4 GHz, one per 2 cycles (32 lanes per cycle; the
+                                      # 157.3 TF f32 vector peak is exactly that with fma).  One WAVE issues at most one per 4 cycles.
 PARITY_NOTE = ("geometry half of RenderPixel pinned to the reference's own z images and compiled headers; "
                "MtlBlinn::Shade, GenLight::Shadow, TraceNode and RenderPixel's loop are restated from main.cpp "
                "(unbuildable here: needs GL/glut.h): Shade parity UNPINNED, GPU == oracle only")
@@ -111,7 +110,7 @@ def profile_figures(default_workload):
     separate rocprofv3 --pmc passes of this very command, condensed by tools_profile_summary.py, gfx950 x2 fetch
     correction applied).  Only quoted for the default workload they were measured on."""
     import glob
-    out = {"hbm": {}, "valu": {}, "hbm_source": None, "valu_source": None}
+    out = {"hbm": {}, "hbm_launches": {}, "valu": {}, "hbm_source": None, "valu_source": None}
     if not default_workload:
         return out
     for key, pat in (("hbm", "*_bench_pmc_hbm.json"), ("valu", "*_bench_sq_counters.json")):
@@ -124,9 +123,9 @@ def profile_figures(default_workload):
                 name = k.split("<")[0]
                 if key == "hbm":
                     out["hbm"][name] = float(v["hbm_bytes_per_launch"])
+                    out.setdefault("hbm_launches", {})[name] = float(v["FETCH_SIZE"]["launches"])
                 elif "SQ_INSTS_VALU" in v and v.get("avg_launch_us"):
-                    # clipped at 1: the count can come out a few percent above it (the peak assumes 2.4 GHz and 4 cycles for
-                    # every VALU instruction) -- the vector pipe is then simply full
+                    # (clipped at 1 for safety: the peak assumes 2.4 GHz)
                     out["valu"][name] = min(1.0, float(v["SQ_INSTS_VALU"]) / (float(v["avg_launch_us"]) * 1e3) / VALU_PEAK_GINST)
             out[key + "_source"] = os.path.basename(files[-1])
         except Exception:
@@ -278,10 +277,10 @@ def main():
                 if "k_wavefront" in parts and "k_wavefront" not in figs["hbm"] and "k_primary" in figs["hbm"]:
                     parts = ["k_primary" if q == "k_wavefront" else q for q in parts]
                 if all(q in figs["hbm"] for q in parts) and sec > 0:
-                    # PMC bytes are per launch of each kernel; launches per frame of each kernel from the stats
-                    per = {"k_gather": P["launches_gather"], "k_primary": P["launches_primary"], "k_wavefront": P["launches_primary"],
-                           "k_bounce": P["launches_bounce"], "k_resolve": P["launches_resolve"]}
-                    hb = sum(figs["hbm"][q] * per[q] for q in parts)
+                    # PMC bytes are per launch of each kernel; the counter passes profile exactly ONE frame of this workload, so a
+                    # kernel's launches in them are its launches per frame (k_wavefront's second pass is a launch of its own there,
+                    # while the library's event classes count it with the level launches)
+                    hb = sum(figs["hbm"][q] * figs["hbm_launches"][q] for q in parts)
                     row["hbm_bytes_per_frame"] = int(hb)
                     row["hbm_frac"] = round(hb / sec / 1e9 / HBM_PEAK_GBS, 4)
                 if all(q in figs["valu"] for q in parts):

@@ -84,10 +84,12 @@ for passname in ("pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_l2", "pmc_ta1", "pmc_ta2"
 if sq:
     for k, d in sq.items():
         if "SQ_INSTS_VALU" in d and "avg_launch_us" in d:
-            # A wave64 VALU instruction holds its SIMD's vector pipe for 4 cycles (16 lanes per cycle): the 157.3 TF f32
-            # vector peak is 1024 SIMDs x 2.4 GHz x 64 FLOP/clk and takes v_pk_fma_f32 (256 FLOP per instruction);
-            # SQ_ACTIVE_INST_VALU confirms it (about one quad-cycle per VALU instruction).  1024 SIMDs at the 2.4 GHz peak clock.
-            d["valu_issue_frac_of_peak"] = round(d["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e3 * d["avg_launch_us"]), 4)
+            # A SIMD issues one wave64 VALU instruction per 2 cycles (32 lanes per cycle: MI355X_MICROARCH.md; the 157.3 TF f32
+            # vector peak is 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flop) -- a SINGLE wave can issue one only every 4 cycles, and
+            # SQ_ACTIVE_INST_VALU counts those 4 (one quad-cycle per instruction), which is why this fraction was priced at 4
+            # cycles for a while in round 2: the build without packed ops then came out at 1.17 of that "peak".  Packed f32 ops
+            # (v_pk_*) hold the pipe twice as long; they are counted once here.
+            d["valu_issue_frac_of_peak"] = round(d["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e3 * d["avg_launch_us"]), 4)
         if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]:
             d["wait_any_frac"] = round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 4)
         if "TCC_HIT_sum" in d and d["TCC_HIT_sum"] + d.get("TCC_MISS_sum", 0) > 0:
