@@ -540,6 +540,201 @@ def gen_refimages():
     print("reference-held z images copied")
 
 
+# ---- the reference's main.cpp (oracle/_ref/ref_main_harness_*, see ref_main_harness.cpp) -------------------------
+MAIN_HARNESS = {m: os.path.join(ROOT, "oracle", "_ref", f"ref_main_harness_{m}") for m in ("fin", "p13")}
+SCENE_DIR = {"fin": os.path.join(REF, "RayTracingFinal", "RayTracingFinal", "data"),
+             "p13": os.path.join(REF, "RayTracingProj13", "RayTracingProj13")}
+MAINHIT = np.dtype([("hit", "<i4"), ("z", "<f4"), ("p", "<f4", 3), ("N", "<f4", 3), ("front", "<i4"), ("node", "<i4")])
+
+
+def run_main(model, cmd, payload):
+    """the reference's own program text, scene.xml loaded by its own LoadScene; cwd = the scene's directory (OBJ names
+    are cwd-relative, xmlload.cpp:205)"""
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(payload)
+        subprocess.run([MAIN_HARNESS[model], cmd, "scene.xml", fin, fout], check=True, cwd=SCENE_DIR[model])
+        with open(fout, "rb") as f:
+            return f.read()
+
+
+def photons_payload(pos, dirn, power):
+    a = np.concatenate([pos, dirn, power], axis=1).astype(np.float32)
+    return struct.pack("<i", len(a)) + a.tobytes()
+
+
+def take_balanced(out):
+    n = struct.unpack_from("<i", out, 0)[0]
+    if n == 0:
+        return np.zeros(0, PHOTON), 4
+    return np.frombuffer(out, PHOTON, n + 1, 4).copy(), 4 + (n + 1) * 24
+
+
+def decode_photons(ph):
+    """Photon::GetDirection / GetPower (cyPhotonMap.h:58,158-180) in numpy: only to turn a dump into AddPhoton inputs"""
+    dx = ph["dir_x"].astype(np.float32) / np.float32(0x7FFF)
+    dy = ph["dir_y"].astype(np.float32) / np.float32(0x7FFF)
+    dz = np.sqrt(np.maximum(0.0, 1.0 - dx.astype(np.float64) ** 2 - dy.astype(np.float64) ** 2)).astype(np.float32)
+    dz = np.where(ph["plane_and_dirz"] & 8, -dz, dz)
+    power = ph["color"].astype(np.float32) / np.float32(255.0) * ph["power"][:, None]
+    return np.stack([dx, dy, dz], 1), power
+
+
+def main_photon_set():
+    """<= 50 000 photons for the Shade / RenderPixel fixtures, made by the reference's own PhotonTracing (1 000 000 stored,
+    seed 11: the density of the real map) and thinned so that BOTH regimes of EstimateIrradiance<400>(radius 1) occur: the
+    full density (about 600 within the radius: the k-th distance decides) inside a ball around the floor between the
+    spheres, sparse elsewhere."""
+    out = run_main("fin", "photontrace", struct.pack("<Iiiii", 11, 1000000, 8, 0, 0))
+    consumed = struct.unpack_from("<i", out, 0)[0]
+    off = 4 + max(consumed, 0) * 4
+    attempts, n = struct.unpack_from("<qi", out, off)
+    ph = np.frombuffer(out, PHOTON, n, off + 12)
+    pos = ph["position"]
+    dense = np.linalg.norm(pos - np.array([0, -6, 0], np.float32), axis=1) < 8.5
+    rng = np.random.default_rng(12)
+    keep_d = rng.permutation(np.flatnonzero(dense))[:44000]
+    keep_s = rng.permutation(np.flatnonzero(~dense))[:6000]
+    sel = np.sort(np.concatenate([keep_d, keep_s]))
+    d, pw = decode_photons(ph[sel])
+    # the powers were scaled by 4*pi/1000000 (the real map's): the thinned set keeps them
+    return pos[sel].astype(np.float32), d, pw.astype(np.float32), dict(attempts=attempts, stored=n, dense=len(keep_d), sparse=len(keep_s))
+
+
+def main_rays(rng, cam_pos, n_cam, n_box):
+    """camera-like rays (from the camera position through the view) and rays between points inside the box"""
+    tgt = np.stack([rng.uniform(-17, 17, n_cam), rng.uniform(-10, 16, n_cam), rng.uniform(-1, 25, n_cam)], 1)
+    d = tgt - cam_pos
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    cam = np.concatenate([np.broadcast_to(cam_pos, (n_cam, 3)), d], 1)
+    o = np.stack([rng.uniform(-14, 14, n_box), rng.uniform(-28, 14, n_box), rng.uniform(0.5, 23.5, n_box)], 1)
+    d = rng.normal(size=(n_box, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    aim = rng.random(n_box) < 0.5                                   # towards the spheres / the teapot
+    tg = np.array([[8, -6, 4], [-8, -6, 4], [2, 5, 3], [0, -6, 0]], float)[rng.integers(0, 4, n_box)] + rng.normal(scale=2.5, size=(n_box, 3))
+    da = tg - o
+    da /= np.linalg.norm(da, axis=1, keepdims=True)
+    d[aim] = da[aim]
+    return np.concatenate([cam, np.concatenate([o, d], 1)]).astype(np.float32)
+
+
+def gen_main_shade(model):
+    """TraceNode + MtlBlinn::Shade + GenLight::Shadow of the reference's main.cpp on the Cornell scene.xml"""
+    rng = np.random.default_rng(201 if model == "fin" else 202)
+    top = 4 if model == "fin" else 6                     # BOUNCE of the snapshot (FIN/main.cpp:25, P13/main.cpp:25)
+    cam_pos = np.array([0, -60, 12], float)
+    if model == "fin":
+        pos, d, pw, info = main_photon_set()
+        counts = {4: (1100, 100), 3: (300, 700), 2: (200, 600), 1: (150, 500), 0: (100, 400)}
+    else:
+        pos, d, pw, info = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), {}
+        counts = {6: (900, 100), 5: (200, 300), 4: (200, 400), 3: (200, 400), 2: (150, 400), 1: (150, 350), 0: (100, 300)}
+    rays, bounce = [], []
+    for b, (nc, nb) in counts.items():
+        r = main_rays(rng, cam_pos, nc, nb)
+        rays.append(r)
+        bounce.append(np.full(len(r), b, np.int32))
+    rays, bounce = np.concatenate(rays), np.concatenate(bounce)
+    n = len(rays)
+    assert n >= 4096 and bounce.max() == top
+    cases = np.zeros(n, np.dtype([("ray", "<f4", 6), ("bounce", "<i4")]))
+    cases["ray"], cases["bounce"] = rays, bounce
+    # first run: hit points only, to aim the Shadow rays from real surface points (where the biases matter)
+    out = run_main(model, "shade", photons_payload(pos, d, pw) + struct.pack("<i", n) + cases.tobytes() + struct.pack("<i", 0))
+    bal, off = take_balanced(out)
+    hits = np.frombuffer(out, MAINHIT, n, off)
+    hp = hits["p"][hits["hit"] == 1]
+    light = np.array([0, 0, 22], np.float32)
+    ns = 2048
+    src = hp[rng.integers(0, len(hp), ns)]
+    sh = np.zeros((ns, 7), np.float32)
+    sh[:, :3] = src
+    sh[:, 3:6] = light - src                             # PointLight::Illuminate: Shadow(Ray(p, position - p), 1)
+    sh[:, 6] = 1.0
+    k = ns // 4                                          # the rest: other targets, lengths and t_max (DirectLight: BIGFLOAT)
+    sh[:k, 3:6] = rng.normal(size=(k, 3)) * rng.choice([0.3, 1.0, 20.0], size=(k, 1))
+    sh[:k, 6] = rng.choice([1.0, 1.0e30], k)
+    sh[k:2 * k, :3] = np.stack([rng.uniform(-14, 14, k), rng.uniform(-28, 14, k), rng.uniform(0.5, 23.5, k)], 1)
+    sh[k:2 * k, 3:6] = light - sh[k:2 * k, :3]
+    out = run_main(model, "shade", photons_payload(pos, d, pw) + struct.pack("<i", n) + cases.tobytes() + struct.pack("<i", ns) + sh.tobytes())
+    bal, off = take_balanced(out)
+    hits = np.frombuffer(out, MAINHIT, n, off).copy(); off += n * MAINHIT.itemsize
+    rgb = np.frombuffer(out, np.float32, 3 * n, off).reshape(n, 3).copy(); off += 12 * n
+    shadow = np.frombuffer(out, np.float32, ns, off).copy()
+    assert off + 4 * ns == len(out)
+    np.savez_compressed(os.path.join(GOLD, f"main_shade_{model}.npz"), photons=bal, rays=rays, bounce=bounce, hits=hits, rgb=rgb,
+                        shadow_rays=sh, shadow=shadow)
+    print(f"main_shade_{model}: {n} cases, {int(hits['hit'].sum())} hits, {len(bal)} photon records {info}, "
+          f"shadow: {ns} rays, {int((shadow == 0).sum())} occluded, nodes hit {sorted(set(hits['node'][hits['hit'] == 1]))}")
+
+
+def gen_main_pixels(model):
+    """RenderPixel of the reference's main.cpp: RGB8 + z + sample-count byte of pixel segments"""
+    segs = []
+    if model == "fin":
+        pos, d, pw, info = main_photon_set()
+        frames = [((160, 120), [(0, 160 * 120)]),                                            # a whole small frame
+                  ((800, 600), [(440 * 800, 800), (455 * 800 + 200, 400), (470 * 800, 800), (520 * 800 + 300, 300)])]
+    else:
+        pos = d = pw = np.zeros((0, 3), np.float32)
+        # rows >= 327 only: P13's RenderPixel skips (and never counts) the rows above (P13/main.cpp:219)
+        frames = [((800, 600), [(330 * 800, 800), (440 * 800 + 100, 600), (470 * 800 + 150, 500), (560 * 800, 400)])]
+    res = {}
+    bal = None
+    for fi, ((w, h), seg) in enumerate(frames):
+        a = np.array(seg, np.int32)
+        out = run_main(model, "pixels", photons_payload(pos, d, pw) + struct.pack("<iii", w, h, len(a)) + a.tobytes())
+        bal, off = take_balanced(out)
+        ow, oh = struct.unpack_from("<ii", out, off); off += 8
+        assert (ow, oh) == (w, h)
+        rgb, z, cnt = [], [], []
+        for start, count in seg:
+            rgb.append(np.frombuffer(out, np.uint8, 3 * count, off).reshape(count, 3)); off += 3 * count
+            z.append(np.frombuffer(out, np.float32, count, off)); off += 4 * count
+            cnt.append(np.frombuffer(out, np.uint8, count, off)); off += count
+        assert off == len(out)
+        res[f"f{fi}_size"] = np.array([w, h], np.int32)
+        res[f"f{fi}_segments"] = a
+        res[f"f{fi}_rgb"], res[f"f{fi}_z"], res[f"f{fi}_count"] = np.concatenate(rgb), np.concatenate(z), np.concatenate(cnt)
+        print(f"main_pixels_{model}: frame {w}x{h}, {sum(c for _, c in seg)} px, {int((res[f'f{fi}_count'] == 255).sum())} took the second batch, "
+              f"{int((res[f'f{fi}_z'] > 1e29).sum())} background")
+    if model == "fin":
+        # the same thinned photon set as main_shade_fin.npz (main_photon_set is deterministic): stored there only
+        shade = np.load(os.path.join(GOLD, "main_shade_fin.npz"))
+        assert shade["photons"].tobytes() == bal.tobytes(), "run gen_main_shade('fin') first"
+    np.savez_compressed(os.path.join(GOLD, f"main_pixels_{model}.npz"), n_frames=len(frames), **res)
+
+
+def gen_main_photontrace():
+    """generatePhotonMap's loop with the reference's RandomPhoton / TraceNode / PhotonTracing (mode 0) and CausticTracing
+    (mode 1), rand() captured (RayTracingFinal: the snapshot the product's photon pass follows)"""
+    res = {}
+    for tag, mode, count, bounce, seed in (("photon", 0, 3000, 8, 7), ("caustic", 1, 6000, 5, 8)):
+        out = run_main("fin", "photontrace", struct.pack("<Iiiii", seed, count, bounce, mode, 600000))
+        consumed = struct.unpack_from("<i", out, 0)[0]
+        assert consumed > 0, "capture too small"
+        raw = np.frombuffer(out, np.int32, consumed, 4).copy()
+        off = 4 + 4 * consumed
+        attempts, n = struct.unpack_from("<qi", out, off); off += 12
+        ph = np.frombuffer(out, PHOTON, n, off).copy()
+        assert off + 24 * n == len(out)
+        res.update({f"{tag}_seed": seed, f"{tag}_count": count, f"{tag}_bounce": bounce, f"{tag}_raw": raw, f"{tag}_attempts": attempts, f"{tag}_photons": ph})
+        print(f"main_photontrace {tag}: {n} photons stored, {attempts} attempts, {consumed} rand() calls")
+    np.savez_compressed(os.path.join(GOLD, "main_photontrace.npz"), **res)
+
+
+def gen_main():
+    for m in ("fin", "p13"):
+        if not os.path.exists(MAIN_HARNESS[m]):
+            sys.exit(f"{MAIN_HARNESS[m]} missing: run `make -C oracle refmain` in the build container first")
+    gen_main_shade("fin")
+    gen_main_shade("p13")
+    gen_main_pixels("fin")
+    gen_main_pixels("p13")
+    gen_main_photontrace()
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     for m in ("fin", "p13"):
@@ -563,12 +758,14 @@ def main():
     gen_pbounce()
     gen_lights()
     gen_refimages()
+    gen_main()
     print("fixtures written to", GOLD)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:          # regenerate only the named fixtures, e.g. `gen_golden.py mesh_mtl`
         for name in sys.argv[1:]:
-            globals()["gen_" + name]()
+            fn, _, arg = name.partition(":")      # e.g. main_shade:fin
+            globals()["gen_" + fn](*([arg] if arg else []))
     else:
         main()

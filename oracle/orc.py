@@ -245,6 +245,30 @@ def shade_rays(scene, params, rays):
     return hit, rgb, z
 
 
+def shade_cases(scene, params, rays, bounces):
+    """TraceNode + Shade(ray, hit, lights, bounce_i, 0) per case -> (hit flags, hit records, linear rgb): the calls
+    oracle/ref_main_harness.cpp `shade` makes on the reference (params.bounce stays the snapshot's BOUNCE)."""
+    rays = _c(rays, np.float32).reshape(-1, 6)
+    n = len(rays)
+    rgb = np.zeros((n, 3), np.float32)
+    hit = np.zeros(n, np.int32)
+    hits = np.zeros(n, HIT)
+    for i in range(n):
+        lib().orc_set_rng(C.c_uint32(params.seed), C.c_uint32(i), C.c_uint32(1))
+        h = hits[i:i + 1]
+        hit[i] = lib().orc_trace(C.byref(scene.c), params.shade_model, _p(rays[i]), C.c_void_p(h.ctypes.data))
+        if hit[i]:
+            lib().orc_shade(C.byref(scene.c), C.byref(params), _p(rays[i]), C.c_void_p(h.ctypes.data), int(bounces[i]), _p(rgb[i]))
+    return hit, hits, rgb
+
+
+def shadow(scene, model, rays, t_max):
+    """GenLight::Shadow(ray, t_max) per ray"""
+    rays = _c(rays, np.float32).reshape(-1, 6)
+    lib().orc_shadow.restype = C.c_float
+    return np.array([lib().orc_shadow(C.byref(scene.c), int(model), _p(rays[i]), C.c_float(float(t_max[i]))) for i in range(len(rays))], np.float32)
+
+
 def texture_sample(texture, texels, uvw):
     texture = _c(texture, TEXTURE).reshape(1)
     texels = _c(texels, np.uint8)

@@ -1125,3 +1125,130 @@ def test_full_size_frame_properties():
     p1 = capi.default_params(min_sample=1, max_sample=1, threshold=-1.0)
     rgb4, z4, _, st4, prog4 = s4.render(cam4, p1)
     assert prog4 == 3840 * 2160 and st4.rays_primary == 3840 * 2160 and (z4 != 0).all() and (z4 < 1e29).mean() > 0.99
+
+
+def test_headline_configuration_pixels_against_the_oracle():
+    """The frame bench.py times (BASELINE config C4): Cornell, FIN shading, 1920 x 1080, 64 spp fixed, k = 400, r = 1,
+    1 000 000 photons from the GPU photon pass (seed 20171203) balanced on the host.  A seeded subset of the 32 x 8 tiles
+    (rt_tile_range first/stride) is rendered on the GPU with the queues, chunks and gather of the real size, and seeded
+    8 x 8 blocks inside those tiles are rendered by the oracle from the SAME photon array: FIN/main.cpp:202-344 (RenderPixel)
+    and :695-705 (the photon term) under the SURVEY 8(c) gate.  Also: a whole-frame render of the same inputs puts the same
+    bytes into those tiles (the 64 Mi-sample chunks, the second k_wavefront pass and the 700-photon queries of the timed
+    configuration, which nothing looked at before)."""
+    W, H, SPP = 1920, 1080, 64
+    s, cam = scenes.load_cornell(W, H)
+    raw, attempts = s.photon_pass(1000000, 8, seed=20171203)
+    assert 1000000 <= len(raw) - 1 <= 1000007 and attempts > 1000000 // 8
+    bal = capi.photon_balance(raw)
+    s.set_photons(bal)
+    p = capi.default_params(min_sample=SPP, max_sample=SPP, threshold=-1.0)
+    tiles_x, tiles_y = W // 32, H // 8
+    first, stride = 7, 29                                    # 280 of the 8 100 tiles, every column phase (29 is coprime to 60)
+    tr = capi.TileRange(32, 8, first, stride)
+    rgb, z, cnt, st, progress = s.render(cam, p, tr)
+    mine = np.arange(first, tiles_x * tiles_y, stride)
+    assert progress == len(mine) * 256 and st.pixels == progress and st.rays_primary == progress * SPP
+    assert st.photon_queries > 0 and st.gather_slow == 0 and st.photons_visited > 400 * st.photon_queries
+    osc = scenes.oracle_scene(s.export(), bal)
+    ocam, op = scenes.oracle_camera(cam), scenes.oracle_params(p)
+    rng = np.random.default_rng(3)
+    # the own tiles that show the glass sphere (image centre about (662, 838), radius 149 px at this size) and the mirror
+    # sphere ((1258, 838)) -- deep ray trees whose far ends make the photon lookups -- plus random ones up to 24
+    tcx, tcy = (mine % tiles_x) * 32 + 16, (mine // tiles_x) * 8 + 4
+    on_sphere = (np.hypot(tcx - 662, tcy - 838) < 125) | (np.hypot(tcx - 1258, tcy - 838) < 125)
+    assert on_sphere.sum() >= 8
+    rest = mine[~on_sphere]
+    picks = np.concatenate([mine[on_sphere][:12], rng.choice(rest, 24 - min(12, int(on_sphere.sum())), replace=False)])
+    d_all, z_all = [], []
+    for t in picks:
+        ty, tx = divmod(int(t), tiles_x)
+        x0, y0 = tx * 32 + 8 * int(rng.integers(0, 4)), ty * 8
+        orgb, oz, ocnt = orc.render(osc, ocam, op, x0, y0, x0 + 8, y0 + 8)
+        sl = (slice(y0, y0 + 8), slice(x0, x0 + 8))
+        d_all.append(np.abs(rgb[sl].astype(int) - orgb[sl].astype(int)).max(axis=2).ravel())
+        z_all.append((z[sl] == oz[sl]).ravel())
+        assert (cnt[sl] == ocnt[sl]).all()
+    d_all, z_all = np.concatenate(d_all), np.concatenate(z_all)
+    assert len(d_all) == 24 * 64
+    assert (d_all <= 1).mean() >= 0.995, ((d_all > 1).sum(), d_all.max())
+    assert z_all.mean() >= 0.999
+    # pixels outside this call's tiles keep the caller's values
+    own = np.zeros((H, W), bool)
+    for t in mine:
+        ty, tx = divmod(int(t), tiles_x)
+        own[ty * 8:ty * 8 + 8, tx * 32:tx * 32 + 32] = True
+    assert (z[~own] == 0).all() and (rgb[~own] == 0).all()
+    # the whole frame (two 64 Mi-sample chunks, like the bench): same bytes in those tiles up to the float-atomic ulp
+    import torch
+    dev = torch.device("cuda", 0)
+    f_rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    f_z = torch.zeros((H, W), dtype=torch.float32, device=dev)
+    f_cnt = torch.zeros((H, W), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        fst = s.render_tiles_device(cam, p, capi.TileRange(32, 8, 0, 1), 0, f_rgb.data_ptr(), f_z.data_ptr(), f_cnt.data_ptr(),
+                                    stream=stream.cuda_stream, sync=True, want_stats=True)
+    assert fst.pixels == W * H and fst.rays_primary == W * H * SPP and fst.gather_slow == 0
+    assert fst.photon_queries > 10 * st.photon_queries
+    full_rgb, full_z = f_rgb.cpu().numpy(), f_z.cpu().numpy()
+    assert (full_z[own] == z[own]).all()
+    assert (np.abs(full_rgb[own].astype(int) - rgb[own].astype(int)).max(axis=1) <= 1).mean() > 0.9999
+    assert (full_z != 0).all()
+
+
+# ---- the HIP path against the REFERENCE's own main.cpp (tests/golden/main_*.npz, made by oracle/ref_main_harness.cpp from
+# ---- TraceNode / MtlBlinn::Shade / RenderPixel as the reference compiles them): no oracle in between ----------------
+def _main_params(model, **kw):
+    if model == capi.SHADE_FIN:
+        return capi.default_params(shade_model=model, min_sample=4, max_sample=8, bounce=4, hemisphere_sample=30, **kw)
+    return capi.default_params(shade_model=model, min_sample=4, max_sample=64, bounce=6, hemisphere_sample=20, **kw)
+
+
+@pytest.mark.parametrize("model,tag", [(capi.SHADE_FIN, "fin"), (capi.SHADE_P13, "p13")])
+def test_trace_and_shade_against_the_reference_main(gold, model, tag):
+    """rt_trace_rays = the reference's TraceNode(rootNode) on 4 150 rays: hit records BIT-EXACT (z, p, N, front, node);
+    rt_shade_rays = TraceNode + MtlBlinn::Shade(ray, hit, lights, BOUNCE, 0) on the >= 1 000 cases at the snapshot's
+    BOUNCE: linear colours within 2e-5 relative (summation order, powf/expf last ulp)."""
+    g = gold(f"main_shade_{tag}.npz")
+    s, cam = scenes.load_cornell()
+    if len(g["photons"]):
+        s.set_photons(g["photons"])
+    ref = g["hits"]
+    got = s.trace_rays(g["rays"], model)
+    h = ref["hit"].astype(bool)
+    assert (got["hit"].astype(bool) == h).all()
+    for f in ("z", "p", "N"):
+        assert got[f][h].tobytes() == ref[f][h].tobytes(), f
+    assert (got["node"][h] == ref["node"][h]).all() and (got["front"][h] == ref["front"][h]).all()
+    p = _main_params(model)
+    top = g["bounce"] == p.bounce
+    assert top.sum() >= 1000
+    hit, rgb, z = s.shade_rays(p, g["rays"][top])
+    assert (hit.astype(bool) == h[top]).all() and z[h[top]].tobytes() == ref["z"][top & h].tobytes()
+    want = g["rgb"][top]
+    err = np.abs(rgb - want)
+    assert (err <= 2e-5 * np.abs(want) + 1e-6).all(), (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert (want.max(axis=1) > 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("model,tag", [(capi.SHADE_FIN, "fin"), (capi.SHADE_P13, "p13")])
+def test_frames_against_the_reference_render_pixel(gold, model, tag):
+    """the frames of the reference's own RenderPixel (Color24, z, sample-count byte): a whole 160 x 120 FIN frame with the
+    46 165-photon map, row segments of the 800 x 600 frames of both snapshots.  Gate: >= 99.5 % of the pixels within one
+    level (float summation order against a truncating Color24), z exact, count byte equal on >= 99.5 %."""
+    g = gold(f"main_pixels_{tag}.npz")
+    p = _main_params(model)
+    for fi in range(int(g["n_frames"])):
+        w, h = (int(v) for v in g[f"f{fi}_size"])
+        s, cam = scenes.load_cornell(w, h)
+        if model == capi.SHADE_FIN:
+            s.set_photons(gold("main_shade_fin.npz")["photons"])
+        rgb, z, cnt, st, progress = s.render(cam, p)
+        assert progress == w * h
+        if model == capi.SHADE_FIN:
+            assert st.photon_queries > 0
+        idx = np.concatenate([np.arange(a, a + n) for a, n in g[f"f{fi}_segments"]])
+        d = np.abs(rgb.reshape(-1, 3)[idx].astype(int) - g[f"f{fi}_rgb"].astype(int)).max(axis=1)
+        assert (d <= 1).mean() >= 0.995 and (d > 8).mean() < 0.002, ((d > 1).sum(), d.max())
+        assert (z.reshape(-1)[idx] == g[f"f{fi}_z"]).mean() > 0.999
+        assert (cnt.reshape(-1)[idx] == g[f"f{fi}_count"]).mean() >= 0.995
