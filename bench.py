@@ -216,13 +216,17 @@ def main():
         pass
     elif a.synthetic_photons:
         balanced = photons.synth_cornell_photon_map(a.photons, seed=20171203)
-    else:
-        # generatePhotonMap on the GPU (counter RNG, seed 20171203), balanced on the host like the
-        # reference does; identical on every rank
-        raw, attempts = s.photon_pass(a.photons, 8, seed=20171203, device=local)
-        balanced = capi.photon_balance(raw)
-    if balanced is not None:
+    setup_ms = None
+    if a.workload != "balls" and not a.synthetic_photons:
+        # generatePhotonMap as a whole on the GPU (FIN/main.cpp:350-402; counter RNG, seed 20171203): photon pass ->
+        # compaction -> the few photons balancing would put out of LocatePhotons' reach (host) -> gather structure; identical
+        # on every rank.  Untimed set-up of the frame metric, reported as setup_ms (the reference's own timer spans it,
+        # viewport.cpp:442).  Run twice: the first call also pays the one-time allocations.
+        s.generate_photons(a.photons, 8, seed=20171203, device=local)
+        setup_ms = s.generate_photons(a.photons, 8, seed=20171203, device=local).as_dict()
+    elif balanced is not None:
         s.set_photons(balanced)
+    n_photons = s.counts()["photons"]
     p = capi.default_params(min_sample=a.spp, max_sample=a.spp, threshold=-1.0)
     R = ShardedRenderer(s, cam, p, rank, world, local, host_gather=rehearsal)
 
@@ -355,10 +359,11 @@ def main():
             "config": {"workload": ("C5 stand-in: 128 tessellated spheres (102 402 triangles, half mirrors) on a ground quad under a PNG sky "
                                     f"(environment + background), FIN shading, {a.width}x{a.height}, {a.spp} spp fixed, no photon map, bounce 4") if a.workload == "balls" else
                                    f"Cornell box, FIN shading, {a.width}x{a.height}, {a.spp} spp fixed, "
-                                   f"{len(balanced) - 1}-photon map ({'sprinkled on the walls' if a.synthetic_photons else 'GPU photon pass, Philox seed 20171203, 8 bounces'}), "
+                                   f"{n_photons}-photon map ({'sprinkled on the walls' if a.synthetic_photons else 'GPU photon pass, Philox seed 20171203, 8 bounces'}), "
                                    f"k=400 r=1, bounce 4",
                        "tiles": "32x8 interleaved, tile t -> rank t mod N", "exchange": "one all_gather of 8 B/pixel per frame"},
             "frame_ms": round(dt / a.steps * 1e3, 2),
+            "setup_ms": setup_ms,
             "step_ms_rank0": step_ms,
             "gather_ms": round(gather_ms, 3),
             "parity_note": PARITY_NOTE,
@@ -371,7 +376,8 @@ def main():
         }
         failed = False
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"], kept = cpu_baseline(s.export(), balanced, cam, p, a.cpu_seconds)
+            # the checker needs the reference's balanced heap (its LocatePhotons walks it): made from the same photons on request
+            out["cpu_baseline"], kept = cpu_baseline(s.export(), s.get_photons() if n_photons else None, cam, p, a.cpu_seconds)
             # the frame that was timed is the frame that is checked: the oracle's pixels against the last timed step's image
             out["parity_check"] = parity_check(kept, frame)
             failed = not out["parity_check"]["pass"]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef int rt_status;
 #define RT_OK               0
@@ -165,7 +165,13 @@ typedef struct rt_params {
      * switches it off.  prj13.html quotes k = 400, r = 0.5. */
     int32_t  caustic_k;
     float    caustic_radius;
-    int32_t  reserved[2];
+    /* generatePhotonMap (FIN/main.cpp:27,29,350-402): MAX_NUM_OF_PHOTON 1000000 and PHOTON_BOUNCE 8.  rt_render_begin --
+     * the replacement of BeginRender, which calls generatePhotonMap() before it spawns its workers (:984-998) -- runs the
+     * photon pass first, on the job's thread, when shade_model is RT_SHADE_FIN, photon_count > 0 and the scene holds no
+     * photon map yet (rt_scene_set_photons / rt_scene_generate_photons); photon_count = 0 renders the scene as it is.
+     * The generator is seeded with `seed`.  The device-side entry points (rt_render_tiles_*) never generate. */
+    int32_t  photon_count;
+    int32_t  photon_bounce;
 } rt_params;
 
 /* Which tiles of the image this call renders.  Tiles are tile_w x tile_h pixels, numbered
@@ -295,6 +301,27 @@ rt_status rt_image_write_png(const char *path, const uint8_t *data, int32_t w, i
 rt_status rt_image_zbuffer(const float *zbuffer, int32_t w, int32_t h, uint8_t *zbuffer_img);
 rt_status rt_image_sample_count(const uint8_t *sample_count, int32_t w, int32_t h, uint8_t *sample_count_img, int32_t *smax);
 
+/* generatePhotonMap as a whole (FIN/main.cpp:350-402) on the GPU: the photon pass (rt_photon_pass), ScalePhotonPowers,
+ * the optional dump of the unbalanced photons (:397-400 fwrite to a path the reference hard-codes; dat_path == NULL: no
+ * dump), PrepareForIrradianceEstimation -- and the result becomes the scene's photon map on every device.  ms_out (may be
+ * NULL) receives the wall time of the stages in milliseconds. */
+typedef struct rt_setup_ms {
+    double photon_pass;      /* emission + bounces + compaction of the stored photons (GPU)                      */
+    double balance;          /* what of PrepareForIrradianceEstimation is needed to know the photons LocatePhotons
+                                can reach (cyPhotonMap.h:217,371); host                                          */
+    double structure_build;  /* decode + median-split sub-leaves + boxes + density grid                          */
+    double upload;           /* host <-> device copies of photon records                                         */
+    double total;
+} rt_setup_ms;
+rt_status rt_scene_generate_photons(rt_scene *s, int device, uint32_t max_photons, int photon_bounce, uint32_t seed,
+                                    const char *dat_path, rt_setup_ms *ms_out);
+/* where the photon pass that rt_render_begin runs (rt_params.photon_count) leaves its .dat dump; NULL (default) = no dump */
+rt_status rt_scene_set_photon_dump(rt_scene *s, const char *dat_path);
+/* the scene's photon map as PhotonMap::photons after PrepareForIrradianceEstimation (balanced, [0] unused): what
+ * rt_scene_set_photons was given, or the balanced form of what rt_scene_generate_photons made.  out == NULL only counts
+ * (*n_stored); cap counts records including [0]. */
+rt_status rt_scene_get_photons(rt_scene *s, rt_photon *out, uint32_t cap, uint32_t *n_stored);
+
 /* ---- host helpers that mirror reference host code --------------------------------------- */
 /* cyBVH build with MeanSplit (FIN/include/cyBVH.h:122-142,295-328) as TriObj::Load calls it
  * (maxElementsPerNode = 4, FIN/include/objects.h:143).  nodes_out needs room for 2*nf+1
@@ -306,6 +333,13 @@ rt_status rt_bvh_build(const float *v, int32_t nv, const uint32_t *f, int32_t nf
  * in = photons[1..n] unordered (in[0] unused), out = balanced heap order (out[0] = in[0]).
  * `in` is permuted in place exactly like the reference permutes its vector. */
 rt_status rt_photon_balance(rt_photon *in, uint32_t n, rt_photon *out);
+
+/* Which photons of an UNBALANCED array (in[1..n], in[0] as rt_photon_balance takes it) LocatePhotons will never reach once
+ * the array is balanced: it descends only while index < halfStoredPhotons = n/2 - 1 (FIN/include/cyPhotonMap.h:217,371), so
+ * the last three or four heap slots are never visited.  Found by running BalanceSegment's own partitions along the root
+ * paths of those slots only (about 2n element visits); `in` is not modified.  raw_indices (1-based, ascending) needs room
+ * for 4; *count receives how many there are. */
+rt_status rt_photon_unreachable(const rt_photon *in, uint32_t n, uint32_t *raw_indices, uint32_t cap, uint32_t *count);
 
 /* The photon dump generatePhotonMap leaves behind (FIN/main.cpp:397-400: fwrite of
  * Photon[NumPhotons], before balancing) and the way the reference's viewer reads it back
@@ -385,6 +419,8 @@ int       rt_render_progress(rt_job *j);      /* pixels finished so far (monoton
 rt_status rt_render_stop(rt_job *j);          /* cooperative cancel (StopRender)          */
 rt_status rt_render_wait(rt_job *j);          /* join; returns the job's final status     */
 rt_status rt_job_stats(rt_job *j, rt_stats *out);
+/* the photon pass the job ran before rendering (rt_params.photon_count): stage times, all zero when it ran none */
+rt_status rt_job_setup_ms(rt_job *j, rt_setup_ms *out);
 void      rt_job_destroy(rt_job *j);
 
 /* ---- single-stage entry points (used by parity tests and by hosts that keep their own

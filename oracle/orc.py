@@ -43,7 +43,7 @@ class Params(C.Structure):
                 ("bounce", C.c_int32), ("hemisphere_sample", C.c_int32), ("knn_k", C.c_int32),
                 ("knn_radius", C.c_float), ("shade_model", C.c_int32),
                 ("shadow_samples", C.c_int32), ("seed", C.c_uint32), ("gamma", C.c_double),
-                ("caustic_k", C.c_int32), ("caustic_radius", C.c_float), ("reserved", C.c_int32 * 2)]
+                ("caustic_k", C.c_int32), ("caustic_radius", C.c_float), ("photon_count", C.c_int32), ("photon_bounce", C.c_int32)]
 
 
 def default_params(**kw):

@@ -1,9 +1,10 @@
 // rt_binding.cpp -- the REFERENCE-SIDE binding of librt_mi355x: the file a maintainer of
 // Roia2529/RayTracing-folder drops next to RayTracingFinal/main.cpp to replace its BeginRender / StopRender /
 // saveImage (FIN/main.cpp:984-1012) by calls into the C ABI of include/rt_mi355x.h, keeping viewport.cpp,
-// xmlload.cpp and the global singletons untouched.  Compiled against the reference's OWN headers; in this
-// repository it is only syntax-checked (`make -C oracle binding-check`: g++ -fsyntax-only -I$FIN/include),
-// because the program around it needs <GL/glut.h>.
+// xmlload.cpp and the global singletons untouched.  Compiled against the reference's OWN headers: syntax-checked
+// for both snapshots (`make -C oracle binding-check`) and LINKED AND RUN with the reference's main.cpp, its
+// LoadScene and its saveImage by oracle/ref_binding_harness.cpp (`make -C oracle refbinding`; the GPU tests run
+// it on the box: reference scene graph -> this file -> HIP kernels -> the reference's RenderImage -> its PNG writer).
 //
 // The reference keeps the fields of MtlBlinn, the lights, TextureFile/TextureChecker, TextureMap and
 // TexturedColor private and offers no getters for most of them.  A maintainer would add accessors (or a
@@ -41,7 +42,7 @@ extern MaterialList materials; extern LightList lights; extern TextureList textu
 extern TexturedColor environment, background; extern cy::PhotonMap photonmap;
 extern Sphere theSphere; extern Plane thePlane;
 
-static rt_scene *g_scene; static rt_job *g_job;
+static rt_scene *g_scene; static std::vector<rt_job *> g_jobs;
 
 // walk the Node tree in TraceNode's order (FIN/main.cpp:108-130): parent before children
 static void LowerNodes(const Node &n, int parent, std::vector<rt_node> &out, std::vector<const TriObj *> &meshes)
@@ -181,41 +182,52 @@ void BeginRender()                                   // must return immediately 
     const rt_texmap env_map = LowerMap(environment, textureList), bg_map = LowerMap(background, textureList);
     rt_scene_set_environment_maps(g_scene, &env_map, &bg_map);
 
-    // Photon map, either (a) the reference's own pass -- its balanced vector IS the wire format:
-    // sizeof(cy::PhotonMap::Photon) == sizeof(rt_photon) == 24, photons[0] unused on both sides ...
+    // generatePhotonMap() (FIN/main.cpp:350-402) is what the replaced BeginRender called first (:989).  Either the host
+    // program still runs the reference's own pass before this function -- then its balanced vector IS the wire format
+    // (sizeof(cy::PhotonMap::Photon) == sizeof(rt_photon) == 24, photons[0] unused on both sides) and is handed over --
+    // or the map is empty and rt_render_begin runs the photon pass itself, on the GPU, on the job's thread
+    // (rt_params.photon_count / photon_bounce = MAX_NUM_OF_PHOTON / PHOTON_BOUNCE; rt_scene_set_photon_dump names the
+    // .dat that :397-400 wrote to a hard-coded path).
     static_assert(sizeof(cy::PhotonMap::Photon) == sizeof(rt_photon), "photon record layout");
-    rt_scene_set_photons(g_scene, (const rt_photon *)&photonmap.photons[0], (uint32_t)photonmap.NumPhotons());
-    // ... or (b) instead of generatePhotonMap() (FIN/main.cpp:350-400), on the GPU:
-    //   std::vector<rt_photon> raw(MAX_NUM_OF_PHOTON + 9), bal(raw.size()); uint32_t n; uint64_t tries;
-    //   rt_photon_pass(g_scene, 0, MAX_NUM_OF_PHOTON, PHOTON_BOUNCE, seed, raw.data(), (uint32_t)raw.size(), &n, &tries);
-    //   rt_photons_write_dat("photonmap.dat", raw.data(), n);   // the dump of :397-400, read by PhotonMapViz
-    //   rt_photon_balance(raw.data(), n, bal.data());           // PrepareForIrradianceEstimation
-    //   rt_scene_set_photons(g_scene, bal.data(), n);
+    if (photonmap.photons.size() > 1) rt_scene_set_photons(g_scene, (const rt_photon *)&photonmap.photons[0], (uint32_t)photonmap.photons.size() - 1);
+    else rt_scene_set_photons(g_scene, nullptr, 0);
     // RayTracingProj13's second map: rt_caustic_pass + rt_photon_balance + rt_scene_set_caustic_photons, and
     // p.shade_model = RT_SHADE_P13, p.caustic_k = 400, p.caustic_radius = 0.5 (prj13.html).
 
     rt_camera cam; rt_params p; rt_params_default(&p);    // the FIN #defines (main.cpp:19-32) as run-time values
     // p.shade_model picks the snapshot whose Shade / primitive semantics are wanted: RT_SHADE_FIN (default),
     // RT_SHADE_P13, RT_SHADE_P12 (live GI), RT_SHADE_P6, RT_SHADE_P3; p.seed keys the counter RNG that stands
-    // in for rand() (soft shadows, glossy, DoF, GI)
+    // in for rand() (photon pass, soft shadows, glossy, DoF, GI)
     memcpy(cam.pos, &camera.pos.x, 12); memcpy(cam.dir, &camera.dir.x, 12); memcpy(cam.up, &camera.up.x, 12);
     cam.fov = camera.fov; cam.focaldist = camera.focaldist; cam.dof = camera.dof;
     cam.width = camera.imgWidth; cam.height = camera.imgHeight;
-    const rt_tile_range all = {32, 8, 0, 1};
-    if (rt_render_begin(g_scene, &cam, &p, &all, /*device*/ 0, &renderImage.GetPixels()->r, renderImage.GetZBuffer(),
-                        renderImage.GetSampleCount(), &g_job) != RT_OK)
-        fprintf(stderr, "BeginRender: %s\n", rt_last_error());    // no GPU => loud failure, there is no CPU path
+    // one job per gfx950 device of the node, interleaved 32 x 8 tiles (the reference: 2 x hardware_concurrency threads on
+    // one shared pixel counter, :987-997), all into the reference's own RenderImage buffers; the first job to start runs
+    // the photon pass, the others wait for it
+    const int N = rt_device_count() > 0 ? rt_device_count() : 1;
+    for (int r = 0; r < N; r++) {
+        const rt_tile_range mine = {32, 8, r, N};
+        rt_job *job = nullptr;
+        if (rt_render_begin(g_scene, &cam, &p, &mine, /*device*/ r, &renderImage.GetPixels()->r, renderImage.GetZBuffer(),
+                            renderImage.GetSampleCount(), &job) != RT_OK) {
+            fprintf(stderr, "BeginRender: %s\n", rt_last_error());    // no GPU => loud failure, there is no CPU path
+            break;
+        }
+        g_jobs.push_back(job);
+    }
 }
 
-void StopRender() { if (g_job) rt_render_stop(g_job); }
+void StopRender() { for (rt_job *j : g_jobs) rt_render_stop(j); }
 
 // viewport.cpp polls renderImage.IsRenderDone() (viewport.cpp:390-409); its idle callback feeds the counter:
 //     renderImage.ResetNumRenderedPixels(); renderImage.IncrementNumRenderPixel(RenderProgress());
-int RenderProgress() { return g_job ? rt_render_progress(g_job) : 0; }
+bool RenderRunning() { return !g_jobs.empty(); }   // false after a BeginRender that could not start (no GPU)
+int RenderProgress() { int n = 0; for (rt_job *j : g_jobs) n += rt_render_progress(j); return n; }
 
 void saveImage()                                     // the body of FIN/main.cpp:1000-1007 behind a wait
 {
-    if (g_job) { rt_render_wait(g_job); rt_job_destroy(g_job); g_job = nullptr; }
+    for (rt_job *j : g_jobs) { if (rt_render_wait(j) != RT_OK) fprintf(stderr, "render: %s\n", rt_last_error()); rt_job_destroy(j); }
+    g_jobs.clear();
     renderImage.ComputeZBufferImage();
     renderImage.SaveImage("prj13box.png");
     renderImage.ComputeSampleCountImage();

@@ -48,7 +48,15 @@ class Params(C.Structure):
                 ("bounce", C.c_int32), ("hemisphere_sample", C.c_int32), ("knn_k", C.c_int32),
                 ("knn_radius", C.c_float), ("shade_model", C.c_int32),
                 ("shadow_samples", C.c_int32), ("seed", C.c_uint32), ("gamma", C.c_double),
-                ("caustic_k", C.c_int32), ("caustic_radius", C.c_float), ("reserved", C.c_int32 * 2)]
+                ("caustic_k", C.c_int32), ("caustic_radius", C.c_float), ("photon_count", C.c_int32), ("photon_bounce", C.c_int32)]
+
+
+class SetupMs(C.Structure):
+    """rt_setup_ms: wall time of the stages of rt_scene_generate_photons, milliseconds"""
+    _fields_ = [(n, C.c_double) for n in ("photon_pass", "balance", "structure_build", "upload", "total")]
+
+    def as_dict(self):
+        return {n: round(getattr(self, n), 3) for n, _ in self._fields_}
 
 
 class TileRange(C.Structure):
@@ -80,7 +88,8 @@ SYMBOLS = [
     "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
     "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photons_write_dat", "rt_photons_read_dat", "rt_photon_pass", "rt_caustic_pass", "rt_render_begin",
     "rt_render_tiles_device", "rt_render_tiles_packed_device", "rt_tiles_packed_size", "rt_tiles_unpack_device", "rt_render_check", "rt_render_progress", "rt_render_stop", "rt_render_wait",
-    "rt_job_stats", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
+    "rt_job_stats", "rt_job_setup_ms", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
+    "rt_scene_generate_photons", "rt_scene_set_photon_dump", "rt_scene_get_photons", "rt_photon_unreachable",
 ]
 
 
@@ -231,6 +240,15 @@ def photon_balance(photons_1based):
     return out
 
 
+def photon_unreachable(photons_1based):
+    """1-based indices into an UNBALANCED photon array of the photons LocatePhotons cannot reach after balancing"""
+    a = _c(photons_1based, PHOTON)
+    idx = np.zeros(8, np.uint32)
+    n = C.c_uint32()
+    _check(lib().rt_photon_unreachable(_p(a), C.c_uint32(len(a) - 1), _p(idx), 8, C.byref(n)))
+    return idx[: n.value].copy()
+
+
 class Scene:
     """Owns an rt_scene handle."""
 
@@ -309,6 +327,26 @@ class Scene:
             return
         a = _c(balanced_1based, PHOTON)
         _check(lib().rt_scene_set_caustic_photons(self._h, _p(a), C.c_uint32(len(a) - 1)))
+
+    def generate_photons(self, max_photons=1000000, photon_bounce=8, seed=20171203, device=0, dat_path=None):
+        """generatePhotonMap as a whole on the GPU (photon pass -> [dump] -> queryable structure); returns the stage times"""
+        ms = SetupMs()
+        _check(lib().rt_scene_generate_photons(self._h, int(device), C.c_uint32(int(max_photons)), int(photon_bounce), C.c_uint32(int(seed)),
+                                               os.fsencode(dat_path) if dat_path else None, C.byref(ms)))
+        return ms
+
+    def set_photon_dump(self, dat_path):
+        _check(lib().rt_scene_set_photon_dump(self._h, os.fsencode(dat_path) if dat_path else None))
+
+    def get_photons(self):
+        """the scene's photon map in the reference's balanced form (1-based; empty array when there is none)"""
+        n = C.c_uint32()
+        _check(lib().rt_scene_get_photons(self._h, None, 0, C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, PHOTON)
+        out = np.zeros(n.value + 1, PHOTON)
+        _check(lib().rt_scene_get_photons(self._h, _p(out), len(out), None))
+        return out
 
     def load_xml(self, path):
         _check(lib().rt_scene_load_xml(self._h, os.fsencode(path)))
@@ -404,8 +442,15 @@ class Scene:
                                      C.c_uint32(int(seed)), _p(out), C.c_uint32(len(out)), C.byref(n), C.byref(att)))
         return out[: n.value + 1].copy(), att.value
 
-    def render(self, cam, params, tiles=None, device=0):
-        """Blocking render through the asynchronous job API (rt_render_begin + rt_render_wait)."""
+    def render(self, cam, params, tiles=None, device=0, photon_pass=False):
+        """Blocking render through the asynchronous job API (rt_render_begin + rt_render_wait).  photon_pass=False (the
+        tests' default) renders the scene's photon map as it is: params.photon_count is taken as 0 for this call;
+        photon_pass=True leaves it alone, so that rt_render_begin first runs generatePhotonMap like BeginRender does."""
+        if not photon_pass and params.photon_count != 0:
+            q = Params()
+            C.memmove(C.byref(q), C.byref(params), C.sizeof(Params))
+            q.photon_count = 0
+            params = q
         w, h = cam.width, cam.height
         rgb, z, cnt = np.zeros((h, w, 3), np.uint8), np.zeros((h, w), np.float32), np.zeros((h, w), np.uint8)
         tiles = tiles or TileRange(32, 8, 0, 1)

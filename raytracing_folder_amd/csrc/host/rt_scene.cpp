@@ -496,6 +496,101 @@ void BalancePhotons(rt_photon *in, uint32_t n, rt_photon *out)
     b.Segment(bmin, bmax, 1, 1, n);
 }
 
+// Which photons of an UNBALANCED array LocatePhotons can never reach once it is balanced: it descends only while
+// index < halfStoredPhotons = n/2 - 1 (cyPhotonMap.h:217,371), so heap slots [2*half, n] -- the last three or four -- are
+// never visited.  Found without balancing everything: the content of a segment when BalanceSegment partitions it depends
+// only on the partitions of its ancestors, so the same quick-select is run along the root paths of those slots alone
+// (about 2n element visits instead of n log n), on (position, index) records with the reference's own swap sequence.
+namespace {
+struct PathBalancer {
+    struct Rec { float pos[3]; uint32_t idx; };
+    Rec *ph; uint32_t first, last;          // target heap slots [first, last]
+    std::vector<uint32_t> *out;
+    bool Holds(uint32_t index) const
+    {
+        for (uint32_t t = first; t <= last; t++) { uint32_t a = t; while (a > index) a >>= 1; if (a == index) return true; }
+        return false;
+    }
+    void Put(uint32_t index, const Rec &r) { if (index >= first && index <= last) out->push_back(r.idx); }
+    void Segment(float bmin[3], float bmax[3], uint32_t index, uint32_t start, uint32_t end)
+    {
+        uint32_t median = 1;
+        while (4 * median <= end - start + 1) median += median;
+        if (3 * median <= end - start + 1) { median += median; median += start - 1; }
+        else median = end - median + 1;
+        int axis = 2;
+        const float dx = bmax[0] - bmin[0], dy = bmax[1] - bmin[1], dz = bmax[2] - bmin[2];
+        if (dx > dy) { if (dx > dz) axis = 0; }
+        else if (dy > dz) axis = 1;
+        uint32_t left = start, right = end;
+        while (right > left) {
+            const float pivot = ph[right].pos[axis];
+            uint32_t i = left - 1, j = right;
+            while (ph[++i].pos[axis] < pivot) {}
+            while (ph[--j].pos[axis] > pivot && j > left) {}
+            while (i < j) {
+                std::swap(ph[i], ph[j]);
+                while (ph[++i].pos[axis] < pivot) {}
+                while (ph[--j].pos[axis] > pivot && j > left) {}
+            }
+            std::swap(ph[i], ph[right]);
+            if (i >= median) right = i - 1;
+            if (i <= median) left = i + 1;
+        }
+        Put(index, ph[median]);
+        const float split = ph[median].pos[axis];
+        if (median > start) {
+            if (start < median - 1) {
+                if (Holds(2 * index)) {
+                    float tmax[3] = {bmax[0], bmax[1], bmax[2]};
+                    tmax[axis] = split;
+                    Segment(bmin, tmax, 2 * index, start, median - 1);
+                }
+            } else Put(2 * index, ph[start]);
+        }
+        if (median < end) {
+            if (median + 1 < end) {
+                if (Holds(2 * index + 1)) {
+                    float tmin[3] = {bmin[0], bmin[1], bmin[2]};
+                    tmin[axis] = split;
+                    Segment(tmin, bmax, 2 * index + 1, median + 1, end);
+                }
+            } else Put(2 * index + 1, ph[end]);
+        }
+    }
+};
+}  // namespace
+
+uint32_t ReachablePhotonSlots(uint32_t n)
+{
+    const long long half = (long long)(n / 2) - 1;
+    long long reach = 2 * half - 1;
+    if (reach < 1) reach = 1;
+    if (reach > (long long)n) reach = n;
+    return n ? (uint32_t)reach : 0u;
+}
+
+void UnreachablePhotons(const rt_photon *in, uint32_t n, std::vector<uint32_t> &raw_indices)
+{
+    raw_indices.clear();
+    const uint32_t reach = ReachablePhotonSlots(n);
+    if (n == 0 || reach >= n) return;
+    std::vector<PathBalancer::Rec> recs((size_t)n + 1);
+    float bmin[3] = {in[0].position[0], in[0].position[1], in[0].position[2]};     // the reference's box loop starts at the unused slot
+    float bmax[3] = {bmin[0], bmin[1], bmin[2]};
+    for (uint32_t i = 0; i <= n; i++) {
+        memcpy(recs[i].pos, in[i].position, 12);
+        recs[i].idx = i;
+        if (i) for (int a = 0; a < 3; a++) {
+            if (bmin[a] > in[i].position[a]) bmin[a] = in[i].position[a];
+            if (bmax[a] < in[i].position[a]) bmax[a] = in[i].position[a];
+        }
+    }
+    PathBalancer b{recs.data(), reach + 1, n, &raw_indices};
+    b.Segment(bmin, bmax, 1, 1, n);
+    std::sort(raw_indices.begin(), raw_indices.end());
+}
+
 // ---- Scene ------------------------------------------------------------------------------------------
 Material *Scene::FindMaterial(const std::string &n)
 {

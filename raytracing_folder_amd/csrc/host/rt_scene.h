@@ -335,6 +335,10 @@ void BuildMeanSplitBVH(const float *v, const uint32_t *f, unsigned nf, unsigned 
                        std::vector<rt_bvh_node> &nodes, std::vector<uint32_t> &elements);
 // PhotonMap::PrepareForIrradianceEstimation (FIN/include/cyPhotonMap.h:196-284)
 void BalancePhotons(rt_photon *in, uint32_t n, rt_photon *out);
+// heap slots 1..ReachablePhotonSlots(n) are the ones LocatePhotons can visit (cyPhotonMap.h:217,371)
+uint32_t ReachablePhotonSlots(uint32_t n);
+// indices (1-based, ascending) into an UNBALANCED array of the photons that balancing would put beyond them
+void UnreachablePhotons(const rt_photon *in, uint32_t n, std::vector<uint32_t> &raw_indices);
 
 // RenderImage::ComputeZBufferImage / ComputeSampleCountImage (FIN/include/scene.h:591-637) on plain arrays
 void ZBufferImage(const float *zbuffer, size_t size, uint8_t *zbufferImg);

@@ -15,7 +15,13 @@ void RenderImage::Init(int w, int h)
     finalPixels = 0;
 }
 
-int RenderImage::GetNumRenderedPixels() const { return job ? rt_render_progress(job) : finalPixels; }
+int RenderImage::GetNumRenderedPixels() const
+{
+    if (jobs.empty()) return finalPixels;
+    int n = 0;
+    for (rt_job *j : jobs) n += rt_render_progress(j);
+    return n;
+}
 
 // RenderImage::ComputeZBufferImage / ComputeSampleCountImage, FIN/include/scene.h:591-637 (rt_image.cpp)
 void RenderImage::ComputeZBufferImage()
@@ -34,7 +40,9 @@ Renderer::Renderer() { rt_params_default(&params); rt_scene_create(&handle); }
 
 Renderer::~Renderer()
 {
-    if (job) { rt_render_stop(job); rt_render_wait(job); renderImage.DetachJob(0); rt_job_destroy(job); }
+    for (rt_job *j : jobs) { rt_render_stop(j); rt_render_wait(j); }
+    renderImage.DetachJobs(0);
+    for (rt_job *j : jobs) rt_job_destroy(j);
     rt_scene_destroy(handle);
 }
 
@@ -54,7 +62,7 @@ bool Renderer::SetPhotonMap(const rt_photon *balanced, uint32_t n_stored)
 
 bool Renderer::BeginRender()
 {
-    if (job) { error = "a render is already running"; return false; }
+    if (!jobs.empty()) { error = "a render is already running"; return false; }
     SceneData d;
     if (!Lower(scene, d, &error)) return false;
     rt_status st = rt_scene_set_nodes(handle, d.nodes.data(), (int32_t)d.nodes.size());
@@ -75,26 +83,60 @@ bool Renderer::BeginRender()
     if (st != RT_OK) { error = rt_last_error(); return false; }
     if (renderImage.GetWidth() != d.camera.width || renderImage.GetHeight() != d.camera.height)
         renderImage.Init(d.camera.width, d.camera.height);
-    const rt_tile_range all = {32, 8, 0, 1};
-    st = rt_render_begin(handle, &d.camera, &params, &all, device, renderImage.GetPixels(), renderImage.GetZBuffer(),
-                         renderImage.GetSampleCount(), &job);
-    if (st != RT_OK) { error = rt_last_error(); job = nullptr; return false; }
-    renderImage.AttachJob(job);
+    if (st == RT_OK) st = rt_scene_set_photon_dump(handle, photonDump.empty() ? nullptr : photonDump.c_str());
+    if (st != RT_OK) { error = rt_last_error(); return false; }
+    // one job per device: device r of N renders the interleaved tiles r, r+N, ... into the SAME caller-owned buffers (a job
+    // writes only the pixels of its own tiles); whichever job comes first runs the photon pass, the others wait for it
+    std::vector<int> devs = devices;
+    if (devs.empty()) for (int i = 0, n = rt_device_count(); i < n; i++) devs.push_back(i);
+    if (devs.empty()) devs.push_back(0);              // no gfx950 device: rt_render_begin reports it (there is no CPU path)
+    const int N = (int)devs.size();
+    for (int r = 0; r < N; r++) {
+        const rt_tile_range mine = {32, 8, r, N};
+        rt_job *job = nullptr;
+        st = rt_render_begin(handle, &d.camera, &params, &mine, devs[r], renderImage.GetPixels(), renderImage.GetZBuffer(),
+                             renderImage.GetSampleCount(), &job);
+        if (st != RT_OK) {
+            error = rt_last_error();
+            for (rt_job *j : jobs) { rt_render_stop(j); rt_render_wait(j); }
+            renderImage.DetachJobs(0);
+            for (rt_job *j : jobs) rt_job_destroy(j);
+            jobs.clear();
+            return false;
+        }
+        jobs.push_back(job);
+        renderImage.AttachJob(job);
+    }
     return true;
 }
 
-void Renderer::StopRender() { if (job) rt_render_stop(job); }
+void Renderer::StopRender() { for (rt_job *j : jobs) rt_render_stop(j); }
 
 bool Renderer::WaitRender()
 {
-    if (!job) return true;
-    const rt_status st = rt_render_wait(job);
-    if (st != RT_OK) error = rt_last_error();
-    rt_job_stats(job, &stats);
-    renderImage.DetachJob(rt_render_progress(job));
-    rt_job_destroy(job);
-    job = nullptr;
-    return st == RT_OK;
+    if (jobs.empty()) return true;
+    bool ok = true;
+    int pixels = 0;
+    memset(&stats, 0, sizeof stats);
+    memset(&setup, 0, sizeof setup);
+    for (rt_job *j : jobs) {
+        const rt_status st = rt_render_wait(j);
+        if (st != RT_OK) { error = rt_last_error(); ok = false; }
+        rt_stats one;
+        if (rt_job_stats(j, &one) == RT_OK) {
+            stats.rays_primary += one.rays_primary; stats.rays_shadow += one.rays_shadow; stats.rays_reflect += one.rays_reflect;
+            stats.rays_refract += one.rays_refract; stats.photon_queries += one.photon_queries; stats.photons_visited += one.photons_visited;
+            stats.pixels += one.pixels; stats.samples += one.samples;
+            if (one.ms_total > stats.ms_total) stats.ms_total = one.ms_total;
+        }
+        rt_setup_ms su;
+        if (rt_job_setup_ms(j, &su) == RT_OK && su.total > 0) setup = su;
+        pixels += rt_render_progress(j);
+    }
+    renderImage.DetachJobs(pixels);
+    for (rt_job *j : jobs) rt_job_destroy(j);
+    jobs.clear();
+    return ok;
 }
 
 // saveImage(), FIN/main.cpp:1000-1007

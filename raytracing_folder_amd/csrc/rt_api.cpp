@@ -49,6 +49,16 @@ static int gather_blocks()
 #define GATHER_BLOCKS gather_blocks()
 
 void rtk_launch_photon_trace(hipStream_t, const DevScene &, unsigned long long, uint32_t, uint32_t, int, float *, uint32_t *, int);
+// rt_photon_build.hip: the photon set-up on the GPU
+struct PhotonGridOut { float min[3]; float cell; int dim[3]; };
+size_t rtk_photon_compact_scratch(uint32_t n_attempts);
+void rtk_photon_compact(hipStream_t, const float *recs, const uint32_t *count, uint32_t n_attempts, int mode, unsigned long long max_count,
+                        void *state_dev, rt_photon *out, uint32_t out_cap, void *scratch, size_t scratch_bytes);
+void rtk_photon_scale(hipStream_t, rt_photon *ph, uint32_t n, float scale);
+void rtk_photon_copy_skipping(hipStream_t, const rt_photon *in, uint32_t n_in, const uint32_t *skip, uint32_t n_skip, rt_photon *out);
+size_t rtk_photon_structure_scratch(uint32_t n, uint32_t n_sub);
+hipError_t rtk_photon_structure(hipStream_t, const rt_photon *ph, uint32_t n, uint32_t n_sub, float4 *pa, float4 *pb, float4 *box4,
+                                uint32_t *grid, PhotonGridOut *grid_out, void *scratch, size_t scratch_bytes);
 
 // ---- errors ---------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -94,6 +104,7 @@ extern "C" void rt_params_default(rt_params *p)
     p->min_sample = 4; p->max_sample = 8; p->threshold = 1e-3f; p->bounce = 4;      // FIN/main.cpp:19-26
     p->hemisphere_sample = 30; p->knn_k = 400; p->knn_radius = 1.0f;                // :26, :699
     p->shade_model = RT_SHADE_FIN; p->shadow_samples = 4; p->seed = 20171203u; p->gamma = 2.2;
+    p->photon_count = 1000000; p->photon_bounce = 8;                                // MAX_NUM_OF_PHOTON, PHOTON_BOUNCE (:27, :29)
 }
 
 // ---- device buffers --------------------------------------------------------------------------------
@@ -143,8 +154,9 @@ struct DeviceState {
     bool scene_valid = false, photons_valid = false, caustic_valid = false;
     DevBuf nodes, objects, meshes, materials, lights, node_material, textures, texels, material_maps;
     std::vector<DevMeshBufs> mesh_bufs;
-    DevBuf pa, pb, tbox, sbox, grid;
-    DevBuf cpa, cpb, ctbox, csbox, cgrid;       // the caustic map
+    DevBuf pa, pb, box4, grid;                  // the gather structure of the photon map (rt_photon_build.hip)
+    DevBuf cpa, cpb, cbox4, cgrid;              // ... of the caustic map
+    DevBuf raw_photons;                         // 24-byte photons of the last photon pass on this device (1-based)
     DevScene scene{};
     Workspace ws[RT_STREAMS];
     DevBuf stats;
@@ -153,6 +165,7 @@ struct DeviceState {
     // stats: `last_done` is recorded at its join and every later call orders its own stream behind it
     hipEvent_t last_done = nullptr;
     bool last_pending = false;
+    bool async_overflow = false;        // an asynchronous render dropped rays and nobody has collected that verdict yet (rt_render_check does)
     // How full the ray / photon-query queues of the last renders got, per sample of a chunk (device-side peaks,
     // rt_stats.peak_*): the next render of the same kind sizes its queues from that instead of the 2^bounce worst case.
     struct QueueHistory { bool valid = false; int model = -1, bounce = -1, fan = -1; bool photons = false, caustic = false;
@@ -163,8 +176,8 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     void release()
     {
-        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &tbox, &sbox, &grid, &cpa, &cpb, &ctbox, &csbox, &cgrid,
-                          &stats, &t_in}) b->release();
+        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &box4, &grid, &cpa, &cpb, &cbox4, &cgrid,
+                          &raw_photons, &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
         for (Workspace &w : ws) w.release();
         for (int k = 0; k < 6; k++) t_out[k].release();
@@ -188,9 +201,18 @@ struct DeviceClaim {
 
 struct rt_scene {
     rt::SceneData data;
+    // A photon map made by rt_scene_generate_photons is kept as generatePhotonMap leaves it BEFORE balancing (1-based,
+    // [0] zero) together with the indices of the few photons LocatePhotons could not reach after balancing
+    // (rt::UnreachablePhotons); data.photons (the balanced form) is produced from it only when somebody asks for it.
+    // Non-empty photons_raw takes precedence over data.photons; rt_scene_set_photons clears it.
+    std::vector<rt_photon> photons_raw;
+    std::vector<uint32_t> photons_skip;
+    std::string photon_dump;            // where rt_render_begin's photon pass writes its .dat ("" = nowhere)
+    std::mutex gen_mu;                  // jobs started together on several devices: ONE of them runs the photon pass, the others wait for it
     std::mutex mu;
     std::vector<DeviceState *> devs;
     std::atomic<int> live_jobs{0};
+    uint32_t photon_count() const { return !photons_raw.empty() ? (uint32_t)photons_raw.size() - 1 : (data.photons.empty() ? 0u : (uint32_t)data.photons.size() - 1); }
     void invalidate(bool scene, bool photons, bool caustic = false)
     {
         for (DeviceState *d : devs) { if (scene) d->scene_valid = false; if (photons) d->photons_valid = false; if (caustic) d->caustic_valid = false; }
@@ -210,6 +232,7 @@ struct rt_job {
     // viewer that polls rt_render_progress can show the frame as it fills (viewport.cpp:367 reads
     // renderImage.GetPixels() while the workers run)
     uint8_t *host_rgb = nullptr, *host_count = nullptr; float *host_z = nullptr;
+    rt_setup_ms setup{};                // the photon pass this job ran first (all zero when it did not)
 };
 
 // ---- scene store ---------------------------------------------------------------------------------------
@@ -460,6 +483,7 @@ extern "C" rt_status rt_scene_set_photons(rt_scene *s, const rt_photon *photons,
     if (st) return st;
     if (n_stored > 0 && !photons) return fail(RT_ERR_ARG, "rt_scene_set_photons: photons is NULL");
     std::lock_guard<std::mutex> lk(s->mu);
+    s->photons_raw.clear(); s->photons_skip.clear();
     if (n_stored == 0) s->data.photons.clear();
     else s->data.photons.assign(photons, photons + (size_t)n_stored + 1);
     s->invalidate(false, true);
@@ -511,7 +535,7 @@ extern "C" rt_status rt_scene_counts(const rt_scene *s, int32_t *n_nodes, int32_
     if (n_meshes) *n_meshes = (int32_t)s->data.meshes.size();
     if (n_materials) *n_materials = (int32_t)s->data.materials.size();
     if (n_lights) *n_lights = (int32_t)s->data.lights.size();
-    if (n_photons) *n_photons = s->data.photons.empty() ? 0u : (uint32_t)(s->data.photons.size() - 1);
+    if (n_photons) *n_photons = s->photon_count();
     return RT_OK;
 }
 
@@ -602,6 +626,19 @@ extern "C" rt_status rt_photon_balance(rt_photon *in, uint32_t n, rt_photon *out
 {
     if (!in || !out) return fail(RT_ERR_ARG, "rt_photon_balance: NULL argument");
     rt::BalancePhotons(in, n, out);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_photon_unreachable(const rt_photon *in, uint32_t n, uint32_t *raw_indices, uint32_t cap, uint32_t *count)
+{
+    if (!in || !count) return fail(RT_ERR_ARG, "rt_photon_unreachable: NULL argument");
+    std::vector<uint32_t> idx;
+    rt::UnreachablePhotons(in, n, idx);
+    *count = (uint32_t)idx.size();
+    if (raw_indices) {
+        if (cap < idx.size()) return fail(RT_ERR_ARG, "rt_photon_unreachable: room for %u indices, %zu needed", cap, idx.size());
+        if (!idx.empty()) memcpy(raw_indices, idx.data(), idx.size() * 4);
+    }
     return RT_OK;
 }
 
@@ -797,135 +834,80 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
     return RT_OK;
 }
 
-// Photon::GetDirection (FIN/include/cyPhotonMap.h:158-180), including the reference's
-// `dirX*dirX + dirY-dirY` (:162): z is derived from x alone.
-static void photon_direction(const rt_photon &p, float d[3])
+// Gather structure of a photon map (rt_dev.h, built by rt_photon_build.hip on the GPU): the photons LocatePhotons can reach
+// -- it descends only while index < halfStoredPhotons = n/2 - 1, cyPhotonMap.h:217,371, so heap slots >= 2*half are never
+// visited: for a balanced array that is a prefix, for an unbalanced one everything but the `skip` indices -- re-sorted by
+// recursive median splits into 2^D sub-leaves of <= RT_SUB_PHOTONS photons with their tight boxes; RT_LEAF_SUBS consecutive
+// sub-leaves are one leaf (128 slots) of the tree the queries walk (boxes of all heap nodes in `box4`: the tree over the
+// leaves is its head, the sub-leaf boxes its last level).  `src_dev` != NULL: the photons already sit on this device
+// (n_src records, 0-based); else they are uploaded from `src_host`.  skip: ascending 0-based positions to leave out.
+static rt_status build_photon_structure(DeviceState *D, bool caustic, const rt_photon *src_dev, const rt_photon *src_host, uint32_t n_src,
+                                        const uint32_t *skip, uint32_t n_skip, double *ms_upload, double *ms_build)
 {
-    const int dirX = p.dir_x, dirY = p.dir_y;
-    d[0] = (float)dirX / (float)0x7FFF;
-    d[1] = (float)dirY / (float)0x7FFF;
-    int dirXY2 = dirX * dirX + dirY - dirY;
-    if (dirXY2 > 0x3FFF0001) dirXY2 = 0x3FFF0001;
-    const int dirZ2 = 0x3FFF0001 - dirXY2;
-    int dirZ = 0, place = 0x40000000, remainder = dirZ2;
-    while (place > remainder) place >>= 2;
-    while (place) {
-        if (remainder >= dirZ + place) { remainder -= dirZ + place; dirZ += place << 1; }
-        dirZ >>= 1;
-        place >>= 2;
-    }
-    d[2] = (float)dirZ / (float)0x7FFF;
-    if (p.plane_and_dirz & 0x8) d[2] = -d[2];
-}
-
-struct PRec { float pos[3], dir[3], maxp; uint32_t color; };
-
-// Gather structure: the photons LocatePhotons can reach (it descends only while index <
-// halfStoredPhotons = n/2 - 1, cyPhotonMap.h:217,371, so indices >= 2*half are never visited)
-// re-sorted by recursive median splits into 2^D sub-leaves of <= 32 photons with their tight boxes
-// (sbox); every four consecutive sub-leaves are one leaf of the tree the queries walk, whose
-// subtree boxes are kept in heap order (tbox).
-static rt_status upload_photons(rt_scene *s, DeviceState *D, bool caustic)
-{
+    using clk = std::chrono::steady_clock;
     DevPhotonMap &pm = caustic ? D->scene.cm : D->scene.pm;
     memset(&pm, 0, sizeof pm);
     (caustic ? D->caustic_valid : D->photons_valid) = true;
-    const std::vector<rt_photon> &ph = caustic ? s->data.caustic_photons : s->data.photons;
-    DevBuf &b_pa = caustic ? D->cpa : D->pa, &b_pb = caustic ? D->cpb : D->pb, &b_tbox = caustic ? D->ctbox : D->tbox,
-           &b_sbox = caustic ? D->csbox : D->sbox, &b_grid = caustic ? D->cgrid : D->grid;
-    if (ph.size() < 2) return RT_OK;
-    const uint32_t n = (uint32_t)ph.size() - 1;
-    const long long half = (long long)(n / 2) - 1;
-    long long reach = 2 * half - 1;
-    if (reach < 1) reach = 1;
-    if (reach > (long long)n) reach = n;
-    std::vector<PRec> recs((size_t)reach);
-    for (long long i = 1; i <= reach; i++) {
-        const rt_photon &p = ph[(size_t)i];
-        PRec &r = recs[(size_t)i - 1];
-        memcpy(r.pos, p.position, 12);
-        photon_direction(p, r.dir);
-        r.maxp = p.power;                                               // GetMaxPower :60
-        // GetPower :58 = Color(color) * power, Color24 -> Color = byte / 255.0f (cyColor.h): the device
-        // forms the correctly rounded byte / 255.0f itself and multiplies by power, the same two roundings
-        r.color = (uint32_t)p.color[0] | ((uint32_t)p.color[1] << 8) | ((uint32_t)p.color[2] << 16);
-    }
+    DevBuf &b_pa = caustic ? D->cpa : D->pa, &b_pb = caustic ? D->cpb : D->pb, &b_box = caustic ? D->cbox4 : D->box4, &b_grid = caustic ? D->cgrid : D->grid;
+    if (n_src <= n_skip) return RT_OK;
+    const uint32_t n = n_src - n_skip;
     uint32_t n_leaves = 1;
-    while ((size_t)n_leaves * RT_LEAF_SUBS * RT_SUB_PHOTONS < recs.size()) n_leaves <<= 1;
-    // leaf ids travel as 16-bit values through the kernel's LDS lists
-    if (n_leaves > 65536) return fail(RT_ERR_LIMIT, "photon map too large for the gather structure (%zu photons, at most 8 Mi)", recs.size());
-    const uint32_t n_sub = n_leaves * RT_LEAF_SUBS;
-    std::vector<float> hbox(6 * 2 * (size_t)n_sub);                     // boxes of the whole heap down to the sub-leaves
-    // one more sub-leaf than the tree has, every slot empty: the kernel pads its sub-leaf lists with it; slots are
-    // addressed by 32-bit byte offsets (at most 2^18 + 1 sub-leaves of 512 bytes)
-    std::vector<float4> pa(((size_t)n_sub + 1) * RT_SUB_PHOTONS), pb(pa.size());
+    while ((size_t)n_leaves * RT_LEAF_SUBS * RT_SUB_PHOTONS < n) n_leaves <<= 1;
+    // leaf ids travel as 16-bit values through the kernel's LDS lists; slots are addressed by 32-bit byte offsets
+    if (n_leaves > 65536) return fail(RT_ERR_LIMIT, "photon map too large for the gather structure (%u photons, at most 8 Mi)", n);
     static_assert((65536ull * RT_LEAF_SUBS + 1) * RT_SUB_PHOTONS * sizeof(float4) <= 0xFFFFFFFFull, "photon slots are addressed by 32-bit byte offsets");
-    for (size_t i = 0; i < pa.size(); i++) { pa[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0); pb[i] = make_float4(0, 0, 0, 0); }
-    struct Build {
-        std::vector<PRec> &r; std::vector<float> &hbox; std::vector<float4> &pa, &pb; uint32_t n_sub;
-        void go(uint32_t node, size_t lo, size_t hi)
-        {
-            float *b = &hbox[6 * (size_t)node];
-            b[0] = b[1] = b[2] = 3.0e38f; b[3] = b[4] = b[5] = -3.0e38f;
-            for (size_t i = lo; i < hi; i++) for (int a = 0; a < 3; a++) { b[a] = std::min(b[a], r[i].pos[a]); b[3 + a] = std::max(b[3 + a], r[i].pos[a]); }
-            if (node >= n_sub) {
-                const size_t base = (size_t)(node - n_sub) * RT_SUB_PHOTONS;
-                for (size_t i = lo; i < hi; i++) {
-                    const PRec &q = r[i];
-                    pa[base + (i - lo)] = make_float4(q.pos[0], q.pos[1], q.pos[2], q.dir[0]);
-                    float cbits;
-                    memcpy(&cbits, &q.color, 4);
-                    pb[base + (i - lo)] = make_float4(q.dir[1], q.dir[2], q.maxp, cbits);
-                }
-                return;
-            }
-            int axis = 0;
-            const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
-            if (ey > ex && ey >= ez) axis = 1; else if (ez > ex && ez > ey) axis = 2;
-            const size_t mid = lo + (hi - lo + 1) / 2;
-            if (hi - lo > 1) std::nth_element(r.begin() + lo, r.begin() + mid, r.begin() + hi,
-                                              [axis](const PRec &x, const PRec &y) { return x.pos[axis] < y.pos[axis]; });
-            go(2 * node, lo, mid);
-            go(2 * node + 1, mid, hi);
-        }
-    } B{recs, hbox, pa, pb, n_sub};
-    B.go(1, 0, recs.size());
-    // heap node ids of a complete binary tree do not depend on its depth: the first 2*n_leaves boxes ARE the tree
-    // over the leaves, the last n_sub ones the sub-leaf boxes
-    const std::vector<float> tbox(hbox.begin(), hbox.begin() + 6 * 2 * (size_t)n_leaves);
-    // device form of a box: two aligned 16-byte words (lo.xyz, 0), (hi.xyz, 0)
-    auto pad_boxes = [](const float *b6, size_t n) {
-        std::vector<float4> out(2 * n);
-        for (size_t i = 0; i < n; i++) { out[2 * i] = make_float4(b6[6 * i], b6[6 * i + 1], b6[6 * i + 2], 0.f); out[2 * i + 1] = make_float4(b6[6 * i + 3], b6[6 * i + 4], b6[6 * i + 5], 0.f); }
-        return out;
-    };
-    const std::vector<float4> tbox4 = pad_boxes(tbox.data(), 2 * (size_t)n_leaves), sbox4 = pad_boxes(&hbox[6 * (size_t)n_sub], n_sub);
+    const uint32_t n_sub = n_leaves * RT_LEAF_SUBS;
     rt_status st;
-    if ((st = b_pa.upload(pa.data(), pa.size() * sizeof(float4)))) return st;
-    if ((st = b_pb.upload(pb.data(), pb.size() * sizeof(float4)))) return st;
-    if ((st = b_tbox.upload(tbox4.data(), tbox4.size() * sizeof(float4)))) return st;
-    if ((st = b_sbox.upload(sbox4.data(), sbox4.size() * sizeof(float4)))) return st;
-    pm.pa = (const float4 *)b_pa.p; pm.pb = (const float4 *)b_pb.p; pm.tbox = (const float4 *)b_tbox.p; pm.sbox = (const float4 *)b_sbox.p;
-    pm.n_leaves = n_leaves; pm.n_photons = (uint32_t)recs.size();
-    {   // density grid over the photons' bounding box, at most 64 cells along the longest axis
-        const float *rb = &tbox[6];
-        float ext = std::max(std::max(rb[3] - rb[0], rb[4] - rb[1]), rb[5] - rb[2]);
-        if (!(ext > 0)) ext = 1.0f;
-        const float cell = ext / 64.0f;
-        int dim[3];
-        for (int a = 0; a < 3; a++) dim[a] = std::min(64, std::max(1, (int)std::floor((rb[3 + a] - rb[a]) / cell) + 1));
-        std::vector<uint32_t> grid((size_t)dim[0] * dim[1] * dim[2], 0u);
-        for (const PRec &q : recs) {
-            int g[3];
-            for (int a = 0; a < 3; a++) g[a] = std::min(dim[a] - 1, std::max(0, (int)((q.pos[a] - rb[a]) / cell)));
-            grid[((size_t)g[2] * dim[1] + g[1]) * dim[0] + g[0]]++;
-        }
-        if ((st = b_grid.upload(grid.data(), grid.size() * 4))) return st;
-        pm.grid = (const uint32_t *)b_grid.p;
-        for (int a = 0; a < 3; a++) { pm.grid_min[a] = rb[a]; pm.grid_dim[a] = dim[a]; }
-        pm.cell = cell; pm.inv_cell = 1.0f / cell;
+    hipStream_t stream = D->stream;
+    const auto t0 = clk::now();
+    DevBuf staged, compacted, scratch;
+    const rt_photon *ph = src_dev;
+    if (!ph) {
+        if ((st = staged.ensure((size_t)n_src * sizeof(rt_photon)))) return st;
+        HIP_TRY(hipMemcpyAsync(staged.p, src_host, (size_t)n_src * sizeof(rt_photon), hipMemcpyHostToDevice, stream));
+        ph = (const rt_photon *)staged.p;
     }
+    if (n_skip) {
+        if ((st = compacted.ensure((size_t)n * sizeof(rt_photon)))) { staged.release(); return st; }
+        rtk_photon_copy_skipping(stream, ph, n_src, skip, n_skip, (rt_photon *)compacted.p);
+        ph = (const rt_photon *)compacted.p;
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    const auto t1 = clk::now();
+    // one more sub-leaf than the tree has, every slot empty: the kernel pads its sub-leaf lists with it
+    const size_t slots = ((size_t)n_sub + 1) * RT_SUB_PHOTONS;
+    const size_t sbytes = rtk_photon_structure_scratch(n, n_sub);
+    if ((st = b_pa.ensure(slots * sizeof(float4))) || (st = b_pb.ensure(slots * sizeof(float4))) || (st = b_box.ensure((size_t)4 * n_sub * sizeof(float4))) ||
+        (st = b_grid.ensure((size_t)64 * 64 * 64 * 4)) || (st = scratch.ensure(sbytes))) { staged.release(); compacted.release(); scratch.release(); return st; }
+    PhotonGridOut g;
+    const hipError_t e = rtk_photon_structure(stream, ph, n, n_sub, (float4 *)b_pa.p, (float4 *)b_pb.p, (float4 *)b_box.p, (uint32_t *)b_grid.p, &g, scratch.p, sbytes);
+    hipError_t e2 = hipStreamSynchronize(stream);
+    staged.release(); compacted.release(); scratch.release();
+    if (e != hipSuccess || e2 != hipSuccess) return fail(RT_ERR_DEVICE, "photon structure build failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    pm.pa = (const float4 *)b_pa.p; pm.pb = (const float4 *)b_pb.p;
+    pm.tbox = (const float4 *)b_box.p; pm.sbox = (const float4 *)b_box.p + 2 * (size_t)n_sub;
+    pm.n_leaves = n_leaves; pm.n_photons = n;
+    pm.grid = (const uint32_t *)b_grid.p;
+    for (int a = 0; a < 3; a++) { pm.grid_min[a] = g.min[a]; pm.grid_dim[a] = g.dim[a]; }
+    pm.cell = g.cell; pm.inv_cell = 1.0f / g.cell;
+    const auto t2 = clk::now();
+    if (ms_upload) *ms_upload += std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (ms_build) *ms_build += std::chrono::duration<double, std::milli>(t2 - t1).count();
     return RT_OK;
+}
+
+static rt_status upload_photons(rt_scene *s, DeviceState *D, bool caustic)
+{
+    if (!caustic && !s->photons_raw.empty()) {
+        // as generated (unbalanced): everything but the photons balancing would put out of LocatePhotons' reach
+        std::vector<uint32_t> skip0;
+        for (uint32_t i : s->photons_skip) skip0.push_back(i - 1);              // 1-based raw index -> position in [1..n]
+        return build_photon_structure(D, false, nullptr, s->photons_raw.data() + 1, (uint32_t)s->photons_raw.size() - 1, skip0.data(), (uint32_t)skip0.size(), nullptr, nullptr);
+    }
+    const std::vector<rt_photon> &ph = caustic ? s->data.caustic_photons : s->data.photons;
+    if (ph.size() < 2) { memset(caustic ? &D->scene.cm : &D->scene.pm, 0, sizeof(DevPhotonMap)); (caustic ? D->caustic_valid : D->photons_valid) = true; return RT_OK; }
+    const uint32_t n = (uint32_t)ph.size() - 1;
+    return build_photon_structure(D, caustic, nullptr, ph.data() + 1, rt::ReachablePhotonSlots(n), nullptr, 0, nullptr, nullptr);
 }
 
 static rt_status prepare_device(rt_scene *s, int device, DeviceState **out)
@@ -939,6 +921,9 @@ static rt_status prepare_device(rt_scene *s, int device, DeviceState **out)
     DeviceState *D = device_state(s, device);
     if (!D->stream) HIP_TRY(hipStreamCreateWithFlags(&D->stream, hipStreamNonBlocking));
     rt_status st;
+    // an asynchronous render (sync == 0) may still be reading the buffers an upload is about to overwrite (scene tables and
+    // photon structure are re-used in place when the new data fits): wait for it on the host first
+    if ((!D->scene_valid || !D->photons_valid || !D->caustic_valid) && D->last_pending && D->last_done) HIP_TRY(hipEventSynchronize(D->last_done));
     if (!D->scene_valid) { const DevPhotonMap keep = D->scene.pm, keepc = D->scene.cm; if ((st = upload_scene(s, D))) return st; D->scene.pm = keep; D->scene.cm = keepc; }
     if (!D->photons_valid) if ((st = upload_photons(s, D, false))) return st;
     if (!D->caustic_valid) if ((st = upload_photons(s, D, true))) return st;
@@ -1087,6 +1072,8 @@ static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const 
     if (p->caustic_k < 0 || p->caustic_k > 65536 || (p->caustic_k > 0 && !(p->caustic_radius > 0))) return fail(RT_ERR_ARG, "render: bad caustic gather parameters");
     if (t->tile_w <= 0 || t->tile_h <= 0 || t->stride <= 0 || t->first < 0) return fail(RT_ERR_ARG, "render: bad tile range");
     if (p->shadow_samples > 32) return fail(RT_ERR_LIMIT, "render: at most 32 shadow samples per light");
+    if (p->photon_count < 0 || p->photon_count > (1 << 28) || (p->photon_count > 0 && (p->photon_bounce < 1 || p->photon_bounce > 8)))
+        return fail(RT_ERR_ARG, "render: need 0 <= photon_count <= 2^28 and 1 <= photon_bounce <= 8");
     return RT_OK;
 }
 
@@ -1173,6 +1160,15 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     hipStream_t stream = use_user_stream ? user_stream : D->stream;
     if ((st = order_after_pending(D, stream))) return st;
     if (!D->last_done) HIP_TRY(hipEventCreateWithFlags(&D->last_done, hipEventDisableTiming));
+    if (D->last_pending && (sync || stats_out != nullptr || job != nullptr)) {
+        // this call will clear and read the shared drop counter: the verdict of the asynchronous renders before it is
+        // collected first and kept for rt_render_check ("queue overflow is always reported")
+        HIP_TRY(hipEventSynchronize(D->last_done));
+        unsigned long long drops = 0;
+        if ((st = read_overflow(D, &drops))) return st;
+        if (drops) { D->async_overflow = true; D->qhist.valid = false; HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 0, 8)); }
+        D->last_pending = false;
+    }
 
     DevCamera dc;
     camera_setup(*cam, dc);
@@ -1223,9 +1219,32 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         n_ready++;
     }
     n_slots = n_ready;
+    // a job that owns only some of the tiles renders into packed records of its own (see finish_oldest)
+    const bool job_packed = job != nullptr && tiles->stride != 1;
+    DevBuf job_packed_buf;
+    struct Release { DevBuf &b; ~Release() { b.release(); } } job_packed_release{job_packed_buf};
+    if (job_packed) {
+        if ((st = job_packed_buf.ensure(std::max<uint64_t>(total_px, 1) * 8))) return st;
+        packed_dev = job_packed_buf.p;
+    }
     const bool want_stats = stats_out != nullptr || job != nullptr;
     Timing tm[RT_STREAMS];
     hipEvent_t e_begin = nullptr, e_end = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> resolve_ev;
+    struct InFlight { uint64_t q0; uint32_t npix; hipEvent_t done; };
+    std::vector<InFlight> flight;
+    // every timing / completion event of this attempt is destroyed when the function is left, on whichever path
+    struct EventGuard {
+        Timing *tm; hipEvent_t &b, &e; std::vector<std::pair<hipEvent_t, hipEvent_t>> &rv; std::vector<InFlight> &fl;
+        ~EventGuard()
+        {
+            for (int sl = 0; sl < RT_STREAMS; sl++) for (hipEvent_t x : tm[sl].ev) (void)hipEventDestroy(x);
+            if (b) (void)hipEventDestroy(b);
+            if (e) (void)hipEventDestroy(e);
+            for (auto &pr : rv) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+            for (InFlight &f : fl) (void)hipEventDestroy(f.done);
+        }
+    } event_guard{tm, e_begin, e_end, resolve_ev, flight};
     if (want_stats) {
         HIP_TRY(hipMemsetAsync(Ws[0].stats, 0, ST_COUNT * 8, stream));
         HIP_TRY(hipEventCreate(&e_begin)); HIP_TRY(hipEventCreate(&e_end));
@@ -1248,10 +1267,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     }
     const float inv_gamma = (float)(1.0 / p->gamma);        // powf(x, 1.0/gamma): double quotient narrowed to float
     double ms_resolve = 0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> resolve_ev;
     // chunks in flight (job mode): finished oldest-first for progress and the band copy
-    struct InFlight { uint64_t q0; uint32_t npix; hipEvent_t done; };
-    std::vector<InFlight> flight;
     int attempt_progress = 0;
     auto finish_oldest = [&]() -> rt_status {
         const InFlight f = flight.front();
@@ -1266,7 +1282,26 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
             const int w = std::min(dt.tile_w, cam->width - tx * dt.tile_w), h = std::min(dt.tile_h, cam->height - ty * dt.tile_h);
             if (w > 0 && h > 0) done += w * h;
         }
-        if (job->host_rgb) {
+        if (job->host_rgb && job_packed) {
+            // a strided tile range (one job per device on the same caller-owned image): rows are shared with other jobs' tiles,
+            // so only this job's pixels may be written -- the chunk's packed 8-byte records come back in one copy and are
+            // scattered on the host
+            std::vector<uint2> rec(f.npix);
+            HIP_TRY(hipMemcpy(rec.data(), (const uint2 *)packed_dev + f.q0, (size_t)f.npix * 8, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < f.npix; i++) {
+                const uint64_t q = f.q0 + i;
+                const int t = dt.first + (int)(q / tile_px) * dt.stride;
+                const int w = (int)(q % tile_px);
+                const int x = (t % dt.tiles_x) * dt.tile_w + w % dt.tile_w, y = (t / dt.tiles_x) * dt.tile_h + w / dt.tile_w;
+                if (x >= cam->width || y >= cam->height) continue;
+                const size_t o = (size_t)y * cam->width + x;
+                const uint2 v = rec[i];
+                job->host_rgb[3 * o] = (uint8_t)(v.x & 255u); job->host_rgb[3 * o + 1] = (uint8_t)((v.x >> 8) & 255u); job->host_rgb[3 * o + 2] = (uint8_t)((v.x >> 16) & 255u);
+                const uint32_t zb = (v.x >> 24) | (v.y << 8);
+                memcpy(&job->host_z[o], &zb, 4);
+                job->host_count[o] = (uint8_t)(v.y >> 24);
+            }
+        } else if (job->host_rgb) {
             // rows spanned by this chunk's tiles (tile-major order: a contiguous band of tile rows; a row shared
             // with a chunk still in flight may arrive torn and is copied again when that chunk finishes)
             const uint64_t k0 = f.q0 / tile_px, k1 = (f.q0 + f.npix - 1) / tile_px;
@@ -1382,14 +1417,11 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
             ms_resolve += ms; R.launches_resolve++;
-            (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
         }
         R.ms_resolve = ms_resolve;
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, e_begin, e_end));
         R.ms_total = ms;
-        for (int sl = 0; sl < RT_STREAMS; sl++) for (hipEvent_t e : tm[sl].ev) (void)hipEventDestroy(e);
-        (void)hipEventDestroy(e_begin); (void)hipEventDestroy(e_end);
         for (uint64_t k = 0; k < (uint64_t)dt.n_tiles; k++) {
             const int t = dt.first + (int)k * dt.stride;
             const int tx = t % dt.tiles_x, ty = t / dt.tiles_x;
@@ -1467,18 +1499,25 @@ extern "C" rt_status rt_render_check(rt_scene *s, int device)
     HIP_TRY(hipSetDevice(device));
     DeviceClaim claim(D);
     if (!claim.ok) return fail(RT_ERR_STATE, "rt_render_check: another call on this scene is using device %d", device);
-    if (D->last_pending && D->last_done) HIP_TRY(hipEventSynchronize(D->last_done));
-    D->last_pending = false;
     unsigned long long drops = 0;
-    rt_status st = read_overflow(D, &drops);
-    if (st) return st;
-    if (drops) {
+    if (D->last_pending && D->last_done) {
+        HIP_TRY(hipEventSynchronize(D->last_done));
+        D->last_pending = false;
+        rt_status st = read_overflow(D, &drops);
+        if (st) return st;
+    }
+    const bool earlier = D->async_overflow;
+    D->async_overflow = false;
+    if (drops || earlier) {
         D->qhist.valid = false;                             // the next render starts from the worst case again
-        HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 0, 8));
+        if (drops) HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 0, 8));
         return fail(RT_ERR_LIMIT, "rt_render_check: a ray/photon queue overflowed (%llu drops) in an asynchronous render", drops);
     }
     return RT_OK;
 }
+
+static rt_status generate_photons(rt_scene *s, int device, uint32_t max_photons, int photon_bounce, uint32_t seed, const char *dat_path,
+                                  rt_setup_ms *ms_out, bool own_job);
 
 extern "C" rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt_params *p, const rt_tile_range *tiles, int device,
                                      uint8_t *rgb8, float *z, uint8_t *count, rt_job **out)
@@ -1500,6 +1539,20 @@ extern "C" rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt
         uint8_t *d_rgb = nullptr, *d_cnt = nullptr; float *d_z = nullptr;
         auto body = [&]() -> rt_status {
             HIP_TRY(hipSetDevice(device));
+            // BeginRender calls generatePhotonMap() before it spawns its workers (FIN/main.cpp:984-998, :350-402); here the
+            // photon pass runs on the job's thread, so the call itself still returns at once and progress stays 0 meanwhile
+            if (pv.shade_model == RT_SHADE_FIN && pv.photon_count > 0) {
+                std::lock_guard<std::mutex> gen(s->gen_mu);         // one job per device may have been started: the first one generates
+                bool have_map, have_source = false;
+                std::string dump;
+                { std::lock_guard<std::mutex> lk(s->mu); have_map = s->photon_count() != 0; dump = s->photon_dump; }
+                for (const rt_light &l : s->data.lights) if (l.type == RT_LIGHT_POINT) have_source = true;
+                if (!have_map && have_source && !job->stop.load()) {
+                    const rt_status g = generate_photons(s, device, (uint32_t)pv.photon_count, pv.photon_bounce, pv.seed, dump.empty() ? nullptr : dump.c_str(),
+                                                         &job->setup, true);
+                    if (g) return g;
+                }
+            }
             HIP_TRY(hipMalloc((void **)&d_rgb, npx * 3)); HIP_TRY(hipMalloc((void **)&d_z, npx * 4)); HIP_TRY(hipMalloc((void **)&d_cnt, npx));
             HIP_TRY(hipMemcpy(d_rgb, rgb8, npx * 3, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(d_z, z, npx * 4, hipMemcpyHostToDevice));
@@ -1534,6 +1587,13 @@ extern "C" rt_status rt_job_stats(rt_job *j, rt_stats *out)
     if (!j || !out) return fail(RT_ERR_ARG, "rt_job_stats: NULL argument");
     if (!j->done.load()) return fail(RT_ERR_STATE, "rt_job_stats: job still running");
     *out = j->stats;
+    return RT_OK;
+}
+extern "C" rt_status rt_job_setup_ms(rt_job *j, rt_setup_ms *out)
+{
+    if (!j || !out) return fail(RT_ERR_ARG, "rt_job_setup_ms: NULL argument");
+    if (!j->done.load()) return fail(RT_ERR_STATE, "rt_job_setup_ms: job still running");
+    *out = j->setup;
     return RT_OK;
 }
 extern "C" void rt_job_destroy(rt_job *j)
@@ -1652,28 +1712,54 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
 }
 
 // ---- photon pass ----------------------------------------------------------------------------------------
-// Photon::SetDirection / SetPower via AddPhoton (FIN/include/cyPhotonMap.h:139-156,184-192)
-static void pack_photon(const float *rec, rt_photon &o)
-{
-    memset(&o, 0, sizeof o);
-    memcpy(o.position, rec, 12);
-    o.dir_x = (int16_t)(rec[3] * 0x7FFF);
-    o.dir_y = (int16_t)(rec[4] * 0x7FFF);
-    o.plane_and_dirz = rec[5] > 0 ? 0 : 0x8;
-    float power = rec[6];
-    if (power < rec[7]) power = rec[7];
-    if (power < rec[8]) power = rec[8];
-    o.power = power;
-    for (int c = 0; c < 3; c++) {
-        const float s = (rec[6 + c] / power) * 255;
-        const int v = (s == s) ? (int)s : 0;
-        o.color[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
-    }
-}
-
 // generatePhotonMap's two loops (P13/main.cpp:338-404): mode 0 = the photon map (stop when max_count photons are STORED),
 // mode 1 = the caustic map (stop when max_count diffuse hits are COUNTED; only those behind more than one specular
 // hit are stored).  Attempts are consumed in order, the count checked between attempts like the reference's while().
+// Everything stays on the device: k_photon_trace writes each attempt's photons, rtk_photon_compact (rt_photon_build.hip)
+// consumes the attempts in order and packs the stored photons into D->raw_photons (1-based, [0] zero), then
+// ScalePhotonPowers.  The caller holds the device claim.
+struct CompactStateHost { unsigned long long attempts, counted; uint32_t stored, pad; };
+static rt_status photon_pass_device(rt_scene *s, DeviceState *D, uint32_t max_count, int photon_bounce, uint32_t seed, int mode,
+                                    uint32_t *n_out, uint64_t *attempts_out, const char *who)
+{
+    if (max_count == 0 || photon_bounce < 1 || photon_bounce > 8) return fail(RT_ERR_ARG, "%s: need a positive count and 1 <= photon_bounce <= 8", who);
+    if (max_count > (1u << 28)) return fail(RT_ERR_LIMIT, "%s: at most 2^28 photons", who);
+    bool have_source = false;
+    for (const rt_light &l : s->data.lights) if (l.type == RT_LIGHT_POINT) have_source = true;
+    if (!have_source) return fail(RT_ERR_STATE, "%s: the scene has no photon source (point light)", who);
+    rt_status st;
+    const uint32_t batch = 1u << 18;
+    const uint32_t out_cap = max_count + 8 + 1;                 // index 0 unused, up to 7 photons of overshoot
+    if ((st = D->t_out[0].ensure((size_t)batch * 8 * 9 * 4))) return st;
+    if ((st = D->t_out[1].ensure((size_t)batch * 4))) return st;
+    if ((st = D->t_out[2].ensure(2 * sizeof(CompactStateHost)))) return st;
+    const size_t sbytes = rtk_photon_compact_scratch(batch);
+    if ((st = D->t_out[3].ensure(sbytes))) return st;
+    if ((st = D->raw_photons.ensure((size_t)out_cap * sizeof(rt_photon)))) return st;
+    hipStream_t stream = D->stream;
+    HIP_TRY(hipMemsetAsync(D->t_out[2].p, 0, 2 * sizeof(CompactStateHost), stream));
+    HIP_TRY(hipMemsetAsync(D->raw_photons.p, 0, sizeof(rt_photon), stream));
+    CompactStateHost h{0, 0, 0, 0};
+    int empty_batches = 0;
+    while (h.counted < max_count) {
+        rtk_launch_photon_trace(stream, D->scene, h.attempts, batch, seed, photon_bounce, (float *)D->t_out[0].p, (uint32_t *)D->t_out[1].p, mode);
+        rtk_photon_compact(stream, (const float *)D->t_out[0].p, (const uint32_t *)D->t_out[1].p, batch, mode, max_count, D->t_out[2].p,
+                           (rt_photon *)D->raw_photons.p, out_cap, D->t_out[3].p, sbytes);
+        HIP_TRY(hipGetLastError());
+        const unsigned long long before = h.counted;
+        HIP_TRY(hipMemcpyAsync(&h, D->t_out[2].p, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h.counted == before && ++empty_batches >= 4) return fail(RT_ERR_STATE, "%s: no photon is ever stored in this scene", who);
+    }
+    uint32_t n = h.stored;
+    if (n + 1 > out_cap) n = out_cap - 1;
+    if (n > 0) rtk_photon_scale(stream, (rt_photon *)D->raw_photons.p, n, (float)(1.0 * 4 * M_PI / n));      // ScalePhotonPowers(1.0*4*M_PI/NumPhotons), :366 / :400
+    HIP_TRY(hipStreamSynchronize(stream));
+    *n_out = n;
+    if (attempts_out) *attempts_out = h.attempts;
+    return RT_OK;
+}
+
 static rt_status photon_pass(rt_scene *s, int device, uint32_t max_count, int photon_bounce, uint32_t seed, int mode,
                              rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out, const char *who)
 {
@@ -1683,44 +1769,13 @@ static rt_status photon_pass(rt_scene *s, int device, uint32_t max_count, int ph
     DeviceState *D = nullptr;
     rt_status st = prepare_device(s, device, &D);
     if (st) return st;
-    bool have_source = false;
-    for (const rt_light &l : s->data.lights) if (l.type == RT_LIGHT_POINT) have_source = true;
-    if (!have_source) return fail(RT_ERR_STATE, "%s: the scene has no photon source (point light)", who);
     DeviceClaim claim(D);
     if (!claim.ok) return fail(RT_ERR_STATE, "%s: another call on this scene is using device %d", who, device);
     if ((st = order_after_pending(D, D->stream))) return st;
-    const uint32_t batch = 1u << 18;
-    if ((st = D->t_out[0].ensure((size_t)batch * 8 * 9 * 4))) return st;
-    if ((st = D->t_out[1].ensure((size_t)batch * 4))) return st;
-    std::vector<float> recs((size_t)batch * 8 * 9);
-    std::vector<uint32_t> counts(batch);
-    uint32_t n = 0;                 // photons stored
-    uint64_t counted = 0;           // what the loop condition counts: stored photons (mode 0) or diffuse hits (mode 1)
-    uint64_t attempts = 0;
-    memset(&out[0], 0, sizeof(rt_photon));
-    int empty_batches = 0;
-    while (counted < max_count) {
-        rtk_launch_photon_trace(D->stream, D->scene, attempts, batch, seed, photon_bounce, (float *)D->t_out[0].p, (uint32_t *)D->t_out[1].p, mode);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(D->stream));
-        HIP_TRY(hipMemcpy(recs.data(), D->t_out[0].p, recs.size() * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(counts.data(), D->t_out[1].p, counts.size() * 4, hipMemcpyDeviceToHost));
-        const uint64_t before = counted;
-        uint32_t a = 0;
-        for (; a < batch && counted < max_count; a++) {    // the reference checks the count between attempts (:341, :383)
-            const uint32_t stored = counts[a] & 0xFFFFu, hits = counts[a] >> 16;
-            for (uint32_t j = 0; j < stored && n + 1 < out_cap; j++) pack_photon(&recs[((size_t)a * 8 + j) * 9], out[++n]);
-            counted += mode == 0 ? stored : hits;
-        }
-        attempts += a;
-        if (counted == before && ++empty_batches >= 4) return fail(RT_ERR_STATE, "%s: no photon is ever stored in this scene", who);
-    }
-    if (n > 0) {
-        const float scale = (float)(1.0 * 4 * M_PI / n);       // ScalePhotonPowers(1.0*4*M_PI/NumPhotons), :366 / :400
-        for (uint32_t i = 1; i <= n; i++) out[i].power *= scale;
-    }
+    uint32_t n = 0;
+    if ((st = photon_pass_device(s, D, max_count, photon_bounce, seed, mode, &n, attempts_out, who))) return st;
+    HIP_TRY(hipMemcpy(out, D->raw_photons.p, ((size_t)n + 1) * sizeof(rt_photon), hipMemcpyDeviceToHost));
     *n_out = n;
-    if (attempts_out) *attempts_out = attempts;
     return RT_OK;
 }
 
@@ -1734,4 +1789,91 @@ extern "C" rt_status rt_caustic_pass(rt_scene *s, int device, uint32_t max_diffu
                                      rt_photon *out, uint32_t out_cap, uint32_t *n_out, uint64_t *attempts_out)
 {
     return photon_pass(s, device, max_diffuse_hits, photon_bounce, seed, 1, out, out_cap, n_out, attempts_out, "rt_caustic_pass");
+}
+
+// generatePhotonMap as a whole (FIN/main.cpp:350-402).  `own_job`: called from the job thread of rt_render_begin (the scene
+// counts that job as live; no other caller can be inside the scene then).
+static rt_status generate_photons(rt_scene *s, int device, uint32_t max_photons, int photon_bounce, uint32_t seed, const char *dat_path,
+                                  rt_setup_ms *ms_out, bool own_job)
+{
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    if (!s) return fail(RT_ERR_ARG, "rt_scene_generate_photons: scene is NULL");
+    rt_status st;
+    if (!own_job && (st = check_idle(s, "rt_scene_generate_photons"))) return st;
+    rt_setup_ms T;
+    memset(&T, 0, sizeof T);
+    const auto t_begin = clk::now();
+    DeviceState *D = nullptr;
+    if ((st = prepare_device(s, device, &D))) return st;
+    DeviceClaim claim(D);
+    if (!claim.ok) return fail(RT_ERR_STATE, "rt_scene_generate_photons: another call on this scene is using device %d", device);
+    if ((st = order_after_pending(D, D->stream))) return st;
+    if (D->last_pending && D->last_done) HIP_TRY(hipEventSynchronize(D->last_done));       // the structure is rebuilt in place
+    const auto t0 = clk::now();
+    uint32_t n = 0;
+    if ((st = photon_pass_device(s, D, max_photons, photon_bounce, seed, 0, &n, nullptr, "rt_scene_generate_photons"))) return st;
+    const auto t1 = clk::now();
+    T.photon_pass = ms(t0, t1);
+    // the unbalanced photons come to the host once: for the dump, for the few that balancing would put out of
+    // LocatePhotons' reach, for other devices and for rt_scene_get_photons
+    std::vector<rt_photon> raw((size_t)n + 1);
+    HIP_TRY(hipMemcpy(raw.data(), D->raw_photons.p, raw.size() * sizeof(rt_photon), hipMemcpyDeviceToHost));
+    const auto t2 = clk::now();
+    T.upload = ms(t1, t2);
+    if (dat_path && dat_path[0] && (st = rt_photons_write_dat(dat_path, raw.data(), n))) return st;
+    const auto t2b = clk::now();
+    std::vector<uint32_t> skip;
+    rt::UnreachablePhotons(raw.data(), n, skip);
+    const auto t3 = clk::now();
+    T.balance = ms(t2b, t3);
+    std::vector<uint32_t> skip0;
+    for (uint32_t i : skip) skip0.push_back(i - 1);
+    double up = 0, build = 0;
+    if ((st = build_photon_structure(D, false, (const rt_photon *)D->raw_photons.p + 1, nullptr, n, skip0.data(), (uint32_t)skip0.size(), &up, &build))) return st;
+    T.upload += up; T.structure_build = build;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->data.photons.clear();
+        s->photons_raw.swap(raw);
+        s->photons_skip.swap(skip);
+        for (DeviceState *d : s->devs) if (d != D) d->photons_valid = false;
+    }
+    T.total = ms(t_begin, clk::now());
+    if (ms_out) *ms_out = T;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_generate_photons(rt_scene *s, int device, uint32_t max_photons, int photon_bounce, uint32_t seed,
+                                               const char *dat_path, rt_setup_ms *ms_out)
+{
+    return generate_photons(s, device, max_photons, photon_bounce, seed, dat_path, ms_out, false);
+}
+
+extern "C" rt_status rt_scene_set_photon_dump(rt_scene *s, const char *dat_path)
+{
+    rt_status st = check_idle(s, "rt_scene_set_photon_dump");
+    if (st) return st;
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->photon_dump = dat_path ? dat_path : "";
+    return RT_OK;
+}
+
+extern "C" rt_status rt_scene_get_photons(rt_scene *s, rt_photon *out, uint32_t cap, uint32_t *n_stored)
+{
+    if (!s) return fail(RT_ERR_ARG, "rt_scene_get_photons: scene is NULL");
+    std::lock_guard<std::mutex> lk(s->mu);
+    const uint32_t n = s->photon_count();
+    if (n_stored) *n_stored = n;
+    if (!out) return RT_OK;
+    if (cap < n + 1) return fail(RT_ERR_ARG, "rt_scene_get_photons: buffer of %u records, %u needed", cap, n + 1);
+    if (n == 0) { memset(out, 0, sizeof(rt_photon)); return RT_OK; }
+    if (!s->photons_raw.empty() && s->data.photons.empty()) {
+        // PrepareForIrradianceEstimation (cyPhotonMap.h:196-218) of the generated photons, bit for bit, on first request
+        std::vector<rt_photon> tmp = s->photons_raw;
+        s->data.photons.resize(tmp.size());
+        rt::BalancePhotons(tmp.data(), n, s->data.photons.data());
+    }
+    memcpy(out, s->data.photons.data(), ((size_t)n + 1) * sizeof(rt_photon));
+    return RT_OK;
 }

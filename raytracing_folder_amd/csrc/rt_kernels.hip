@@ -2406,7 +2406,8 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
         uint32_t pr = 0;
         for (int l = 1; l < CNT_PHOTONQ; l++) pr = max(pr, W.counts[l]);
         atomicMax(&W.stats[ST_PEAK_RAYS], (unsigned long long)pr);
-        atomicMax(&W.stats[ST_PEAK_QUERIES], (unsigned long long)W.counts[CNT_PHOTONQ]);
+        // both query queues are sized from this one figure (the caustic queue gets the photon queue's capacity)
+        atomicMax(&W.stats[ST_PEAK_QUERIES], (unsigned long long)max(W.counts[CNT_PHOTONQ], W.counts[CNT_CAUSTICQ]));
     }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix_round; i += gridDim.x * blockDim.x) {
         const uint32_t i0 = i - (uint32_t)lane;                  // first pixel of this wave

@@ -1,0 +1,336 @@
+// rt_photon_build.hip -- the photon set-up on the GPU ("emit, bounce, pack, kd-balance"), gfx950.
+//
+//   photon_compact   what generatePhotonMap's while() does with the attempts of a k_photon_trace batch (FIN/main.cpp:
+//                    361-395): attempts are consumed in order while fewer than MAX photons are stored; the stored photons of
+//                    the consumed attempts are packed into the reference's 24-byte Photon (AddPhoton: SetDirection /
+//                    SetPower, cyPhotonMap.h:139-156,184-192), in attempt order; ScalePhotonPowers (:396) afterwards.
+//   photon_structure the gather structure k_gather walks (rt_dev.h), from 24-byte photons resident in HBM: recursive median
+//                    splits along the widest axis of each segment's tight box down to sub-leaves of <= RT_SUB_PHOTONS
+//                    photons -- one stable radix sort of (segment id, coordinate) keys per level, all segments of a level
+//                    at once --, tight boxes of every node of the tree, decoded 32-byte slots, density grid.
+//
+// k_gather returns the exact k nearest photons whatever the partition, so this build only has to be a GOOD partition
+// (balanced, tight boxes), not the reference's left-balanced heap: the heap order is only needed to know which photons
+// LocatePhotons can never reach (cyPhotonMap.h:217,371) and is found on the host for those few (rt_api.cpp).
+// Sort and scan are rocPRIM's (hipcub front end); everything else is written here.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+#include <stdint.h>
+#include "rt_dev.h"
+
+#define PB_BLOCK 256
+
+// ---- photon_compact ---------------------------------------------------------------------------------------------
+struct CompactState { unsigned long long attempts, counted; uint32_t stored, pad; };
+
+__global__ __launch_bounds__(PB_BLOCK) void k_split_counts(const uint32_t *count, uint32_t n, int mode, uint32_t *stored, uint32_t *counted)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = count[i];
+    stored[i] = c & 0xFFFFu;
+    counted[i] = mode == 0 ? (c & 0xFFFFu) : (c >> 16);
+}
+
+// Photon::SetDirection / SetPower via AddPhoton (FIN/include/cyPhotonMap.h:139-156,184-192)
+__device__ __forceinline__ void pack_photon(const float *rec, rt_photon &o)
+{
+    o.position[0] = rec[0]; o.position[1] = rec[1]; o.position[2] = rec[2];
+    o.dir_x = (int16_t)(rec[3] * 0x7FFF);
+    o.dir_y = (int16_t)(rec[4] * 0x7FFF);
+    o.plane_and_dirz = rec[5] > 0 ? 0 : 0x8;
+    float power = rec[6];
+    if (power < rec[7]) power = rec[7];
+    if (power < rec[8]) power = rec[8];
+    o.power = power;
+    for (int c = 0; c < 3; c++) {
+        const float s = (rec[6 + c] / power) * 255;
+        const int v = (s == s) ? (int)s : 0;
+        o.color[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+// one thread per attempt of the batch; ex_* = exclusive prefix sums over the batch
+__global__ __launch_bounds__(PB_BLOCK) void k_compact(const float *recs, const uint32_t *stored, const uint32_t *counted, const uint32_t *ex_stored,
+                                                      const uint32_t *ex_counted, uint32_t n_attempts, unsigned long long max_count,
+                                                      CompactState *st, rt_photon *out, uint32_t out_cap)
+{
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_attempts) return;
+    const unsigned long long before = st->counted;            // state of the previous batches (read-only in this launch)
+    const uint32_t n0 = st->stored;
+    // the reference checks the count between attempts (:361): attempt a runs iff fewer than max were counted before it
+    const bool consumed = before + ex_counted[a] < max_count;
+    if (!consumed) return;
+    const uint32_t ns = stored[a];
+    for (uint32_t j = 0; j < ns; j++) {
+        const uint32_t at = n0 + ex_stored[a] + j + 1u;       // 1-based
+        if (at < out_cap) pack_photon(recs + ((size_t)a * 8 + j) * 9, out[at]);
+    }
+    const bool last = a + 1 == n_attempts || !(before + ex_counted[a + 1] < max_count);
+    if (last) {
+        // the only writer; the other threads of this launch read the fields above -- written to the shadow slot st[1]
+        st[1].attempts = st->attempts + a + 1;
+        st[1].counted = before + ex_counted[a] + counted[a];
+        st[1].stored = n0 + ex_stored[a] + ns;
+    }
+}
+
+__global__ void k_commit_state(CompactState *st) { st[0] = st[1]; }
+
+__global__ __launch_bounds__(PB_BLOCK) void k_scale_powers(rt_photon *ph, uint32_t n, float scale)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ph[i + 1].power *= scale;
+}
+
+// scratch = 4 arrays of n_attempts uint32 + the scan's temporary storage (rtk_photon_compact_scratch bytes)
+size_t rtk_photon_compact_scratch(uint32_t n_attempts)
+{
+    size_t tmp = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_attempts);
+    return (size_t)n_attempts * 16 + ((tmp + 255) & ~(size_t)255) + 256;
+}
+void rtk_photon_compact(hipStream_t st, const float *recs, const uint32_t *count, uint32_t n_attempts, int mode, unsigned long long max_count,
+                        void *state_dev, rt_photon *out, uint32_t out_cap, void *scratch, size_t scratch_bytes)
+{
+    uint32_t *stored = (uint32_t *)scratch, *counted = stored + n_attempts, *ex_s = counted + n_attempts, *ex_c = ex_s + n_attempts;
+    void *tmp = (char *)scratch + (size_t)n_attempts * 16;
+    size_t tmp_bytes = scratch_bytes - (size_t)n_attempts * 16;
+    const int grid = (int)((n_attempts + PB_BLOCK - 1) / PB_BLOCK);
+    hipLaunchKernelGGL(k_split_counts, dim3(grid), dim3(PB_BLOCK), 0, st, count, n_attempts, mode, stored, counted);
+    (void)hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, stored, ex_s, (int)n_attempts, st);
+    (void)hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, counted, ex_c, (int)n_attempts, st);
+    CompactState *S = (CompactState *)state_dev;
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(PB_BLOCK), 0, st, recs, stored, counted, ex_s, ex_c, n_attempts, max_count, S, out, out_cap);
+    hipLaunchKernelGGL(k_commit_state, dim3(1), dim3(1), 0, st, S);
+}
+void rtk_photon_scale(hipStream_t st, rt_photon *ph, uint32_t n, float scale)
+{
+    if (n) hipLaunchKernelGGL(k_scale_powers, dim3((n + PB_BLOCK - 1) / PB_BLOCK), dim3(PB_BLOCK), 0, st, ph, n, scale);
+}
+
+// out[i] = in[i + (number of skipped indices <= ...)]: the photons LocatePhotons can reach (at most 8 indices are skipped)
+struct SkipList { uint32_t n; uint32_t idx[8]; };      // ascending, 0-based positions in `in`
+__global__ __launch_bounds__(PB_BLOCK) void k_copy_skipping(const rt_photon *in, uint32_t n_in, SkipList skip, rt_photon *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < skip.n; k++) { if (skip.idx[k] == i) return; if (skip.idx[k] < i) before++; }
+    out[i - before] = in[i];
+}
+void rtk_photon_copy_skipping(hipStream_t st, const rt_photon *in, uint32_t n_in, const uint32_t *skip, uint32_t n_skip, rt_photon *out)
+{
+    SkipList S; S.n = n_skip > 8 ? 8 : n_skip;
+    for (uint32_t k = 0; k < S.n; k++) S.idx[k] = skip[k];
+    if (n_in) hipLaunchKernelGGL(k_copy_skipping, dim3((n_in + PB_BLOCK - 1) / PB_BLOCK), dim3(PB_BLOCK), 0, st, in, n_in, S, out);
+}
+
+// ---- photon_structure -----------------------------------------------------------------------------------------------
+// order-preserving map float -> uint32 (for atomicMin / atomicMax and for radix keys)
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+// (written without a select: `(u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u` feeding a float subtraction crashes this compiler's instruction selection)
+__device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float(u ^ ((uint32_t)((int32_t)(~u) >> 31) | 0x80000000u)); }
+
+// Segment j of level L (0 <= j < 2^L) of the recursion  [lo, hi) -> [lo, mid), [mid, hi)  with mid = lo + (hi - lo + 1) / 2:
+// which one holds sorted position i, and where it starts / ends
+__device__ __forceinline__ uint32_t segment_of(uint32_t i, uint32_t n, int L, uint32_t &lo, uint32_t &hi)
+{
+    lo = 0; hi = n;
+    uint32_t j = 0;
+    for (int l = 0; l < L; l++) {
+        const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+        if (i < mid) { hi = mid; j = 2u * j; } else { lo = mid; j = 2u * j + 1u; }
+    }
+    return j;
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ __launch_bounds__(PB_BLOCK) void k_fill_boxes(uint32_t *boxu, size_t n_nodes)
+{
+    const uint32_t vmin = f2ord(3.0e38f), vmax = f2ord(-3.0e38f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes * 6; i += (size_t)gridDim.x * blockDim.x) boxu[i] = (i % 6) < 3 ? vmin : vmax;
+}
+__global__ __launch_bounds__(PB_BLOCK) void k_iota(uint32_t *p, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+// boxes of the nodes of level L (heap index 2^L + j), as ordered uints: boxu[node][0..2] = min, [3..5] = max
+__global__ __launch_bounds__(PB_BLOCK) void k_level_boxes(const rt_photon *ph, const uint32_t *perm, uint32_t n, int L, uint32_t *boxu)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool have = i < n;
+    uint32_t lo, hi;
+    const uint32_t j = have ? segment_of(i, n, L, lo, hi) : 0xFFFFFFFFu;
+    uint32_t v[3] = {0, 0, 0};
+    if (have) { const float *p = ph[perm[i]].position; v[0] = f2ord(p[0]); v[1] = f2ord(p[1]); v[2] = f2ord(p[2]); }
+    // a wave whose lanes all sit in one segment (the rule while segments are longer than a wave) reduces first
+    const uint32_t j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+    const bool uniform = __all(j == j0) && have;
+    uint32_t *b = boxu + 6 * (size_t)((1u << L) + (have ? j : 0u));
+    if (uniform) {
+        uint32_t mn[3] = {v[0], v[1], v[2]}, mx[3] = {v[0], v[1], v[2]};
+        for (int off = 32; off > 0; off >>= 1)
+            for (int a = 0; a < 3; a++) { mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], off)); mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], off)); }
+        if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; a++) { atomicMin(b + a, mn[a]); atomicMax(b + 3 + a, mx[a]); }
+    } else if (have) {
+        for (int a = 0; a < 3; a++) { atomicMin(b + a, v[a]); atomicMax(b + 3 + a, v[a]); }
+    }
+}
+
+// key of sorted position i for the split of level L: (segment id, coordinate along the segment's widest axis)
+__global__ __launch_bounds__(PB_BLOCK) void k_level_keys(const rt_photon *ph, const uint32_t *perm, uint32_t n, int L, const uint32_t *boxu,
+                                                         unsigned long long *keys)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo, hi;
+    const uint32_t j = segment_of(i, n, L, lo, hi);
+    const uint32_t *b = boxu + 6 * (size_t)((1u << L) + j);
+    const float ex = ord2f(b[3]) - ord2f(b[0]), ey = ord2f(b[4]) - ord2f(b[1]), ez = ord2f(b[5]) - ord2f(b[2]);
+    int axis = 0;
+    if (ey > ex && ey >= ez) axis = 1; else if (ez > ex && ez > ey) axis = 2;
+    const float *pp = ph[perm[i]].position;
+    const float px = pp[0], py = pp[1], pz = pp[2];
+    const float c = axis == 0 ? px : (axis == 1 ? py : pz);     // (a dynamically indexed member array crashes this compiler's instruction selection)
+    ((uint2 *)keys)[i] = make_uint2(f2ord(c), j);              // little-endian: low word = coordinate, high word = segment id
+}
+
+// Photon::GetDirection (FIN/include/cyPhotonMap.h:158-180), including the reference's `dirX*dirX + dirY-dirY` (:162): z from x alone
+__device__ __forceinline__ void photon_direction(const rt_photon &p, float d[3])
+{
+    const int dirX = p.dir_x, dirY = p.dir_y;
+    d[0] = (float)dirX / (float)0x7FFF;
+    d[1] = (float)dirY / (float)0x7FFF;
+    int dirXY2 = dirX * dirX + dirY - dirY;
+    if (dirXY2 > 0x3FFF0001) dirXY2 = 0x3FFF0001;
+    const int dirZ2 = 0x3FFF0001 - dirXY2;
+    int dirZ = 0, place = 0x40000000, remainder = dirZ2;
+    while (place > remainder) place >>= 2;
+    while (place) {
+        if (remainder >= dirZ + place) { remainder -= dirZ + place; dirZ += place << 1; }
+        dirZ >>= 1;
+        place >>= 2;
+    }
+    d[2] = (float)dirZ / (float)0x7FFF;
+    if (p.plane_and_dirz & 0x8) d[2] = -d[2];
+}
+
+// sorted position i -> slot (i - lo) of sub-leaf j: the 32-byte record k_gather reads (pa = position, dir.x; pb = dir.yz,
+// GetMaxPower, colour bytes: the device forms byte / 255.0f * power itself, GetPower :58)
+__global__ __launch_bounds__(PB_BLOCK) void k_scatter_slots(const rt_photon *ph, const uint32_t *perm, uint32_t n, int D, float4 *pa, float4 *pb)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo, hi;
+    const uint32_t j = segment_of(i, n, D, lo, hi);
+    const rt_photon p = ph[perm[i]];
+    float d[3];
+    photon_direction(p, d);
+    const size_t at = (size_t)j * RT_SUB_PHOTONS + (i - lo);
+    pa[at] = make_float4(p.position[0], p.position[1], p.position[2], d[0]);
+    const uint32_t cb = (uint32_t)p.color[0] | ((uint32_t)p.color[1] << 8) | ((uint32_t)p.color[2] << 16);
+    pb[at] = make_float4(d[1], d[2], p.power, __uint_as_float(cb));
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void k_fill_slots(float4 *pa, float4 *pb, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        pa[i] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+        pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// boxu -> the device form of a box: two aligned 16-byte words (lo.xyz, 0), (hi.xyz, 0); node 0 is unused
+__global__ __launch_bounds__(PB_BLOCK) void k_boxes_to_float(const uint32_t *boxu, uint32_t n_nodes, float4 *box4)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t *b = boxu + 6 * (size_t)i;
+    box4[2 * (size_t)i] = make_float4(ord2f(b[0]), ord2f(b[1]), ord2f(b[2]), 0.f);
+    box4[2 * (size_t)i + 1] = make_float4(ord2f(b[3]), ord2f(b[4]), ord2f(b[5]), 0.f);
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void k_density_grid(const rt_photon *ph, uint32_t n, float gx, float gy, float gz, float cell, int dx, int dy, int dz, uint32_t *grid)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = ph[i].position;
+    const int x = min(dx - 1, max(0, (int)((p[0] - gx) / cell))), y = min(dy - 1, max(0, (int)((p[1] - gy) / cell))), z = min(dz - 1, max(0, (int)((p[2] - gz) / cell)));
+    atomicAdd(&grid[((size_t)z * dy + y) * dx + x], 1u);
+}
+
+// Scratch of a build over n photons with n_sub sub-leaves: perm x2, keys x2, boxu, sort temp.
+size_t rtk_photon_structure_scratch(uint32_t n, uint32_t n_sub)
+{
+    size_t tmp = 0;
+    hipcub::DoubleBuffer<unsigned long long> k(nullptr, nullptr);
+    hipcub::DoubleBuffer<uint32_t> v(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, k, v, (int)n, 0, 64);
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
+    return np * (2 * 4 + 2 * 8) + (size_t)2 * n_sub * 24 + ((tmp + 255) & ~(size_t)255) + 1024;
+}
+
+// Builds pa / pb ((n_sub + 1) * RT_SUB_PHOTONS slots each), box4 (2 * 2 * n_sub float4: heap node i at [2i, 2i+1]; the
+// tree over the leaves is its head, the sub-leaf boxes the nodes [n_sub, 2 n_sub)) and the density grid (64^3 counters
+// provided; dims / origin / cell come back in grid_out after a stream synchronisation inside this call).
+struct PhotonGridOut { float min[3]; float cell; int dim[3]; };
+hipError_t rtk_photon_structure(hipStream_t st, const rt_photon *ph, uint32_t n, uint32_t n_sub, float4 *pa, float4 *pb, float4 *box4,
+                                uint32_t *grid, PhotonGridOut *grid_out, void *scratch, size_t scratch_bytes)
+{
+    int D = 0;
+    while ((1u << D) < n_sub) D++;
+    const size_t np = ((size_t)n + 63) & ~(size_t)63;
+    char *sp = (char *)scratch;
+    uint32_t *perm0 = (uint32_t *)sp; sp += np * 4;
+    uint32_t *perm1 = (uint32_t *)sp; sp += np * 4;
+    unsigned long long *keys0 = (unsigned long long *)sp; sp += np * 8;
+    unsigned long long *keys1 = (unsigned long long *)sp; sp += np * 8;
+    uint32_t *boxu = (uint32_t *)sp; sp += (size_t)2 * n_sub * 24;
+    void *tmp = sp;
+    size_t tmp_bytes = scratch_bytes - (size_t)(sp - (char *)scratch);
+    const int grid_n = (int)((n + PB_BLOCK - 1) / PB_BLOCK);
+    // empty boxes: min = +3e38, max = -3e38 (what the gather's box test treats as "nothing here"; rt_api.cpp's host build did the same)
+    hipLaunchKernelGGL(k_fill_boxes, dim3(256), dim3(PB_BLOCK), 0, st, boxu, (size_t)2 * n_sub);
+    hipLaunchKernelGGL(k_iota, dim3(grid_n), dim3(PB_BLOCK), 0, st, perm0, n);
+    hipLaunchKernelGGL(k_fill_slots, dim3(512), dim3(PB_BLOCK), 0, st, pa, pb, ((size_t)n_sub + 1) * RT_SUB_PHOTONS);
+    hipcub::DoubleBuffer<unsigned long long> kb(keys0, keys1);
+    hipcub::DoubleBuffer<uint32_t> vb(perm0, perm1);
+    for (int L = 0; L <= D; L++) {
+        hipLaunchKernelGGL(k_level_boxes, dim3(grid_n), dim3(PB_BLOCK), 0, st, ph, vb.Current(), n, L, boxu);
+        if (L == D) break;
+        hipLaunchKernelGGL(k_level_keys, dim3(grid_n), dim3(PB_BLOCK), 0, st, ph, vb.Current(), n, L, boxu, kb.Current());
+        // stable: equal coordinates keep their order; only the bits in use are sorted (L bits of segment id above 32 of key)
+        const hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kb, vb, (int)n, 0, 32 + L, st);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_scatter_slots, dim3(grid_n), dim3(PB_BLOCK), 0, st, ph, vb.Current(), n, D, pa, pb);
+    hipLaunchKernelGGL(k_boxes_to_float, dim3((2 * n_sub + PB_BLOCK - 1) / PB_BLOCK), dim3(PB_BLOCK), 0, st, boxu, 2 * n_sub, box4);
+    // density grid over the photons' bounding box (the root's box), at most 64 cells along the longest axis
+    uint32_t root[6];
+    hipError_t e = hipMemcpyAsync(root, boxu + 6, sizeof root, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    float rb[6];
+    for (int a = 0; a < 6; a++) { const uint32_t u = root[a]; const uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; memcpy(&rb[a], &b, 4); }
+    float ext = fmaxf(fmaxf(rb[3] - rb[0], rb[4] - rb[1]), rb[5] - rb[2]);
+    if (!(ext > 0)) ext = 1.0f;
+    const float cell = ext / 64.0f;
+    for (int a = 0; a < 3; a++) {
+        int d = (int)floorf((rb[3 + a] - rb[a]) / cell) + 1;
+        grid_out->dim[a] = d < 1 ? 1 : (d > 64 ? 64 : d);
+        grid_out->min[a] = rb[a];
+    }
+    grid_out->cell = cell;
+    const size_t cells = (size_t)grid_out->dim[0] * grid_out->dim[1] * grid_out->dim[2];
+    hipLaunchKernelGGL(k_fill_u32, dim3(256), dim3(PB_BLOCK), 0, st, grid, cells, 0u);
+    hipLaunchKernelGGL(k_density_grid, dim3(grid_n), dim3(PB_BLOCK), 0, st, ph, n, rb[0], rb[1], rb[2], cell, grid_out->dim[0], grid_out->dim[1], grid_out->dim[2], grid);
+    return hipGetLastError();
+}

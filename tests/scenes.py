@@ -56,3 +56,16 @@ def build_shim_driver(tmp_path):
                     os.path.join(ROOT, "tests", "shim_driver.cpp"), "-L" + lib, "-lrt_mi355x", "-Wl,-rpath," + lib, "-lpthread"],
                    check=True, capture_output=True)
     return exe
+
+
+def build_dist_driver(tmp_path):
+    """g++ build of tests/dist_driver.cpp: the C++ multi-GPU host (rt_render_tiles_packed_device -> ncclAllGather ->
+    rt_tiles_unpack_device) against the C ABI header and /opt/rocm/include/rccl; returns the executable's path"""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "dist_driver")
+    lib = os.path.join(ROOT, "raytracing_folder_amd", "lib")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "dist_driver.cpp"), "-L" + lib, "-lrt_mi355x", "-Wl,-rpath," + lib,
+                    "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"],
+                   check=True, capture_output=True)
+    return exe

@@ -865,7 +865,7 @@ def test_job_progress_stop_and_partial_image(cornell, monkeypatch):
     import time
     monkeypatch.setenv("RT_CHUNK_SAMPLES", "8192")            # many chunks on a small frame
     s, cam = scenes.load_cornell(128, 96)
-    p = capi.default_params(min_sample=8, max_sample=8, threshold=-1.0)
+    p = capi.default_params(min_sample=8, max_sample=8, threshold=-1.0, photon_count=0)
     full, zfull, _, _, prog = s.render(cam, p)
     assert prog == 128 * 96
     rgb, z, cnt = np.zeros((96, 128, 3), np.uint8), np.zeros((96, 128), np.float32), np.zeros((96, 128), np.uint8)
@@ -1060,23 +1060,34 @@ def test_single_stage_calls_are_refused_while_a_job_owns_the_device(monkeypatch)
 
 
 def test_cpp_beginrender_shim_end_to_end(tmp_path):
-    """tests/shim_driver.cpp drives rt::Renderer like the reference's viewport: BeginRender returns at once,
-    IsRenderDone is polled while the image fills, saveImage writes the three PNGs -- which must hold what a
-    render through the C ABI gives (textured scene: the shim lowers textures, maps and texture vertices too)"""
+    """tests/shim_driver.cpp drives rt::Renderer like the reference's viewport: BeginRender returns at once -- the photon pass
+    it starts with (generatePhotonMap, FIN/main.cpp:984-998 -> :350-402: 1 000 000 photons, 8 bounces) runs on the job's
+    thread --, IsRenderDone is polled while the image fills, saveImage writes the three PNGs -- which must hold what a render
+    through the C ABI gives with the same seed (textured scene: the shim lowers textures, maps and texture vertices too)"""
     import subprocess
     exe = scenes.build_shim_driver(tmp_path)
     xml = os.path.join(scenes.GOLD, "cornell_textured.xml")
     out = [str(tmp_path / n) for n in ("image.png", "samples.png", "z.png")]
-    r = subprocess.run([exe, xml] + out, capture_output=True, text=True)
+    dat = str(tmp_path / "photonmap.dat")
+    r = subprocess.run([exe, xml] + out + ["dump=" + dat], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     info = dict(zip(r.stdout.split()[0::2], r.stdout.split()[1::2]))
     assert float(info["begin_ms"]) < 2000 and int(info["pixels"]) == 160 * 120 and int(info["rays"]) > 160 * 120
+    assert int(info["photon_queries"]) > 0 and float(info["photon_pass_ms"]) > 0       # the frame HAS the reference's photon term
     s = capi.Scene()
     s.load_xml(xml)
     cam = s.camera()
-    rgb, z, cnt, _, _ = s.render(cam, capi.default_params())
+    rgb, z, cnt, st, _ = s.render(cam, capi.default_params(), photon_pass=True)
+    assert st.photon_queries == int(info["photon_queries"])
     img = capi.image_read_rgb(out[0])
     assert img.shape == rgb.shape and (np.abs(img.astype(int) - rgb.astype(int)) <= 1).mean() > 0.999
+    # the dump generatePhotonMap leaves behind (:397-400): the unbalanced photons; balanced they are the scene's map
+    dumped = capi.photons_read_dat(dat)
+    assert 1000000 <= len(dumped) - 1 <= 1000007
+    assert capi.photon_balance(dumped).tobytes() == s.get_photons().tobytes()
+    # ... and without the photon pass the frame is a different one (the term is visible)
+    rgb0, _, _, st0, _ = s2_render_without_photons(xml)
+    assert st0.photon_queries == 0 and (np.abs(rgb0.astype(int) - rgb.astype(int)).max(axis=2) > 1).mean() > 0.01
     # ComputeZBufferImage / ComputeSampleCountImage (scene.h:591-637): integer maps, BIT-EXACT.  The PNGs the
     # C++ shim wrote must be what the same functions (pinned to the reference's own in tests/golden/zimage.npz)
     # make of the z / count buffers of a render through the C ABI -- the z buffer itself is deterministic
@@ -1088,10 +1099,127 @@ def test_cpp_beginrender_shim_end_to_end(tmp_path):
     # a pixel exactly on the threshold may flip between two runs, everything else is exact
     assert smax == 255 and (spng != sc).sum() <= 2
     # StopRender after the first progress: fewer pixels, no error
-    r = subprocess.run([exe, xml] + out + ["stop"], capture_output=True, text=True, env=dict(os.environ, RT_CHUNK_SAMPLES="4096"))
+    r = subprocess.run([exe, xml] + out + ["stop", "photons=20000"], capture_output=True, text=True, env=dict(os.environ, RT_CHUNK_SAMPLES="4096"))
     assert r.returncode == 0, r.stderr
     info = dict(zip(r.stdout.split()[0::2], r.stdout.split()[1::2]))
     assert 0 < int(info["pixels"]) <= 160 * 120
+
+
+def s2_render_without_photons(xml):
+    s = capi.Scene()
+    s.load_xml(xml)
+    return s.render(s.camera(), capi.default_params())
+
+
+def test_jobs_on_interleaved_tile_sets_share_one_image(cornell):
+    """what rt::Renderer does with several devices, on one: jobs that own interleaved tile sets (rank t mod N) write into the
+    SAME caller-owned buffers and only their own pixels (rows are shared between the jobs' tiles); run one after the other
+    here (one render at a time per scene and device), they compose the frame a single job renders"""
+    import ctypes as C
+    s, cam = scenes.load_cornell(200, 67)                     # ragged: 7 x 9 tiles of 32 x 8
+    bal = photons.synth_cornell_photon_map(20000, seed=4)
+    s.set_photons(bal)
+    p = capi.default_params(min_sample=4, max_sample=4, threshold=-1.0, photon_count=0)
+    want, wz, wcnt, _, _ = s.render(cam, p)
+    rgb = np.full((67, 200, 3), 7, np.uint8)
+    z = np.full((67, 200), -1.0, np.float32)
+    cnt = np.full((67, 200), 9, np.uint8)
+    total = 0
+    for rank in range(3):
+        tiles = capi.TileRange(32, 8, rank, 3)
+        job = C.c_void_p()
+        capi._check(capi.lib().rt_render_begin(s._h, C.byref(cam), C.byref(p), C.byref(tiles), 0, capi._p(rgb), capi._p(z), capi._p(cnt), C.byref(job)))
+        try:
+            capi._check(capi.lib().rt_render_wait(job))
+            total += capi.lib().rt_render_progress(job)
+        finally:
+            capi.lib().rt_job_destroy(job)
+        if rank < 2:
+            assert (z == -1.0).any() and (cnt == 9).any()       # the other ranks' pixels are still the caller's
+    assert total == 200 * 67
+    assert (z == wz).all() and (cnt == wcnt).all() and (np.abs(rgb.astype(int) - want.astype(int)) <= 1).all()
+
+
+def test_cpp_multi_gpu_driver_with_rccl(tmp_path):
+    """tests/dist_driver.cpp: one C++ process drives every gfx950 device of the box -- photon map generated once, each
+    device renders its interleaved tiles into its all-gather contribution, ONE ncclAllGather (RCCL), rt_tiles_unpack_device
+    -- and the frame it writes equals a single render through the C ABI.  (One device here: the collective is a copy, but
+    every call of the multi-GPU path is made, through librccl.)"""
+    import subprocess
+    exe = scenes.build_dist_driver(tmp_path)
+    out = str(tmp_path / "frame.png")
+    r = subprocess.run([exe, scenes.CORNELL, "200", "67", "4", "30000", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("devices ")]
+    assert line, (r.stdout[-1500:], r.stderr[-1500:])
+    info = dict(zip(line[-1].split()[0::2], line[-1].split()[1::2]))
+    assert int(info["devices"]) >= 1 and int(info["pixels"]) == 200 * 67 and int(info["photon_queries"]) > 0
+    s, cam = scenes.load_cornell(200, 67)
+    s.generate_photons(30000, 8, seed=20171203)
+    rgb, _, _, st, _ = s.render(cam, capi.default_params(min_sample=4, max_sample=4, threshold=-1.0))
+    img = capi.image_read_rgb(out)
+    assert st.photon_queries == int(info["photon_queries"])
+    assert img.shape == rgb.shape and (np.abs(img.astype(int) - rgb.astype(int)) <= 1).all()
+
+
+def test_reference_side_binding_linked_into_the_reference_program(tmp_path):
+    """oracle/_ref/ref_binding_harness_fin = the reference's own main.cpp (LoadScene, Node / MtlBlinn / PointLight objects,
+    RenderImage, saveImage with its lodepng) with raytracing_folder_amd/binding/rt_binding.cpp in place of its BeginRender /
+    StopRender / saveImage: the binding lowers the REFERENCE's scene graph, rt_render_begin runs the photon pass and the
+    frame, the pixels land in the reference's RenderImage.  They must be what the product's own loader + a render through the
+    C ABI give for the same file and seed.  (Built in the build container by `make -C oracle refbinding`; it travels to the
+    GPU box like any built file and needs nothing of the reference tree at run time.)"""
+    import shutil
+    import subprocess
+    exe = os.path.join(scenes.ROOT, "oracle", "_ref", "ref_binding_harness_fin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_binding_harness_fin was not built (needs the reference tree at build time)")
+    data = os.path.dirname(scenes.CORNELL)
+    for f in ("cornell.xml", "teapot_tri.obj"):
+        shutil.copy(os.path.join(data, f), tmp_path / f)
+    r = subprocess.run([exe, "cornell.xml", "out.bin", "160", "120"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    raw = open(tmp_path / "out.bin", "rb").read()
+    w, h, done = np.frombuffer(raw, np.int32, 3)
+    assert (w, h, done) == (160, 120, 160 * 120)
+    rgb = np.frombuffer(raw, np.uint8, 3 * w * h, 12).reshape(h, w, 3)
+    z = np.frombuffer(raw, np.float32, w * h, 12 + 3 * w * h).reshape(h, w)
+    cnt = np.frombuffer(raw, np.uint8, w * h, 12 + 7 * w * h).reshape(h, w)
+    s, cam = scenes.load_cornell(160, 120)
+    want, wz, wcnt, st, _ = s.render(cam, capi.default_params(), photon_pass=True)
+    assert st.photon_queries > 0
+    assert (z == wz).all() and (np.abs(rgb.astype(int) - want.astype(int)) <= 1).mean() > 0.999 and (cnt == wcnt).mean() > 0.999
+    # the reference's own saveImage wrote its PNGs from those buffers
+    assert np.array_equal(capi.image_read_rgb(str(tmp_path / "prj13box.png")), rgb)
+    sc, _ = capi.sample_count_image(cnt)
+    assert np.array_equal(capi.image_read_rgb(str(tmp_path / "prj13box_sc.png"))[..., 0], sc)
+
+
+def test_generated_photon_map_equals_the_host_balanced_one(cornell):
+    """rt_scene_generate_photons (photon pass, compaction and gather structure on the GPU; only the few photons balancing
+    would put out of LocatePhotons' reach are found on the host) against the long way round -- rt_photon_pass to the host,
+    rt_photon_balance (the reference's PrepareForIrradianceEstimation, bit-identical), rt_scene_set_photons: the same
+    photons, the same candidate set, so every estimate agrees to summation rounding; the dump is the unbalanced array"""
+    s, cam, e = cornell
+    s1, _ = scenes.load_cornell()
+    raw, attempts = s1.photon_pass(60000, 8, seed=5)
+    bal = capi.photon_balance(raw)
+    s1.set_photons(bal)
+    s2, _ = scenes.load_cornell()
+    ms = s2.generate_photons(60000, 8, seed=5)
+    assert ms.total > 0 and ms.photon_pass > 0 and ms.structure_build > 0
+    assert s2.counts()["photons"] == len(raw) - 1
+    assert s2.get_photons().tobytes() == bal.tobytes()
+    rng = np.random.default_rng(8)
+    pick = rng.integers(1, len(bal), 600)
+    pos = bal["position"][pick] + rng.normal(scale=0.05, size=(600, 3)).astype(np.float32)
+    d, _ = orc.photon_decode(bal[pick])
+    nrm = -d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-6)
+    for k, radius in ((400, 1.0), (50, 3.0)):
+        i1, d1 = s1.estimate_irradiance(k, radius, pos, nrm)
+        i2, d2 = s2.estimate_irradiance(k, radius, pos, nrm)
+        assert np.allclose(i1, i2, rtol=2e-5, atol=1e-9) and np.allclose(d1, d2, rtol=0, atol=2e-5)
+        assert (i1.max(axis=1) > 0).mean() > 0.9
 
 
 def test_full_size_frame_properties():

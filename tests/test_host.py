@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -21,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.lib()
     for name in declared:
         assert getattr(lib, name)
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
 
 
 def test_struct_sizes_match_header():
@@ -30,6 +32,8 @@ def test_struct_sizes_match_header():
     p = capi.default_params()
     assert (p.min_sample, p.max_sample, p.bounce, p.knn_k, p.shadow_samples) == (4, 8, 4, 400, 4)
     assert p.threshold == np.float32(1e-3) and p.gamma == 2.2 and p.knn_radius == 1.0
+    assert (p.photon_count, p.photon_bounce) == (1000000, 8)       # MAX_NUM_OF_PHOTON, PHOTON_BOUNCE (FIN/main.cpp:27,29)
+    assert C.sizeof(capi.SetupMs) == 5 * 8
 
 
 def test_xml_loader_reproduces_reference_transforms(gold):
@@ -123,6 +127,27 @@ def test_photon_pack_and_balance_match_reference(gold, tag):
     assert bal[1:].tobytes() == g["balanced"][1:].tobytes()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 100, 101, 1023, 1024, 1025, 4097, 20000, 20001])
+def test_unreachable_photons_are_the_tail_of_the_balanced_heap(n):
+    """rt_photon_unreachable (partial BalanceSegment along the root paths of the last heap slots) names exactly the photons the
+    full PrepareForIrradianceEstimation puts at heap slots >= 2 * halfStoredPhotons, which LocatePhotons never visits
+    (cyPhotonMap.h:217,371) -- also with many equal coordinates, where the partition's tie handling decides"""
+    rng = np.random.default_rng(n)
+    ph = np.zeros(n + 1, capi.PHOTON)
+    pos = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    if n > 8:
+        pos[:, rng.integers(0, 3)] = np.round(pos[:, 0] * 2) / 2          # heavy ties along one axis
+    ph["position"][1:] = pos
+    ph["power"][1:] = np.arange(1, n + 1)                                 # identifies the record
+    bal = capi.photon_balance(ph)
+    half = n // 2 - 1
+    reach = min(n, max(1, 2 * half - 1))
+    want = sorted(bal["power"][reach + 1:].astype(int).tolist())
+    got = capi.photon_unreachable(ph)
+    assert sorted(ph["power"][got].astype(int).tolist()) == want and len(got) == n - reach
+    assert (np.diff(got.astype(int)) > 0).all() if len(got) > 1 else True
+
+
 def test_photon_dat_round_trip_and_reference_dump(gold, tmp_path):
     """rt_photons_read_dat / write_dat on the dump the reference ships, and the host balance of it
     against the reference's cyPhotonMap"""
@@ -210,6 +235,35 @@ def test_cpp_driver_of_the_beginrender_shim_fails_loudly_without_a_gpu(tmp_path)
         assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, str(tmp_path / "missing.xml"), "a", "b", "c"], capture_output=True, text=True)
     assert r.returncode == 3 and "LoadScene failed" in r.stderr
+
+
+def test_cpp_multi_gpu_driver_builds_against_rccl_and_fails_loudly_without_a_gpu(tmp_path):
+    """tests/dist_driver.cpp -- rt_render_tiles_packed_device -> ncclAllGather -> rt_tiles_unpack_device from plain C++ --
+    compiles and links against include/rt_mi355x.h, /opt/rocm/include/rccl and librccl; without a gfx950 device it exits
+    with an error instead of rendering anything on the CPU"""
+    exe = scenes_mod().build_dist_driver(tmp_path)
+    r = subprocess.run([exe, scenes_mod().CORNELL, "64", "48", "2", "1000", str(tmp_path / "x.png")], capture_output=True, text=True)
+    assert r.returncode != 0 and "no gfx950 device" in r.stderr and not (tmp_path / "x.png").exists()
+
+
+def test_reference_side_binding_links_into_the_reference_program_and_fails_loudly_without_a_gpu(tmp_path):
+    """oracle/_ref/ref_binding_harness_fin (the reference's main.cpp + rt_binding.cpp, `make -C oracle refbinding`): the
+    reference's LoadScene reads the product's Cornell file, the binding's BeginRender lowers the scene -- and reports that
+    there is no GPU instead of rendering on the CPU"""
+    import shutil
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_binding_harness_fin")
+    if not os.path.exists(exe):
+        pytest.skip("not built (needs the reference tree at build time)")
+    data = os.path.dirname(scenes_mod().CORNELL)
+    for f in ("cornell.xml", "teapot_tri.obj"):
+        shutil.copy(os.path.join(data, f), tmp_path / f)
+    r = subprocess.run([exe, "cornell.xml", "out.bin", "32", "24"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 5 and "no HIP device" in r.stderr and not (tmp_path / "out.bin").exists()
+
+
+def scenes_mod():
+    from tests import scenes
+    return scenes
 
 
 def test_synthetic_photon_map_is_well_formed():
