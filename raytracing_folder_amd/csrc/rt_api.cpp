@@ -29,7 +29,7 @@ void rtk_launch_trace(hipStream_t, const DevScene &, int, const float *, long lo
 bool rtk_launch_wavefront_queue(hipStream_t, const DevScene &, const DevWork &, const rt_params &, const DevRayQueue &, const uint32_t *,
                                 const DevRayQueue &, uint32_t *);
 void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const float4 *, const float4 *, const uint32_t *,
-                       uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint32_t *);
+                       uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint32_t *, float *);
 void rtk_launch_resolve(hipStream_t, const DevScene &, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
                         float, float, int, const float *, uint8_t *, float *, uint8_t *, void *, int);
 void rtk_launch_unpack_tiles(hipStream_t, const void *, int, int, int, int, int, int, uint8_t *, float *, uint8_t *);
@@ -157,6 +157,9 @@ struct DeviceState {
     DevBuf pa, pb, box4, grid;                  // the gather structure of the photon map (rt_photon_build.hip)
     DevBuf cpa, cpb, cbox4, cgrid;              // ... of the caustic map
     DevBuf raw_photons;                         // 24-byte photons of the last photon pass on this device (1-based)
+    // per density-grid cell, the k-th squared distance of the last query k_gather answered there: predicts the next one's (a
+    // hint that only steers which of two exact paths a query takes); zeroed whenever the structure is rebuilt
+    DevBuf cell_rk2, ccell_rk2;
     DevScene scene{};
     Workspace ws[RT_STREAMS];
     DevBuf stats;
@@ -177,7 +180,7 @@ struct DeviceState {
     void release()
     {
         for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &box4, &grid, &cpa, &cpb, &cbox4, &cgrid,
-                          &raw_photons, &stats, &t_in}) b->release();
+                          &raw_photons, &cell_rk2, &ccell_rk2, &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
         for (Workspace &w : ws) w.release();
         for (int k = 0; k < 6; k++) t_out[k].release();
@@ -890,6 +893,12 @@ static rt_status build_photon_structure(DeviceState *D, bool caustic, const rt_p
     pm.grid = (const uint32_t *)b_grid.p;
     for (int a = 0; a < 3; a++) { pm.grid_min[a] = g.min[a]; pm.grid_dim[a] = g.dim[a]; }
     pm.cell = g.cell; pm.inv_cell = 1.0f / g.cell;
+    {
+        DevBuf &b_rk = caustic ? D->ccell_rk2 : D->cell_rk2;
+        if ((st = b_rk.ensure((size_t)64 * 64 * 64 * 4))) return st;
+        HIP_TRY(hipMemsetAsync(b_rk.p, 0, (size_t)64 * 64 * 64 * 4, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     const auto t2 = clk::now();
     if (ms_upload) *ms_upload += std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (ms_build) *ms_build += std::chrono::duration<double, std::milli>(t2 - t1).count();
@@ -1110,13 +1119,13 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
     if ((s = mark(1))) return s;
     if (D->scene.pm.n_leaves) {
         rtk_launch_gather(st, D->scene.pm, W.pq.qa, W.pq.qb, W.pq.qc, W.counts + CNT_PHOTONQ, W.pq.cap, P.knn_k, P.knn_radius,
-                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, W.counts + CNT_GATHER_NEXT);
+                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, W.counts + CNT_GATHER_NEXT, (float *)D->cell_rk2.p);
         if ((s = mark(2))) return s;
     }
     if (D->scene.cm.n_leaves && P.caustic_k > 0 && W.cq.cap) {
         // the P13-family models queued their caustic lookups separately: same kernel on the second map
         rtk_launch_gather(st, D->scene.cm, W.cq.qa, W.cq.qb, W.cq.qc, W.counts + CNT_CAUSTICQ, W.cq.cap, P.caustic_k, P.caustic_radius,
-                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, W.counts + CNT_GATHER_NEXT2);
+                          W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, W.counts + CNT_GATHER_NEXT2, (float *)D->ccell_rk2.p);
         if ((s = mark(2))) return s;
     }
     HIP_TRY(hipGetLastError());
@@ -1660,7 +1669,7 @@ extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, 
     if ((st = D->t_in.upload(cnt, sizeof cnt))) return st;
     rtk_launch_gather(D->stream, D->scene.pm, (const float4 *)D->t_out[0].p, (const float4 *)D->t_out[1].p, (const float4 *)D->t_out[2].p,
                       (const uint32_t *)D->t_in.p, cnt[0], k, radius, nullptr, (float *)D->t_out[3].p, (float *)D->t_out[4].p, 1, nullptr, GATHER_BLOCKS,
-                      (uint32_t *)D->t_in.p + 1);
+                      (uint32_t *)D->t_in.p + 1, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(D->stream));
     HIP_TRY(hipMemcpy(irr, D->t_out[3].p, (size_t)n * 12, hipMemcpyDeviceToHost));

@@ -52,6 +52,20 @@
 #ifndef RT_GATHER_BATCH
 #define RT_GATHER_BATCH 32     // queries a wave lists per phase A (40 leaf ids each: lists + ring keep 5 waves/SIMD)
 #endif
+#ifndef RT_GATHER_FMA
+#define RT_GATHER_FMA 1        // 1: the photon loop's d^2, dir.N, box distances and weighted sums may contract mul+add into fma (scoped
+                               // `#pragma clang fp contract(fast)`; the rest of the file stays uncontracted: hit records are bit-exact,
+                               // the gather's gate is 2e-5)
+#endif
+#ifndef RT_GATHER_CELLPRED
+#define RT_GATHER_CELLPRED 1   // 1: the k-th distance of the last query answered in a density-grid cell predicts the band of the next one
+                               // there (a table in HBM, written racily: a hint only); 0: the wave's previous query predicts
+#endif
+#if RT_GATHER_FMA
+#define RT_FP_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define RT_FP_CONTRACT
+#endif
 #define RT_SUBS_PER_STEP (64 / RT_SUB_PHOTONS)                  // sub-leaves a wavefront examines per step
 #define RT_SUBLIST_CAP (RT_LEAFLIST_CAP * RT_LEAF_SUBS)         // sub-leaf ids of one query
 
@@ -1641,6 +1655,7 @@ struct GatherArgs {
     float *out_irr, *out_dir;        // mode 1: write irr[3], dir[3] per query (rt_estimate_irradiance)
     int mode;
     unsigned long long *stats;
+    float *cell_rk2;                 // per density-grid cell: the k-th squared distance of the last query answered there (0 = none yet); may be NULL
 };
 
 // Wave-wide inclusive scans on the DPP path (row_shr 1/2/4/8 inside each row of 16 lanes, then
@@ -1728,6 +1743,7 @@ __device__ __forceinline__ uint32_t lane_u(uint32_t v, int l) { return (uint32_t
 // boxes are two aligned 16-byte words (lo.xyz, -), (hi.xyz, -): one visit = two dwordx4 loads
 __device__ __forceinline__ float box_dist2(const float4 *b, float px, float py, float pz)
 {
+    RT_FP_CONTRACT
     const float4 lo = b[0], hi = b[1];
     const float dx = fmaxf(fmaxf(lo.x - px, px - hi.x), 0.0f);
     const float dy = fmaxf(fmaxf(lo.y - py, py - hi.y), 0.0f);
@@ -1781,6 +1797,7 @@ struct Cand { float d2; float4 pa, pb; };
 struct GatherQuery { float px, py, pz, nx, ny, nz, rq2, kscale; };
 __device__ __forceinline__ Cand make_cand(float4 pa, float4 pb, const GatherQuery &Q)
 {
+    RT_FP_CONTRACT
     Cand c;
     c.pa = pa; c.pb = pb;
     const float dfx = pa.x - Q.px, dfy = pa.y - Q.py, dfz = pa.z - Q.pz;       // dif = p.position - np.pos
@@ -1927,12 +1944,22 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
         // first trial radius from the density grid: about RT_GATHER_GUESS * k photons expected inside (count ~ r^2
         // on a surface through a cell of side h: c photons per h^2)
         float r2cur = r2;
+        float cell_pred = 0.0f;                              // this lane's query: what its grid cell remembers (RT_GATHER_CELLPRED)
+        uint32_t cell_index = 0;
         if (have && n_leaves > 1) {
             const int gx = min(max((int)((a.x - G.pm.grid_min[0]) * G.pm.inv_cell), 0), G.pm.grid_dim[0] - 1);
             const int gy = min(max((int)((a.y - G.pm.grid_min[1]) * G.pm.inv_cell), 0), G.pm.grid_dim[1] - 1);
             const int gz = min(max((int)((a.z - G.pm.grid_min[2]) * G.pm.inv_cell), 0), G.pm.grid_dim[2] - 1);
-            const uint32_t cnt = G.pm.grid[((size_t)gz * G.pm.grid_dim[1] + gy) * G.pm.grid_dim[0] + gx];
+            cell_index = (uint32_t)(((size_t)gz * G.pm.grid_dim[1] + gy) * G.pm.grid_dim[0] + gx);
+            const uint32_t cnt = G.pm.grid[cell_index];
             r2cur = fminf(fmaxf(guess_c / (float)(cnt > 0u ? cnt : 1u), r2 * 1.0e-4f), r2);
+#if RT_GATHER_CELLPRED
+            if (G.cell_rk2) {
+                cell_pred = G.cell_rk2[cell_index];
+                // a cell that has seen a query also knows a better first radius than the density estimate: a little above its k-th distance
+                if (cell_pred > 0.0f) r2cur = fminf(fmaxf(cell_pred * RT_GATHER_GUESS, r2 * 1.0e-4f), r2);
+            }
+#endif
         }
 
         while (ballot64(pending)) {
@@ -2073,6 +2100,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 // sum of power (GetPower = Color24 -> Color times power) and of dir * maxPower for one photon
                 // (branch-free variant: take == false adds exact zeros; measured slower than the branch)
                 auto accumulate5 = [&](float dirx, float diry, float dirz, float maxp, uint32_t cbits, bool take) {
+                    RT_FP_CONTRACT
 #ifdef RT_EXP_NOACC             /* cost attribution build: no summation; results are garbage */
                     return;
 #endif
@@ -2095,6 +2123,9 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 // the scaling by a power of two being exact.
                 const float kscale_bin = Q.kscale * (1.0f / 65536.0f);
 #if RT_GATHER_RING
+#if RT_GATHER_CELLPRED
+                { const float cp = lane_f(cell_pred, q); if (cp > 0.0f) pred_rk2 = cp; }
+#endif
                 const float pk = (pred_rk2 > 0.0f && pred_rk2 < rq2) ? pred_rk2 : rq2 * (1.0f / RT_GATHER_GUESS);
                 const float t_lo = RT_GATHER_BAND_LO * pk;
                 const float t_hi = final_round ? rq2 : fminf(RT_GATHER_BAND_HI * pk, rq2);     // <= rq2: inside the band implies accepted
@@ -2318,6 +2349,10 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
             }
             if (finish) {
                 float irr_r = f_pr, irr_g = f_pg, irr_b = f_pb, dx = f_dx, dy = f_dy, dz = f_dz;
+#if RT_GATHER_CELLPRED
+                // remember the k-th distance for the next query of this cell (only when more than k qualified: f_area < r2)
+                if (G.cell_rk2 && n_leaves > 1 && f_area > 0.0f && f_area < r2) G.cell_rk2[cell_index] = f_area;
+#endif
                 if (f_area >= 0.0f) {
                     const float area = (float)M_PI * f_area;               // :326
                     if (area > 0) { const float inv = 1.0f / area; irr_r *= inv; irr_g *= inv; irr_b *= inv; }
@@ -2335,9 +2370,13 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     float theta = nx * (-dx) + ny * (-dy) + nz * (-dz);
                     theta = theta > 0.0f ? theta : 0.0f;
                     float *dst = G.sample_rgb + 3 * (size_t)slot;
+#ifdef RT_EXP_NOATOMIC          /* cost attribution build: the result is stored once per batch instead of added per query; results are garbage */
+                    if (slot == 0xFFFFFFFFu) dst[0] = (wr * irr_r) * theta + (wg * irr_g) * theta + (wb * irr_b) * theta;
+#else
                     atomicAdd(dst, (wr * irr_r) * theta);
                     atomicAdd(dst + 1, (wg * irr_g) * theta);
                     atomicAdd(dst + 2, (wb * irr_b) * theta);
+#endif
                 }
                 finish = false;
             }
@@ -2624,9 +2663,9 @@ void rtk_launch_trace(hipStream_t st, const DevScene &S, int model, const float 
 void rtk_launch_gather(hipStream_t st, const DevPhotonMap &pm, const float4 *qa, const float4 *qb,
                        const float4 *qc, const uint32_t *count_ptr, uint32_t count_cap, int k,
                        float radius, float *sample_rgb, float *out_irr, float *out_dir, int mode,
-                       unsigned long long *stats, int blocks, uint32_t *next_batch)
+                       unsigned long long *stats, int blocks, uint32_t *next_batch, float *cell_rk2)
 {
-    GatherArgs G; G.pm = pm; G.qa = qa; G.qb = qb; G.qc = qc; G.count_ptr = count_ptr; G.count_cap = count_cap;
+    GatherArgs G; G.pm = pm; G.cell_rk2 = cell_rk2; G.qa = qa; G.qb = qb; G.qc = qc; G.count_ptr = count_ptr; G.count_cap = count_cap;
     G.k = k; G.radius = radius; G.sample_rgb = sample_rgb; G.out_irr = out_irr; G.out_dir = out_dir; G.mode = mode; G.stats = stats; G.next_batch = next_batch;
     hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(64 * RT_GATHER_WAVES), 0, st, G);
 }
