@@ -50,13 +50,15 @@ def parse():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--photons", type=int, default=1000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="wait for every timed frame on the host before the next one is started")
     ap.add_argument("--synthetic-photons", action="store_true", help="wall-sprinkled photons instead of the GPU photon pass")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--profile-frames", type=int, default=2, help="frames of the RT_STREAMS=1 pass behind the timed region (0: no roofline)")
-    ap.add_argument("--workload", choices=["cornell", "balls"], default="cornell",
+    ap.add_argument("--workload", choices=["cornell", "balls", "gi"], default="cornell",
                     help="cornell = the headline (BASELINE C4); balls = stand-in for the absent christmas_balls scene (C5): "
                          "128 tessellated spheres, 102 402 triangles, half of them mirrors, no photon map -- a BVH-bound "
-                         "frame, reported for insight only")
+                         "frame, reported for insight only; gi = BASELINE C3: the Cornell box with the live path-traced GI of "
+                         "RayTracingProj12 (its Shade, bounce 8, one hemisphere ray per hit), 800x600, 64 spp, no photon map")
     return ap.parse_args()
 
 
@@ -140,30 +142,38 @@ def parity_check(kept, frame):
 
 def profile_figures(default_workload):
     """What cannot be read from inside bench.py -- HBM bytes (FETCH_SIZE / WRITE_SIZE) and VALU instructions (SQ_INSTS_VALU)
-    per launch -- from the newest committed counter summaries (profiles/*_bench_pmc_hbm.json, *_bench_sq_counters.json:
+    per launch -- from the NEWEST committed counter summaries (profiles/r*_bench_pmc_hbm.json, r*_bench_sq_counters.json:
     separate rocprofv3 --pmc passes of this very command, condensed by tools_profile_summary.py, gfx950 x2 fetch
-    correction applied).  Only quoted for the default workload they were measured on."""
+    correction applied).  Only quoted for the default workload they were measured on, and only for the kernel build they
+    were measured on: each summary carries the hash of the kernel sources + build flags of its run (`kernel_source_sha16`);
+    when that differs from the build in this tree, or the live launch time of a kernel differs from the file's by more than
+    5 %, the figures are reported as STALE instead of quoted (main() then emits frac: null, stale_profile: true)."""
     import glob
-    out = {"hbm": {}, "hbm_launches": {}, "valu": {}, "hbm_source": None, "valu_source": None}
+    from raytracing_folder_amd import buildinfo
+    out = {"hbm": {}, "hbm_launches": {}, "valu_insts": {}, "file_launch_us": {}, "hbm_source": None, "valu_source": None,
+           "build": buildinfo.kernel_source_sha16(), "stale": []}
     if not default_workload:
         return out
-    for key, pat in (("hbm", "*_bench_pmc_hbm.json"), ("valu", "*_bench_sq_counters.json")):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02" + pat)))
+    for key, pat in (("hbm", "_bench_pmc_hbm.json"), ("valu", "_bench_sq_counters.json")):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*" + pat)))
         if not files:
             continue
         try:
             d = json.load(open(files[-1]))
+            if d.get("kernel_source_sha16") != out["build"]:
+                out["stale"].append(f"{os.path.basename(files[-1])}: collected on kernel build {d.get('kernel_source_sha16')}, this tree is {out['build']}")
             for k, v in d["kernels"].items():
                 name = k.split("<")[0]
                 if key == "hbm":
                     out["hbm"][name] = float(v["hbm_bytes_per_launch"])
                     out.setdefault("hbm_launches", {})[name] = float(v["FETCH_SIZE"]["launches"])
                 elif "SQ_INSTS_VALU" in v and v.get("avg_launch_us"):
-                    # (clipped at 1 for safety: the peak assumes 2.4 GHz)
-                    out["valu"][name] = min(1.0, float(v["SQ_INSTS_VALU"]) / (float(v["avg_launch_us"]) * 1e3) / VALU_PEAK_GINST)
+                    # wave instructions and microseconds per profiled FRAME (the counter passes profile exactly one frame)
+                    out["valu_insts"][name] = float(v["SQ_INSTS_VALU"]) * float(v.get("launches", 1))
+                    out["file_launch_us"][name] = float(v["avg_launch_us"]) * float(v.get("launches", 1))
             out[key + "_source"] = os.path.basename(files[-1])
-        except Exception:
-            pass
+        except Exception as e:
+            out["stale"].append(f"{os.path.basename(files[-1])}: unreadable ({e})")
     return out
 
 
@@ -208,16 +218,18 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before anything is timed -------------------------
     balanced = None
+    if a.workload == "gi" and (a.width, a.height) == (1920, 1080):
+        a.width, a.height = 800, 600                       # BASELINE config C3's size unless another one was asked for
     if a.workload == "balls":
         s, cam = workloads.make_balls_scene(a.width, a.height)
     else:
         s, cam = workloads.load_cornell(a.width, a.height)
-    if a.workload == "balls":
+    if a.workload in ("balls", "gi"):
         pass
     elif a.synthetic_photons:
         balanced = photons.synth_cornell_photon_map(a.photons, seed=20171203)
     setup_ms = None
-    if a.workload != "balls" and not a.synthetic_photons:
+    if a.workload == "cornell" and not a.synthetic_photons:
         # generatePhotonMap as a whole on the GPU (FIN/main.cpp:350-402; counter RNG, seed 20171203): photon pass ->
         # compaction -> the few photons balancing would put out of LocatePhotons' reach (host) -> gather structure; identical
         # on every rank.  Untimed set-up of the frame metric, reported as setup_ms (the reference's own timer spans it,
@@ -228,6 +240,9 @@ def main():
         s.set_photons(balanced)
     n_photons = s.counts()["photons"]
     p = capi.default_params(min_sample=a.spp, max_sample=a.spp, threshold=-1.0)
+    if a.workload == "gi":
+        # RayTracingProj12 main.cpp:17-25 (BOUNCE 8, HEMISPHERE_SAMPLE 1) and its Shade (:341-588)
+        p.shade_model, p.bounce, p.hemisphere_sample = capi.SHADE_P12, 8, 1
     R = ShardedRenderer(s, cam, p, rank, world, local, host_gather=rehearsal)
 
     def barrier():
@@ -236,16 +251,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Warm-up frames are synchronous (statistics, queue sizes from measurement); the K timed frames are ENQUEUED back to back
+    # on the renderer's stream -- render, all-gather and un-interleave of a frame follow each other in stream order, a frame
+    # is ordered behind the one before it on the GPU -- with no host round trip in between; finish() waits for all of them
+    # and raises if any dropped a ray.  (--sync-steps: every step waits for its frame, as rounds 1 and 2 timed it.)
+    st_warm = None
     for _ in range(max(a.warmup, 0)):
-        R.step()
+        st_warm, _ = R.step()
     barrier()
     t0 = time.perf_counter()
     stats, step_ms = [], []
     for _ in range(a.steps):
         t_step = time.perf_counter()
-        st, frame = R.step()
-        stats.append(st.as_dict())
-        step_ms.append(round((time.perf_counter() - t_step) * 1e3, 2))      # this rank's steps as it saw them (R.step() returns with its statistics)
+        st, frame = R.step(sync=a.sync_steps or st_warm is None)            # (without a warm-up the first timed frame is the synchronous one)
+        st_warm = st if st is not None else st_warm
+        stats.append(st_warm.as_dict())                                      # the same frame every step: the last synchronous frame's counts hold
+        step_ms.append(round((time.perf_counter() - t_step) * 1e3, 2))      # this rank's steps as the host saw them (enqueue time when asynchronous)
+    R.finish()
     barrier()
     dt = time.perf_counter() - t0
     if a.steps > 0:
@@ -323,8 +345,20 @@ def main():
                     hb = sum(figs["hbm"][q] * figs["hbm_launches"][q] for q in parts)
                     row["hbm_bytes_per_frame"] = int(hb)
                     row["hbm_frac"] = round(hb / sec / 1e9 / HBM_PEAK_GBS, 4)
-                if all(q in figs["valu"] for q in parts):
-                    row["valu_frac"] = round(max(figs["valu"][q] for q in parts), 4)
+                q0 = parts[0]
+                if q0 in figs["valu_insts"] and sec > 0 and c["launches"] > 0:
+                    # VALU issue fraction of the DOMINANT kernel of the class: counted instructions per launch (profile) / LIVE
+                    # exclusive time per launch.  Peak = one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz (inferred
+                    # in round 2 from a build that came out at 1.17 of the 4-cycle figure; not pinned by a microbenchmark);
+                    # NOT clamped: a value above 1 would show the peak is mispriced.
+                    live_us = c["ms"] * 1e3                                     # this class, per frame, exclusive
+                    row["valu_frac"] = round(figs["valu_insts"][q0] / (live_us * 1e3) / VALU_PEAK_GINST, 4)
+                    row["live_us_per_frame"] = round(live_us, 1)
+                    row["profile_us_per_frame"] = round(figs["file_launch_us"][q0], 1)
+                    # (the tracer class also holds the k_bounce launches behind k_wavefront: compared with a wider margin)
+                    margin = 0.05 if name != "k_wavefront+k_bounce" else 0.10
+                    if abs(live_us - figs["file_launch_us"][q0]) > margin * figs["file_launch_us"][q0]:
+                        figs["stale"].append(f"{q0}: live {live_us:.0f} us per frame vs {figs['file_launch_us'][q0]:.0f} us in {figs['valu_source']}")
                 table[name] = row
             dom = max(classes, key=lambda k: classes[k]["ms"])
             d, c = table[dom], classes[dom]
@@ -338,8 +372,15 @@ def main():
                 ach, peak, unit = d["l2_GBps"], L2_PEAK_GBS, "GB/s"
             else:
                 ach, peak, unit = fr["valu"] * VALU_PEAK_GINST, VALU_PEAK_GINST, "Gwave-inst/s"
-            roof = {"kernel": dom, "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit, "frac": round(fr[bound], 4),
-                    "traffic": int(figs["hbm"][dom]) if dom in figs["hbm"] else None,
+            stale = bool(figs["stale"])
+            if stale:
+                # counter-derived fractions belong to other kernels than the ones that just ran: not quoted
+                fr = {"hbm": None, "l2": fr["l2"], "valu": None}
+            roof = {"kernel": dom, "bound": bound if not stale else "l2", "achieved": round(ach, 2) if not stale else d["l2_GBps"],
+                    "peak": round(peak, 1) if not stale else L2_PEAK_GBS, "unit": unit if not stale else "GB/s",
+                    "frac": round(fr[bound], 4) if not stale else None, "stale_profile": stale, "stale_reasons": figs["stale"],
+                    "kernel_build": figs["build"], "valu_peak_note": "one wave64 VALU instruction per 2 cycles per SIMD: inferred from measurement (round 2), unclamped",
+                    "traffic": int(figs["hbm"][dom]) if dom in figs["hbm"] and not stale else None,
                     "traffic_source": figs["hbm_source"], "valu_source": figs["valu_source"],
                     "fractions": fr,
                     "avg_launch_ms": round(sec_launch * 1e3, 4), "launches_per_frame": round(launches, 1),
@@ -358,11 +399,14 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("C5 stand-in: 128 tessellated spheres (102 402 triangles, half mirrors) on a ground quad under a PNG sky "
                                     f"(environment + background), FIN shading, {a.width}x{a.height}, {a.spp} spp fixed, no photon map, bounce 4") if a.workload == "balls" else
+                                   (f"C3: Cornell box, RayTracingProj12 shading (live path-traced GI: one cosine-hemisphere ray per hit), {a.width}x{a.height}, "
+                                    f"{a.spp} spp fixed, bounce 8, no photon map") if a.workload == "gi" else
                                    f"Cornell box, FIN shading, {a.width}x{a.height}, {a.spp} spp fixed, "
                                    f"{n_photons}-photon map ({'sprinkled on the walls' if a.synthetic_photons else 'GPU photon pass, Philox seed 20171203, 8 bounces'}), "
                                    f"k=400 r=1, bounce 4",
                        "tiles": "32x8 interleaved, tile t -> rank t mod N", "exchange": "one all_gather of 8 B/pixel per frame"},
             "frame_ms": round(dt / a.steps * 1e3, 2),
+            "render_attempts": int(max(x.get("attempts", 1) for x in stats)) if stats else None,
             "setup_ms": setup_ms,
             "step_ms_rank0": step_ms,
             "gather_ms": round(gather_ms, 3),

@@ -209,6 +209,8 @@ typedef struct rt_stats {
     uint64_t launches_primary, launches_bounce;
     uint64_t streams;               /* chunks in flight at once during this call                     */
     uint64_t peak_rays, peak_queries;   /* largest ray-queue level / photon-query count of any chunk */
+    uint64_t attempts;              /* ABI 3: 1, or 2 when queues sized from history overflowed and the library rendered the
+                                       frame again with worst-case queues (the statistics are those of the last attempt) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;   /* opaque */

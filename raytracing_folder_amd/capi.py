@@ -71,7 +71,7 @@ class Stats(C.Structure):
                 [(n, C.c_uint64) for n in ("launches_trace", "launches_gather", "launches_resolve",
                                            "gather_rounds", "gather_slow", "gather_leaf_reads")] +
                 [(n, C.c_double) for n in ("ms_primary", "ms_bounce")] +
-                [(n, C.c_uint64) for n in ("launches_primary", "launches_bounce", "streams", "peak_rays", "peak_queries")])
+                [(n, C.c_uint64) for n in ("launches_primary", "launches_bounce", "streams", "peak_rays", "peak_queries", "attempts")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

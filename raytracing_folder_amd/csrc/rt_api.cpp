@@ -27,7 +27,7 @@ void rtk_launch_bounce(hipStream_t, const DevScene &, const DevWork &, const rt_
                        const DevRayQueue &, uint32_t *, int, int);
 void rtk_launch_trace(hipStream_t, const DevScene &, int, const float *, long long, uint8_t *, float *, float *, float *, int32_t *, uint8_t *);
 bool rtk_launch_wavefront_queue(hipStream_t, const DevScene &, const DevWork &, const rt_params &, const DevRayQueue &, const uint32_t *,
-                                const DevRayQueue &, uint32_t *);
+                                const DevRayQueue &, uint32_t *, const DevCamera &, const DevTiles &, uint32_t, int, int);
 void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const float4 *, const float4 *, const uint32_t *,
                        uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint32_t *, float *);
 void rtk_launch_resolve(hipStream_t, const DevScene &, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
@@ -59,6 +59,7 @@ void rtk_photon_copy_skipping(hipStream_t, const rt_photon *in, uint32_t n_in, c
 size_t rtk_photon_structure_scratch(uint32_t n, uint32_t n_sub);
 hipError_t rtk_photon_structure(hipStream_t, const rt_photon *ph, uint32_t n, uint32_t n_sub, float4 *pa, float4 *pb, float4 *box4,
                                 uint32_t *grid, PhotonGridOut *grid_out, void *scratch, size_t scratch_bytes);
+void rtk_photon_cell_start(hipStream_t, const float4 *tbox, uint32_t n_leaves, const float grid_min[3], float cell, const int dim[3], float radius, uint32_t *start);
 
 // ---- errors ---------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -160,6 +161,7 @@ struct DeviceState {
     // per density-grid cell, the k-th squared distance of the last query k_gather answered there: predicts the next one's (a
     // hint that only steers which of two exact paths a query takes); zeroed whenever the structure is rebuilt
     DevBuf cell_rk2, ccell_rk2;
+    DevBuf cell_start, ccell_start;             // DevPhotonMap::cell_start of the two maps (built for the gather radius in use)
     DevScene scene{};
     Workspace ws[RT_STREAMS];
     DevBuf stats;
@@ -180,7 +182,7 @@ struct DeviceState {
     void release()
     {
         for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &box4, &grid, &cpa, &cpb, &cbox4, &cgrid,
-                          &raw_photons, &cell_rk2, &ccell_rk2, &stats, &t_in}) b->release();
+                          &raw_photons, &cell_rk2, &ccell_rk2, &cell_start, &ccell_start, &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
         for (Workspace &w : ws) w.release();
         for (int k = 0; k < 6; k++) t_out[k].release();
@@ -696,6 +698,7 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
     const rt::SceneData &sd = s->data;
     if (sd.nodes.empty()) return fail(RT_ERR_STATE, "scene has no nodes");
     if (sd.nodes.size() > 65535) return fail(RT_ERR_LIMIT, "too many scene nodes (%zu)", sd.nodes.size());
+    if (sd.materials.size() > 65535) return fail(RT_ERR_LIMIT, "too many materials (%zu): ray records carry 16-bit material indices", sd.materials.size());
     const int nn = (int)sd.nodes.size();
     std::vector<DevNodeXf> xf(nn);
     std::vector<int32_t> node_mat(nn, 0);
@@ -764,6 +767,7 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
     for (auto &mb : D->mesh_bufs) { mb.nodes.release(); mb.tris.release(); mb.tri_face.release(); mb.nrm.release(); mb.tex.release(); }
     D->mesh_bufs.assign(sd.meshes.size(), DevMeshBufs());
     std::vector<DevMesh> dm(sd.meshes.size());
+    int max_depth = 0;
     for (size_t mi = 0; mi < sd.meshes.size(); mi++) {
         const rt::MeshData &m = sd.meshes[mi];
         memset(&dm[mi], 0, sizeof(DevMesh));
@@ -773,6 +777,7 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
         int depth = 0;
         if ((st = convert_bvh(m, bn, root_ref, depth))) return st;
         if (depth > RT_BVH_STACK) return fail(RT_ERR_LIMIT, "mesh %zu: BVH depth %d exceeds the device traversal stack (%d)", mi, depth, RT_BVH_STACK);
+        max_depth = std::max(max_depth, depth);
         const size_t nf = m.f.size() / 3;
         std::vector<DevTri> tris(nf);
         std::vector<uint32_t> tri_face(nf);
@@ -833,6 +838,10 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
     S.material_maps = sd.material_maps.empty() ? nullptr : (const rt_texmap *)D->material_maps.p;
     S.env_map = sd.env_map; S.bg_map = sd.bg_map;
     S.use_uvw = sd.material_maps.empty() ? 0 : 1;
+    S.max_bvh_depth = max_depth;
+    S.stochastic = 0;
+    for (const rt_light &l : sd.lights) if (l.type == RT_LIGHT_POINT && l.size != 0) S.stochastic = 1;
+    for (const rt_blinn &m : sd.materials) if (m.reflection_glossiness != 0 || m.refraction_glossiness != 0) S.stochastic = 1;
     D->scene_valid = true;
     return RT_OK;
 }
@@ -1086,6 +1095,21 @@ static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const 
     return RT_OK;
 }
 
+// DevPhotonMap::cell_start for the radius the gather is about to use: built on first use and again when a larger radius comes
+// (a table built for a radius serves every smaller one), on the stream the gather will run on
+static rt_status ensure_cell_start(DeviceState *D, bool caustic, float radius, hipStream_t st)
+{
+    DevPhotonMap &pm = caustic ? D->scene.cm : D->scene.pm;
+    if (pm.n_leaves < 2 || (pm.cell_start && radius <= pm.start_radius)) return RT_OK;
+    DevBuf &b = caustic ? D->ccell_start : D->cell_start;
+    rt_status s = b.ensure((size_t)64 * 64 * 64 * 4);
+    if (s) return s;
+    rtk_photon_cell_start(st, pm.tbox, pm.n_leaves, pm.grid_min, pm.cell, pm.grid_dim, radius, (uint32_t *)b.p);
+    HIP_TRY(hipGetLastError());
+    pm.cell_start = (const uint32_t *)b.p; pm.start_radius = radius;
+    return RT_OK;
+}
+
 struct Timing { std::vector<hipEvent_t> ev; std::vector<int> cls; };
 
 static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const DevWork &W, const rt_params &P, Timing *tm,
@@ -1113,15 +1137,18 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
     // k_wavefront's overflow (level-1 queue) first goes through a second k_wavefront pass; what overflows again, and the
     // models without that kernel, take one launch per level
     int first_level = 1;
-    if (max_level >= 2 && rtk_launch_wavefront_queue(st, D->scene, W, P, W.rq[1], W.counts + 1, W.rq[0], W.counts + 2)) first_level = 2;
+    if (max_level >= 2 && rtk_launch_wavefront_queue(st, D->scene, W, P, W.rq[1], W.counts + 1, W.rq[0], W.counts + 2, dc, dt, q0, max_sample, mode)) first_level = 2;
     for (int level = first_level; level <= max_level && level < 15; level++)
         rtk_launch_bounce(st, D->scene, W, P, W.rq[level & 1], W.rq[(level + 1) & 1], W.counts + level + 1, level, max_blocks);
     if ((s = mark(1))) return s;
+    rt_status cs;
+    if ((cs = ensure_cell_start(D, false, P.knn_radius, st))) return cs;
     if (D->scene.pm.n_leaves) {
         rtk_launch_gather(st, D->scene.pm, W.pq.qa, W.pq.qb, W.pq.qc, W.counts + CNT_PHOTONQ, W.pq.cap, P.knn_k, P.knn_radius,
                           W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, W.counts + CNT_GATHER_NEXT, (float *)D->cell_rk2.p);
         if ((s = mark(2))) return s;
     }
+    if (D->scene.cm.n_leaves && P.caustic_k > 0 && W.cq.cap && (cs = ensure_cell_start(D, true, P.caustic_radius, st))) return cs;
     if (D->scene.cm.n_leaves && P.caustic_k > 0 && W.cq.cap) {
         // the P13-family models queued their caustic lookups separately: same kernel on the second map
         rtk_launch_gather(st, D->scene.cm, W.cq.qa, W.cq.qb, W.cq.qc, W.counts + CNT_CAUSTICQ, W.cq.cap, P.caustic_k, P.caustic_radius,
@@ -1148,9 +1175,14 @@ static rt_status render_tiles(rt_scene *s, const rt_camera *cam, const rt_params
 {
     rt_status st = render_tiles_once(s, cam, p, tiles, device, user_stream, use_user_stream, rgb8_dev, z_dev, count_dev, sync, stats_out, job,
                                      packed_dev, false);
-    if (st == RT_ERR_OVERFLOW_RETRY)
+    int attempts = 1;
+    if (st == RT_ERR_OVERFLOW_RETRY) {
+        attempts = 2;
         st = render_tiles_once(s, cam, p, tiles, device, user_stream, use_user_stream, rgb8_dev, z_dev, count_dev, sync, stats_out, job,
                                packed_dev, true);
+    }
+    if (st == RT_OK && stats_out) stats_out->attempts = (uint64_t)attempts;
+    if (st == RT_OK && job) job->stats.attempts = (uint64_t)attempts;
     return st;
 }
 
@@ -1208,7 +1240,17 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         // floors: how many rays k_wavefront cannot keep in LDS depends on timing, and a view change can bring glass into a
         // frame that had none -- one ray and a quarter of a query per sample cost 1.4 GB per working set and cover both
         if (hist_ok) { ray_factor = std::max(2.0 * H.rays_per_sample, 1.0); query_factor = std::max(2.0 * H.queries_per_sample, 0.25); }
-        else if (sync || job) { ray_factor = 1.0; query_factor = 0.5; }
+        else if (sync || job) {
+            // first render of a kind: from the model's fan-out.  k_wavefront keeps the ray tree in LDS (the global queue only sees
+            // what does not fit).  The per-level models put a whole level into the queue: about one hemisphere ray per path that
+            // is still alive (P12: hemisphere_sample of them on the first level, RayTracingProj12 main.cpp:393-446) PLUS the
+            // ungated reflection / refraction pairs of the P13-family Shade, which double level by level inside glass
+            // (P13/main.cpp:633-751: measured 2.5 rays per sample on the fullest level of a Cornell chunk that holds the glass
+            // sphere, bounce 8) -- four per sample on top of the hemisphere rays, 640 B per sample of queue memory
+            const bool wf = (p->shade_model == RT_SHADE_FIN || p->shade_model == RT_SHADE_P13) && getenv("RT_TRACER") == nullptr;
+            ray_factor = wf ? 1.0 : (p->shade_model == RT_SHADE_P12 ? (double)std::max(p->hemisphere_sample, 1) + 3.0 : 4.0);
+            query_factor = 0.5;
+        }
     }
     D->qhist_used = ray_factor > 0 || query_factor > 0;
     DevWork Ws[RT_STREAMS];
@@ -1264,6 +1306,9 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         HIP_TRY(hipMemsetAsync(Ws[0].stats + ST_QUEUE_OVERFLOW, 0, 8, stream));
         HIP_TRY(hipMemsetAsync(Ws[0].stats + ST_PEAK_RAYS, 0, 16, stream));
     }
+    // the gathers' start tables are built on `stream` before the slots fork from it
+    if ((st = ensure_cell_start(D, false, p->knn_radius, stream))) return st;
+    if (use_caustic && (st = ensure_cell_start(D, true, p->caustic_radius, stream))) return st;
     // slot 0 runs on `stream` itself; the other slots' streams start after everything already queued on
     // `stream` (fork) and `stream` waits for them at the end (join), so the call keeps stream-order semantics
     auto slot_stream = [&](int slot) { return slot == 0 ? stream : D->ws[slot].stream; };
@@ -1667,6 +1712,7 @@ extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, 
     if ((st = D->t_out[3].ensure((size_t)n * 12))) return st;
     if ((st = D->t_out[4].ensure((size_t)n * 12))) return st;
     if ((st = D->t_in.upload(cnt, sizeof cnt))) return st;
+    if ((st = ensure_cell_start(D, false, radius, D->stream))) return st;
     rtk_launch_gather(D->stream, D->scene.pm, (const float4 *)D->t_out[0].p, (const float4 *)D->t_out[1].p, (const float4 *)D->t_out[2].p,
                       (const uint32_t *)D->t_in.p, cnt[0], k, radius, nullptr, (float *)D->t_out[3].p, (float *)D->t_out[4].p, 1, nullptr, GATHER_BLOCKS,
                       (uint32_t *)D->t_in.p + 1, nullptr);

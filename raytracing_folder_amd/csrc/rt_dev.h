@@ -83,6 +83,13 @@ struct DevPhotonMap {
     const uint32_t *grid;
     float grid_min[3]; float cell, inv_cell;
     int32_t grid_dim[3];
+    // per grid cell: the deepest node of the leaf-box tree (even depth, internal) whose subtree alone can hold photons within
+    // `start_radius` of ANY point of the cell -- every sibling subtree on the way down lies farther from the cell than that.
+    // A query inside the grid with a radius <= start_radius starts its walk there instead of at the root (the levels above
+    // are a chain of dependent box reads with one survivor each).  NULL / 0: start at the root.  Rebuilt when the gather
+    // radius grows (rt_api.cpp).
+    const uint32_t *cell_start;
+    float start_radius;
 };
 
 struct DevScene {
@@ -101,6 +108,8 @@ struct DevScene {
     const rt_texmap *material_maps;          // 2 per material, or NULL
     rt_texmap env_map, bg_map;
     int32_t use_uvw;
+    int32_t max_bvh_depth;       // deepest mesh BVH (levels): which tracer kernels' traversal stacks it fits
+    int32_t stochastic;          // some light has a size or some material a glossy reflection/refraction: shading draws random numbers
 };
 
 // camera set-up computed once on the host the way RenderPixel does it per thread

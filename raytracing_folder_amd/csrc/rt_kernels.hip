@@ -61,6 +61,12 @@
 #define RT_GATHER_CELLPRED 1   // 1: the k-th distance of the last query answered in a density-grid cell predicts the band of the next one
                                // there (a table in HBM, written racily: a hint only); 0: the wave's previous query predicts
 #endif
+#ifndef RT_GATHER_CELLSTART
+#define RT_GATHER_CELLSTART 1  // 1: a query inside the density grid starts its tree walk at its cell's start node (DevPhotonMap::cell_start)
+#endif
+#ifndef RT_GATHER_CELL_GUESS
+#define RT_GATHER_CELL_GUESS RT_GATHER_GUESS    // first trial radius^2 of a query whose cell remembers a k-th distance: that distance times this
+#endif
 #if RT_GATHER_FMA
 #define RT_FP_CONTRACT _Pragma("clang fp contract(fast)")
 #else
@@ -492,12 +498,20 @@ __device__ __forceinline__ int __reduce_max_sync_compat(int v)
 struct PathIn { V3 o, d, thr, absorb; uint32_t slot; int bounce; uint32_t kind; bool primary; uint32_t node, sample; V3 side_dir, side_K;
                 uint32_t spec; };      // Shade's `specount` argument (P13/main.cpp:485): lights seen on the way, for the caustic lookup
 
+// How a sample slot of the chunk maps back to its global sample id (pixel * max_sample + j, the key of the counter RNG): the
+// LDS ray records of k_wavefront do not carry the id, it is recomputed for the rays of a scene that draws random numbers
+struct SlotMap { DevTiles tiles; int32_t width, height; uint32_t q0; int32_t max_sample, mode; FastDiv div_ms; };
+
 struct ShadeCtx {
     DevScene S; DevWork W; rt_params P;
     DevRayQueue qout; uint32_t *qout_count;
-    // k_wavefront only: the workgroup's ray stack in LDS (same four 16-byte words per ray as the global queue);
-    // children go there first and to qout only when it is full.  NULL in the per-level kernels.
-    float4 *lds_a, *lds_b, *lds_c; uint4 *lds_d; uint32_t *lds_count; uint32_t lds_cap;
+    // k_wavefront only: the workgroup's ray stack in LDS, THREE 16-byte words per ray (48 B):
+    //   a = (o.xyz, d.x)   b = (d.yz, thr.r, thr.g)   c = (thr.b, slot, bounce | kind << 4 | spec << 8 | material << 16, node)
+    // -- the absorption the child needs on arrival travels as the index of the material that spawned it, the sample id is
+    // recomputed from the slot (SlotMap).  Children go there first and to qout (the 64-byte global form) only when it is
+    // full.  NULL in the per-level kernels.
+    float4 *lds_a, *lds_b, *lds_c; uint32_t *lds_count; uint32_t lds_cap;
+    SlotMap sm;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -681,7 +695,7 @@ __device__ __forceinline__ void add_sample(const ShadeCtx &C, uint32_t slot, V3 
 template <bool SIDE = false>
 __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 d, V3 thr, V3 absorb,
                                          uint32_t slot, int bounce, uint32_t kind, uint32_t node, uint32_t sample,
-                                         V3 side_dir = V3{0, 0, 0}, V3 side_K = V3{0, 0, 0}, uint32_t spec = 0)
+                                         V3 side_dir = V3{0, 0, 0}, V3 side_K = V3{0, 0, 0}, uint32_t spec = 0, uint32_t mat = 0)
 {
     if (!SIDE && C.lds_count) {
         // workgroup-local stack first (LDS atomic, one per wave); what does not fit goes to the global queue
@@ -689,8 +703,7 @@ __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 
         if (pred && at < C.lds_cap) {
             C.lds_a[at] = make_float4(o.x, o.y, o.z, d.x);
             C.lds_b[at] = make_float4(d.y, d.z, thr.x, thr.y);
-            C.lds_c[at] = make_float4(thr.z, absorb.x, absorb.y, absorb.z);
-            C.lds_d[at] = make_uint4(slot, (uint32_t)bounce | (kind << 8) | (spec << 16), node, sample);
+            C.lds_c[at] = make_float4(thr.z, __uint_as_float(slot), __uint_as_float((uint32_t)bounce | (kind << 4) | (spec << 8) | (mat << 16)), __uint_as_float(node));
         }
         pred = pred && at >= C.lds_cap;
         if (!__any(pred)) return;
@@ -737,6 +750,7 @@ struct ShadeOut {
     uint32_t spec_out;               // P13: specount handed to the children
     int n_gi;                        // P12: hemisphere rays to spawn (weights/dirs are drawn at push time)
     V3 gi_x, gi_y, gi_z;             // P12: frame of the hemisphere
+    uint32_t mat;                    // index of the hit's material (what child_absorb was read from)
 };
 
 // MtlBlinn::Shade, FIN/main.cpp:516-708
@@ -805,6 +819,7 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
     o.want_photon = (bounce != P.bounce) && S.pm.n_leaves != 0;
     o.color = color; o.kd = kd; o.N = N;
     o.child_absorb = ld3(m.absorption);      // children: K *= Attenuation(absorption, z) on a back-face hit (:620,:632)
+    o.mat = (uint32_t)S.node_material[h.node];
 }
 
 // MtlBlinn::Shade, P13/main.cpp:485-756 (reflectionGlossiness == refractionGlossiness == 0).
@@ -915,6 +930,7 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
     o.want_photon = false;
     o.kd = Kd; o.N = h.N;
     o.child_absorb = mk(m.absorption[0], 0, 0);          // refraction child: *= exp(-absorption.r * z) (:728)
+    o.mat = (uint32_t)S.node_material[h.node];
 }
 
 // MtlBlinn::Shade of RayTracingProj3, main.cpp:152-190: ambient + Blinn with V = camera.pos - p (all P3
@@ -1046,7 +1062,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
     o.rdir = o.tdir = mk(0, 0, 1); o.rK = o.tK = o.child_absorb = o.kd = o.N = mk(0, 0, 0);
     o.n_gi = 0; o.gi_x = o.gi_y = o.gi_z = mk(0, 0, 1);
     o.want_side = false; o.side_dir = mk(0, 0, 1); o.side_K = mk(0, 0, 0);
-    o.n_caustic = 0; o.spec_out = in.spec;
+    o.n_caustic = 0; o.spec_out = in.spec; o.mat = 0;
     constexpr bool p6 = MODEL == RT_SHADE_P6, p3 = MODEL == RT_SHADE_P3;
     bool spawn_side = false;
     if (active && !in.primary) {
@@ -1079,7 +1095,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
     }
     // pushes are wave-collective: every lane of the wave reaches them
     push_ray(C, o.want_refl, h.p, o.rdir, thr * o.rK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFLECT,
-             child_node(in.node, 1u), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out);
+             child_node(in.node, 1u), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out, o.mat);
     if (p6) {
         const V3 sK = thr * o.side_K;
         push_ray<true>(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
@@ -1088,7 +1104,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
         push_ray(C, spawn_side, in.o, in.side_dir, in.side_K, mk(0, 0, 0), in.slot, in.bounce, KIND_REFLECT, child_node(in.node, 4u), in.sample);
     } else
     push_ray(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
-             child_node(in.node, 2u), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out);
+             child_node(in.node, 2u), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out, o.mat);
     push_photon_query(C, o.want_photon, h.p, o.N, thr * o.kd, in.slot);
     if (p13) {
         // cau_Color += Kd * causticrad * theta, once per counted light (P13/main.cpp:518-531): one query, weight x count
@@ -1302,23 +1318,47 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
 // the stack full goes to the global queue and is picked up by the per-level k_bounce launches that follow
 // (normally empty).  FIN and P13 models (at most two children per hit); the others keep the per-level kernels.
 // ------------------------------------------------------------------------------------------------
-#ifndef RT_WF_STACK
-#define RT_WF_STACK 704        // rays per workgroup stack: 4 x 16 B x 704 = 44 KB next to the 32 KB of BVH stacks -> 2 workgroups per CU (79.9 KB each)
-#endif
-#ifndef RT_WF_POP
-#define RT_WF_POP (RT_WF_STACK - 2 * RT_BLOCK + 1 < RT_BLOCK ? RT_WF_STACK - 2 * RT_BLOCK + 1 : RT_BLOCK)    // 193 for a 704-ray stack
-#endif
+// Configuration: the texture-free instantiations run THREE workgroups per CU (3 waves/SIMD: the traversal waits on dependent
+// loads for 0.44 of its wave cycles at two) -- 168 VGPRs, and per workgroup at most 53 760 B of LDS (160 KB / 3 in 1280-byte
+// granules): 24 BVH stack entries per lane (24.6 KB; meshes deeper than that take the per-level kernels, see
+// rtk_launch_primary) + a 592-ray stack of 48-byte records (28.4 KB) + two 64-entry Halton tables.  The textured ones need
+// 255 VGPRs anyway: two workgroups per CU, 32-entry BVH stacks, 1008 rays.
 #ifndef RT_WF_WAVES
-#define RT_WF_WAVES 2          // waves per SIMD = workgroups per CU the kernel is built for
+#define RT_WF_WAVES 3          // waves per SIMD = workgroups per CU of the texture-free instantiations
 #endif
-template <int MODEL, bool TEX>
-__attribute__((amdgpu_waves_per_eu(RT_WF_WAVES, RT_WF_WAVES))) __global__ __launch_bounds__(RT_BLOCK) void k_wavefront(ShadeCtx C, PrimaryArgs A)
+#ifndef RT_WF_BVH
+#define RT_WF_BVH (RT_WF_WAVES >= 3 ? 24 : RT_BVH_STACK)
+#endif
+#ifndef RT_WF_STACK
+#define RT_WF_STACK (RT_WF_WAVES >= 3 ? 592 : 1008)
+#endif
+#define RT_WF_HALTON 64
+template <bool TEX> struct WfCfg {
+    static constexpr int WAVES = TEX ? 2 : RT_WF_WAVES;
+    static constexpr int BVH = TEX ? RT_BVH_STACK : RT_WF_BVH;
+    static constexpr int STACK = TEX ? 1008 : RT_WF_STACK;
+    // pop a round as soon as a round of primary rays (two children each) could no longer be sure to fit
+    static constexpr int POP = STACK - 2 * RT_BLOCK + 1 < RT_BLOCK ? STACK - 2 * RT_BLOCK + 1 : RT_BLOCK;
+    static_assert(BVH * RT_BLOCK * 4 + STACK * 48 + 2 * RT_WF_HALTON * 4 + 16 <= (WAVES >= 3 ? 53760 : 81920), "LDS budget of the occupancy the kernel is built for");
+};
+// global sample id of a chunk slot (see SlotMap)
+__device__ __forceinline__ uint32_t sample_of_slot(const SlotMap &M, uint32_t slot)
 {
-    __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
-    __shared__ float4 s_qa[RT_WF_STACK], s_qb[RT_WF_STACK], s_qc[RT_WF_STACK];
-    __shared__ uint4 s_qd[RT_WF_STACK];
+    if (M.mode == 2) return M.q0 + slot;
+    const uint32_t ql = fastdiv(slot, M.div_ms), j = slot - ql * (uint32_t)M.max_sample;
+    DevCamera cam; cam.width = M.width; cam.height = M.height;
+    int x = 0, y = 0;
+    pixel_of(M.tiles, cam, M.q0 + ql, x, y);
+    return ((uint32_t)y * (uint32_t)M.width + (uint32_t)x) * (uint32_t)M.max_sample + j;
+}
+template <int MODEL, bool TEX>
+__attribute__((amdgpu_waves_per_eu(TEX ? 2 : RT_WF_WAVES, TEX ? 2 : RT_WF_WAVES))) __global__ __launch_bounds__(RT_BLOCK) void k_wavefront(ShadeCtx C, PrimaryArgs A)
+{
+    using Cfg = WfCfg<TEX>;
+    __shared__ uint32_t s_stack[Cfg::BVH * RT_BLOCK];
+    __shared__ float4 s_qa[Cfg::STACK], s_qb[Cfg::STACK], s_qc[Cfg::STACK];
     __shared__ uint32_t s_count, s_batch;
-    __shared__ float s_h2[RT_BLOCK], s_h3[RT_BLOCK];
+    __shared__ float s_h2[RT_WF_HALTON], s_h3[RT_WF_HALTON];
     uint32_t *stack = s_stack + threadIdx.x;
     Counters cnt = {0, 0, 0, 0};
     uint32_t nprim = 0, nrefl = 0, nrefr = 0;
@@ -1328,20 +1368,20 @@ __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES, RT_WF_WAVES))) __global__ __laun
     const unsigned long long total = A.mode == 3 ? (unsigned long long)min(*A.qsrc_count, A.qsrc.cap)
                                                  : (unsigned long long)npix * (unsigned long long)A.ns;
     const unsigned long long n_batches = (total + RT_BLOCK - 1) / RT_BLOCK;
-    const bool h_table = A.mode < 2 && A.ns <= RT_BLOCK;
+    const bool h_table = A.mode < 2 && A.ns <= RT_WF_HALTON;
     uint32_t *next_batch = C.W.counts + (A.mode == 3 ? CNT_WF2_NEXT : CNT_PRIMARY_NEXT);
     if (h_table && (int)threadIdx.x < A.ns) { s_h2[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 2); s_h3[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 3); }
     if (threadIdx.x == 0) s_count = 0;
-    C.lds_a = s_qa; C.lds_b = s_qb; C.lds_c = s_qc; C.lds_d = s_qd; C.lds_count = &s_count; C.lds_cap = RT_WF_STACK;
+    C.lds_a = s_qa; C.lds_b = s_qb; C.lds_c = s_qc; C.lds_count = &s_count; C.lds_cap = Cfg::STACK;
     bool more_primaries = true;                           // workgroup-uniform
     for (;;) {
         __syncthreads();                                  // last round's pushes are complete
         uint32_t waiting = s_count;
-        if (waiting > RT_WF_STACK) waiting = RT_WF_STACK; // the excess went to the global queue
+        if (waiting > (uint32_t)Cfg::STACK) waiting = Cfg::STACK;   // the excess went to the global queue
         // pop a full workgroup's worth when there is one -- and already earlier when a round of primary rays (up to two
         // children each) could no longer be sure to fit: rays that do not fit go through the global queue and the
         // per-level launches, the slow path (measured: 5 ms per Cornell frame before this rule)
-        const bool pop = waiting >= RT_WF_POP || (!more_primaries && waiting > 0);
+        const bool pop = waiting >= (uint32_t)Cfg::POP || (!more_primaries && waiting > 0);
         if (!pop && !more_primaries) break;
         __syncthreads();                                  // everyone has read s_count
         PathIn in;
@@ -1359,16 +1399,22 @@ __attribute__((amdgpu_waves_per_eu(RT_WF_WAVES, RT_WF_WAVES))) __global__ __laun
             if (active) {
                 const uint32_t src = waiting - 1u - threadIdx.x;          // newest (deepest) first: the stack stays shallow
                 const float4 a = s_qa[src], b = s_qb[src], c = s_qc[src];
-                const uint4 dd = s_qd[src];
                 in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
-                in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
-                in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.spec = (dd.y >> 16) & 0xFFu; in.node = dd.z; in.sample = dd.w;
+                in.thr = mk(b.z, b.w, c.x);
+                in.slot = __float_as_uint(c.y);
+                const uint32_t pk = __float_as_uint(c.z);
+                in.bounce = (int)(pk & 0xFu); in.kind = (pk >> 4) & 0xFu; in.spec = (pk >> 8) & 0xFFu; in.node = __float_as_uint(c.w);
+                // what the child needs of its parent's material on arrival: Attenuation(absorption, z) (FIN/main.cpp:620,632),
+                // exp(-absorption.r * z) (P13/main.cpp:728)
+                const float *ab = C.S.materials[pk >> 16].absorption;
+                in.absorb = (MODEL == RT_SHADE_FIN) ? ld3(ab) : mk(ab[0], 0, 0);
+                if (C.S.stochastic) in.sample = sample_of_slot(C.sm, in.slot);
                 if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
             }
             __syncthreads();                              // all pops read before anything is pushed over them
             if (threadIdx.x == 0) s_count = waiting - n;
         } else {
-            if (threadIdx.x == 0) { s_batch = atomicAdd(next_batch, 1u); if (s_count > RT_WF_STACK) s_count = RT_WF_STACK; }
+            if (threadIdx.x == 0) { s_batch = atomicAdd(next_batch, 1u); if (s_count > (uint32_t)Cfg::STACK) s_count = Cfg::STACK; }
             __syncthreads();
             const unsigned long long batch = s_batch;
             if (batch >= n_batches) { more_primaries = false; continue; }
@@ -1946,18 +1992,25 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
         float r2cur = r2;
         float cell_pred = 0.0f;                              // this lane's query: what its grid cell remembers (RT_GATHER_CELLPRED)
         uint32_t cell_index = 0;
+        uint32_t walk_start = 1;                             // where this lane's query starts its tree walk (RT_GATHER_CELLSTART)
         if (have && n_leaves > 1) {
-            const int gx = min(max((int)((a.x - G.pm.grid_min[0]) * G.pm.inv_cell), 0), G.pm.grid_dim[0] - 1);
-            const int gy = min(max((int)((a.y - G.pm.grid_min[1]) * G.pm.inv_cell), 0), G.pm.grid_dim[1] - 1);
-            const int gz = min(max((int)((a.z - G.pm.grid_min[2]) * G.pm.inv_cell), 0), G.pm.grid_dim[2] - 1);
+            const float fx = (a.x - G.pm.grid_min[0]) * G.pm.inv_cell, fy = (a.y - G.pm.grid_min[1]) * G.pm.inv_cell, fz = (a.z - G.pm.grid_min[2]) * G.pm.inv_cell;
+            const int gx = min(max((int)fx, 0), G.pm.grid_dim[0] - 1);
+            const int gy = min(max((int)fy, 0), G.pm.grid_dim[1] - 1);
+            const int gz = min(max((int)fz, 0), G.pm.grid_dim[2] - 1);
             cell_index = (uint32_t)(((size_t)gz * G.pm.grid_dim[1] + gy) * G.pm.grid_dim[0] + gx);
+#if RT_GATHER_CELLSTART
+            // only for a point that really lies in its cell (points outside the photons' bounding box are clamped to the rim)
+            const bool in_grid = fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && (int)fx == gx && (int)fy == gy && (int)fz == gz;
+            if (G.pm.cell_start && in_grid && G.radius <= G.pm.start_radius) walk_start = G.pm.cell_start[cell_index];
+#endif
             const uint32_t cnt = G.pm.grid[cell_index];
             r2cur = fminf(fmaxf(guess_c / (float)(cnt > 0u ? cnt : 1u), r2 * 1.0e-4f), r2);
 #if RT_GATHER_CELLPRED
             if (G.cell_rk2) {
                 cell_pred = G.cell_rk2[cell_index];
                 // a cell that has seen a query also knows a better first radius than the density estimate: a little above its k-th distance
-                if (cell_pred > 0.0f) r2cur = fminf(fmaxf(cell_pred * RT_GATHER_GUESS, r2 * 1.0e-4f), r2);
+                if (cell_pred > 0.0f) r2cur = fminf(fmaxf(cell_pred * RT_GATHER_CELL_GUESS, r2 * 1.0e-4f), r2);
             }
 #endif
         }
@@ -1972,6 +2025,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
             const bool upper = lane >= 32;
             auto from_lower = [](float v) { return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false)[0]); };
             const float wx = from_lower(a.x), wy = from_lower(a.y), wz = from_lower(a.z), wr2 = from_lower(r2cur);
+            const uint32_t wstart = __builtin_amdgcn_permlane32_swap(walk_start, walk_start, false, false)[0];
             const bool walking = ((uint32_t)ballot64(pending) >> (lane & 31)) & 1u;
             auto both_halves = [](uint32_t mine, int bits) {       // my half's result bits -> lower half's | upper half's << bits, in every lane
                 const auto r = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
@@ -1991,7 +2045,8 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 if (box_dist2(G.pm.tbox + 2, wx, wy, wz) < wr2) {
                     if (n_leaves == 1) list_leaf(0u);
                     else {
-                        uint32_t node = 1, pd = 0;              // current internal node and its pair-depth (tree depth = 2 * pd)
+                        uint32_t node = wstart;                 // current internal node (the root, or the cell's start node: even depth) ...
+                        uint32_t pd = (31u - (uint32_t)__clz((int)node)) >> 1;      // ... and its pair-depth (tree depth = 2 * pd)
                         uint32_t todo_mask = 0;                 // nibble pd: grandchildren of the path's node at pair-depth pd still to visit (at most 65536 leaves: 8 nibbles)
                         for (;;) {
                             if (4u * node < 2u * n_leaves && 2u * node < n_leaves) {
@@ -2565,6 +2620,23 @@ static inline int grid_for(unsigned long long work, int block, int max_blocks)
     return (int)b;
 }
 
+static SlotMap make_slotmap(const DevCamera &cam, const DevTiles &tiles_prepared, uint32_t q0, int max_sample, int mode)
+{
+    SlotMap m; m.tiles = tiles_prepared; m.width = cam.width; m.height = cam.height; m.q0 = q0; m.max_sample = max_sample; m.mode = mode;
+    m.div_ms = fastdiv_make((uint32_t)(max_sample > 0 ? max_sample : 1));
+    return m;
+}
+// k_wavefront serves the FIN and P13 models (at most two children per hit) when every mesh's BVH fits the traversal stack the
+// kernel keeps in LDS (24 entries per lane at 3 workgroups per CU; deeper meshes take the per-level kernels with 32);
+// RT_TRACER=levels forces the per-level structure (A/B)
+static bool wavefront_usable(const DevScene &S, const rt_params &P, bool tex)
+{
+    static int wavefront = -1;
+    if (wavefront < 0) { const char *e = getenv("RT_TRACER"); wavefront = (e && !strcmp(e, "levels")) ? 0 : 1; }
+    if (!wavefront || !(P.shade_model == RT_SHADE_FIN || P.shade_model == RT_SHADE_P13)) return false;
+    return S.max_bvh_depth <= (tex ? RT_BVH_STACK : RT_WF_BVH);
+}
+
 void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
                         const DevRayQueue &qout, uint32_t *qout_count, const DevCamera &cam,
                         const DevTiles &tiles, uint32_t q0, uint32_t npix, int j0, int ns,
@@ -2577,13 +2649,12 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
     A.div_ns = fastdiv_make((uint32_t)(ns > 0 ? ns : 1));
     const int grid = grid_for((unsigned long long)npix * ns, RT_BLOCK, max_blocks);
     const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
-    C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_d = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
+    C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
+    C.sm = make_slotmap(cam, A.tiles, q0, max_sample, mode);
     // default: the whole ray tree in one persistent launch with LDS ray stacks (FIN / P13 models); RT_TRACER=levels: one
     // launch per level of the tree (round 1's structure, kept for the other models and for A/B: DESIGN.md section 3)
-    static int wavefront = -1;
-    if (wavefront < 0) { const char *e = getenv("RT_TRACER"); wavefront = (e && !strcmp(e, "levels")) ? 0 : 1; }
-    if (wavefront && (P.shade_model == RT_SHADE_FIN || P.shade_model == RT_SHADE_P13)) {
-        const int wgrid = grid_for((unsigned long long)npix * ns, RT_BLOCK, 256 * RT_WF_WAVES);      // resident workgroups per CU (LDS)
+    if (wavefront_usable(S, P, tex)) {
+        const int wgrid = grid_for((unsigned long long)npix * ns, RT_BLOCK, 256 * (tex ? 2 : RT_WF_WAVES));      // resident workgroups per CU (LDS)
         if (P.shade_model == RT_SHADE_FIN) {
             if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
             else hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
@@ -2609,19 +2680,23 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
 // queue as its source (their whole subtrees stay in LDS; what does not fit THIS time goes on to qout and the per-level
 // launches).  Returns false when the model has no wavefront kernel (the caller then starts the level launches at qin).
 bool rtk_launch_wavefront_queue(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
-                                const DevRayQueue &qin, const uint32_t *qin_count, const DevRayQueue &qout, uint32_t *qout_count)
+                                const DevRayQueue &qin, const uint32_t *qin_count, const DevRayQueue &qout, uint32_t *qout_count,
+                                const DevCamera &cam, const DevTiles &tiles, uint32_t q0, int max_sample, int mode)
 {
-    static int wavefront = -1;
-    if (wavefront < 0) { const char *e = getenv("RT_TRACER"); const char *q = getenv("RT_WF_QUEUE_PASS"); wavefront = ((e && !strcmp(e, "levels")) || (q && q[0] == '0')) ? 0 : 1; }
-    if (!wavefront || !(P.shade_model == RT_SHADE_FIN || P.shade_model == RT_SHADE_P13)) return false;
+    static int queue_pass = -1;
+    if (queue_pass < 0) { const char *q = getenv("RT_WF_QUEUE_PASS"); queue_pass = (q && q[0] == '0') ? 0 : 1; }
+    const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
+    if (!queue_pass || !wavefront_usable(S, P, tex)) return false;
     ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
-    C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_d = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
+    C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
+    DevTiles tp = tiles;
+    tiles_prepare(tp);
+    C.sm = make_slotmap(cam, tp, q0, max_sample, mode);
     PrimaryArgs A;
     memset(&A, 0, sizeof A);
     A.mode = 3; A.ns = 1; A.qsrc = qin; A.qsrc_count = qin_count;
     A.div_ns = fastdiv_make(1u);
-    const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
-    const int wgrid = 256 * RT_WF_WAVES;       // the count is on the device: a full persistent grid, idle workgroups leave at once
+    const int wgrid = 256 * (tex ? 2 : RT_WF_WAVES);       // the count is on the device: a full persistent grid, idle workgroups leave at once
     if (P.shade_model == RT_SHADE_FIN) {
         if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
         else hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
@@ -2637,7 +2712,8 @@ void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, cons
                        int level, int max_blocks)
 {
     ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
-    C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_d = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
+    C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
+    memset(&C.sm, 0, sizeof C.sm);
     const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
 #define RT_LAUNCH_BOUNCE(M) do { if (tex) hipLaunchKernelGGL((k_bounce<M, true>), dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level); \
                                  else hipLaunchKernelGGL((k_bounce<M, false>), dim3(max_blocks), dim3(RT_BLOCK), 0, st, C, qin, level); } while (0)

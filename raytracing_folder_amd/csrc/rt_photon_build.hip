@@ -334,3 +334,43 @@ hipError_t rtk_photon_structure(hipStream_t st, const rt_photon *ph, uint32_t n,
     hipLaunchKernelGGL(k_density_grid, dim3(grid_n), dim3(PB_BLOCK), 0, st, ph, n, rb[0], rb[1], rb[2], cell, grid_out->dim[0], grid_out->dim[1], grid_out->dim[2], grid);
     return hipGetLastError();
 }
+
+// ---- per-cell start node of the gather's tree walk (DevPhotonMap::cell_start) -------------------------------------------------
+__device__ __forceinline__ float boxbox_dist2(const float4 *b, const float lo[3], const float hi[3])
+{
+    const float4 blo = b[0], bhi = b[1];
+    const float gx = fmaxf(fmaxf(blo.x - hi[0], lo[0] - bhi.x), 0.0f);
+    const float gy = fmaxf(fmaxf(blo.y - hi[1], lo[1] - bhi.y), 0.0f);
+    const float gz = fmaxf(fmaxf(blo.z - hi[2], lo[2] - bhi.z), 0.0f);
+    return gx * gx + gy * gy + gz * gz;
+}
+__global__ __launch_bounds__(PB_BLOCK) void k_cell_start(const float4 *tbox, uint32_t n_leaves, float gx, float gy, float gz, float cell, int dx, int dy, int dz,
+                                                          float radius, uint32_t *start)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)(dx * dy * dz)) return;
+    const int x = (int)(i % (uint32_t)dx), y = (int)((i / (uint32_t)dx) % (uint32_t)dy), z = (int)(i / (uint32_t)(dx * dy));
+    // the cell, a little inflated: the query's cell index is computed in float from its position
+    const float pad = 1e-3f * cell;
+    const float lo[3] = {gx + x * cell - pad, gy + y * cell - pad, gz + z * cell - pad};
+    const float hi[3] = {gx + (x + 1) * cell + pad, gy + (y + 1) * cell + pad, gz + (z + 1) * cell + pad};
+    const float r2 = radius * radius * 1.0001f;
+    uint32_t node = 1;
+    for (;;) {
+        if (!(4u * node < 2u * n_leaves && 2u * node < n_leaves)) break;       // no grandchildren below this node
+        uint32_t hit = 0, which = 0;
+        for (uint32_t g = 0; g < 4; g++)
+            if (boxbox_dist2(tbox + 2 * (size_t)(4u * node + g), lo, hi) < r2) { hit++; which = g; }
+        if (hit != 1) break;
+        const uint32_t next = 4u * node + which;
+        if (next >= n_leaves) break;                                           // a leaf: the walk lists leaves from their grandparent
+        node = next;
+    }
+    start[i] = node;
+}
+void rtk_photon_cell_start(hipStream_t st, const float4 *tbox, uint32_t n_leaves, const float grid_min[3], float cell, const int dim[3], float radius, uint32_t *start)
+{
+    const uint32_t cells = (uint32_t)(dim[0] * dim[1] * dim[2]);
+    hipLaunchKernelGGL(k_cell_start, dim3((cells + PB_BLOCK - 1) / PB_BLOCK), dim3(PB_BLOCK), 0, st, tbox, n_leaves, grid_min[0], grid_min[1], grid_min[2], cell,
+                       dim[0], dim[1], dim[2], radius, start);
+}

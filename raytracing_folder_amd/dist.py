@@ -106,28 +106,35 @@ class ShardedRenderer:
     def _stream(self):
         return self.stream.cuda_stream
 
-    def render_own_tiles(self, want_stats=True):
+    def render_own_tiles(self, want_stats=True, sync=True):
         """this rank's tiles into the image planes (single-GPU path, and the profiling leg of bench.py)"""
         tiles = capi.TileRange(self.tile_w, self.tile_h, self.rank, self.world)
         return self.scene.render_tiles_device(self.cam, self.params, tiles, self.device_index, self.rgb.data_ptr(),
-                                              self.z.data_ptr(), self.cnt.data_ptr(), stream=self._stream(), sync=True,
+                                              self.z.data_ptr(), self.cnt.data_ptr(), stream=self._stream(), sync=sync,
                                               want_stats=want_stats)
 
-    def render_own_tiles_packed(self, want_stats=True):
+    def render_own_tiles_packed(self, want_stats=True, sync=True):
         tiles = capi.TileRange(self.tile_w, self.tile_h, self.rank, self.world)
         return self.scene.render_tiles_packed_device(self.cam, self.params, tiles, self.device_index, self.packed.data_ptr(),
-                                                     self.packed.numel(), stream=self._stream(), sync=True, want_stats=want_stats)
+                                                     self.packed.numel(), stream=self._stream(), sync=sync, want_stats=want_stats)
 
-    def step(self):
+    def step(self, sync=True):
+        """One frame.  sync=True: the call returns with the finished frame and this rank's statistics (the host waits for the
+        render before it starts the exchange).  sync=False: everything -- render, all-gather, un-interleave -- is only ENQUEUED
+        on this renderer's stream (the library orders a frame behind the one before it on the GPU, the collective follows in
+        stream order); no statistics, no host round trip between frames: call finish() before reading the frame.  The first
+        frame of a renderer should be a synchronous one (it sizes the queues from measurement; an asynchronous render
+        without history takes worst-case queues)."""
         if self.world == 1:
-            st = self.render_own_tiles()
+            st = self.render_own_tiles(want_stats=sync, sync=sync)
             self.gather_ms.append(0.0)
-            return st, (self.rgb, self.z, self.cnt)
+            return (st if sync else None), (self.rgb, self.z, self.cnt)
         import time
         with torch.cuda.stream(self.stream):
-            st = self.render_own_tiles_packed()                             # synchronous: this rank's tiles are final
+            st = self.render_own_tiles_packed(want_stats=sync, sync=sync)       # sync: this rank's tiles are final
             t0 = time.perf_counter()
             if self.host_gather:
+                self.stream.synchronize()
                 mine = self.packed.cpu()
                 gathered = torch.empty((self.world * self.per_rank,) + tuple(mine.shape[1:]), dtype=torch.uint8)
                 dist.all_gather_into_tensor(gathered, mine)
@@ -137,6 +144,13 @@ class ShardedRenderer:
             capi.tiles_unpack_device(self.device_index, self._stream(), self.gathered.data_ptr(), self.world, self.per_rank,
                                      self.cam.width, self.cam.height, self.tile_w, self.tile_h,
                                      self.rgb.data_ptr(), self.z.data_ptr(), self.cnt.data_ptr())
-            self.stream.synchronize()
-        self.gather_ms.append((time.perf_counter() - t0) * 1e3)
-        return st, (self.rgb, self.z, self.cnt)
+            if sync:
+                self.stream.synchronize()
+        if sync:
+            self.gather_ms.append((time.perf_counter() - t0) * 1e3)
+        return (st if sync else None), (self.rgb, self.z, self.cnt)
+
+    def finish(self):
+        """wait for the frames enqueued with step(sync=False) and collect their verdict (raises if a queue overflowed)"""
+        self.stream.synchronize()
+        self.scene.render_check(self.device_index)

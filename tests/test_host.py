@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header():
     assert C.sizeof(capi.Camera) == 56 and C.sizeof(capi.Params) == 64
-    assert C.sizeof(capi.TileRange) == 16 and C.sizeof(capi.Stats) == 28 * 8
+    assert C.sizeof(capi.TileRange) == 16 and C.sizeof(capi.Stats) == 29 * 8
     p = capi.default_params()
     assert (p.min_sample, p.max_sample, p.bounce, p.knn_k, p.shadow_samples) == (4, 8, 4, 400, 4)
     assert p.threshold == np.float32(1e-3) and p.gamma == 2.2 and p.knn_radius == 1.0

@@ -7,6 +7,7 @@ tag=$1; groups=$2; shift 2
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+python3 -c "import json; from raytracing_folder_amd import buildinfo as b; json.dump({'kernel_source_sha16': b.kernel_source_sha16(), 'build_flags': b.build_flags()}, open('$out/build_id.json', 'w'))"
 run() {  # name, extra rocprof args...
   local name=$1; shift
   timeout -k 10 400 rocprofv3 --kernel-trace "$@" --output-format csv -d $out/$name -o $name -- python3 bench.py --no-cpu-baseline --profile-frames 0 "${BENCH_ARGS[@]}" > $out/$name.log 2>&1

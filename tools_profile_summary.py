@@ -13,8 +13,18 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from raytracing_folder_amd import buildinfo      # noqa: E402
+
 src, tag = sys.argv[1], sys.argv[2]
 note = sys.argv[3] if len(sys.argv) > 3 else ""
+# which kernels these counters belong to: bench.py refuses to quote them for another build.  The profile run leaves the id of
+# the build it ran on the GPU box in <src>/build_id.json (tools_profile_run.sh); the working tree's is the fallback.
+BUILD = {"kernel_source_sha16": buildinfo.kernel_source_sha16(), "build_flags": buildinfo.build_flags()}
+try:
+    BUILD = json.load(open(os.path.join(src, "build_id.json")))
+except Exception:
+    pass
 
 
 def kname(n):
@@ -63,7 +73,7 @@ if hbm:
             d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE"]["per_launch_KiB"] + d["WRITE_SIZE"]["per_launch_KiB"]) * 1024)
     json.dump({"command": "tools_profile_run.sh: rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
                           "--no-cpu-baseline --profile-frames 0 (one pass per counter)",
-               "workload": note, "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
+               "workload": note, **BUILD, "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them",
                "note": "gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM section); "
                        "hbm_bytes_per_launch applies that x2 to the fetch side",
                "kernels": hbm}, open(f"profiles/{tag}_bench_pmc_hbm.json", "w"), indent=1)
@@ -96,7 +106,7 @@ if sq:
             d["l2_hit_rate"] = round(d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"]), 4)
     json.dump({"command": "tools_profile_run.sh: rocprofv3 --kernel-trace --pmc <4 counters per pass> --output-format csv -- python3 bench.py --steps 1 "
                           "--warmup 0 --no-cpu-baseline --profile-frames 0",
-               "workload": note,
+               "workload": note, **BUILD,
                "units": "per-launch averages; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are per-wave quad-cycles summed over all waves, SQ_INSTS_* wave "
                         "instructions; avg_launch_us from the kernel trace of the same pass (kernels of up to three chunks overlap in it)",
                "kernels": sq}, open(f"profiles/{tag}_bench_sq_counters.json", "w"), indent=1)
