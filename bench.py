@@ -35,9 +35,10 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0        # aggregate L2 rate of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
 VALU_PEAK_GINST = 1024 * 2.4 / 2      # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs at 2.4 GHz, one per 2 cycles (32 lanes per cycle; the
                                       # 157.3 TF f32 vector peak is exactly that with fma).  One WAVE issues at most one per 4 cycles.
-PARITY_NOTE = ("geometry half of RenderPixel pinned to the reference's own z images and compiled headers; "
-               "MtlBlinn::Shade, GenLight::Shadow, TraceNode and RenderPixel's loop are restated from main.cpp "
-               "(unbuildable here: needs GL/glut.h): Shade parity UNPINNED, GPU == oracle only")
+PARITY_NOTE = ("oracle pinned bit for bit to the reference's own code on the whole path: primitives / BVH / kNN / photon balance (compiled "
+               "headers) and TraceNode, GenLight::Shadow, MtlBlinn::Shade (FIN + P13), RenderPixel, PhotonTracing / CausticTracing (the reference's "
+               "main.cpp compiled with only its viewport include removed: tests/golden/main_*.npz); GPU vs those fixtures in the -m gpu suite; this "
+               "run's timed frame vs the oracle: parity_check")
 
 
 def parse():

@@ -411,6 +411,8 @@ rt_status rt_render_tiles_packed_device(rt_scene *s, const rt_camera *cam, const
                                         const rt_tile_range *tiles, int device, void *hip_stream,
                                         void *packed_dev, uint64_t packed_bytes, int sync, rt_stats *stats_out);
 rt_status rt_tiles_packed_size(int32_t width, int32_t height, const rt_tile_range *tiles, uint64_t *bytes, int32_t *n_tiles);
+/* (hip_stream == NULL here means the device's legacy null stream, NOT the library's own stream: the call has no scene to
+ * take one from; pass the stream the gather ran on.) */
 rt_status rt_tiles_unpack_device(int device, void *hip_stream, const void *gathered_dev, int32_t world, int32_t tiles_per_rank,
                                  int32_t width, int32_t height, int32_t tile_w, int32_t tile_h,
                                  uint8_t *rgb8_dev, float *z_dev, uint8_t *count_dev);

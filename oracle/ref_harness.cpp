@@ -9,16 +9,15 @@
 // cyPhotonMap.h, cyColor.h/cyPoint.h/cyMatrix.h, lights.h (the inline PointLight::Illuminate of
 // either snapshot) and materials.h (the inline MtlBlinn::RandomPhotonBounce, Attenuation,
 // createCoordinateSystem of RayTracingFinal).
-// What cannot: main.cpp (TraceNode, Shade, RenderPixel, GenLight::Shadow) -- it textually
-// includes viewport.cpp, which needs <GL/glut.h>, absent from this image.  No stand-in header is
-// written for it; those functions stay "parity unpinned" (DESIGN.md).
+// main.cpp itself (TraceNode, Shade, RenderPixel, GenLight::Shadow, PhotonTracing) is driven by
+// ref_main_harness.cpp (round 3): compiled with only its viewport include removed, no GL header.
 //
 // GenLight::Shadow is only DECLARED by lights.h (its body, FIN/main.cpp:499-513, is in the
 // unbuildable translation unit).  PointLight::Illuminate calls it once per shadow sample, so to
 // exercise Illuminate this file defines GenLight::Shadow as a RECORDING TEST DOUBLE: it logs the
 // ray it is handed and returns the next value of a script supplied by the caller.  What the
 // `illum` vectors pin is therefore Illuminate's own arithmetic (sample placement, rand()
-// consumption, the 4 -> 16 escalation rule, the fall-off) -- NOT Shadow, which stays unpinned.
+// consumption, the 4 -> 16 escalation rule, the fall-off); Shadow itself is pinned by ref_main_harness.
 // libc rand() is made reproducible the plain way: srand(seed), draw and store the raw values,
 // srand(seed) again, call the reference; the stored values are what the oracle is fed.
 //

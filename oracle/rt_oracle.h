@@ -6,16 +6,15 @@
  * the product may include, link or call it (only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg do).
  *
- * Pinning status (see DESIGN.md "Oracle"):
- *   pinned against the reference's own code compiled here (oracle/_ref/ref_harness, built from
- *   the headers where they lie in /root/reference):
+ * Pinning status (see DESIGN.md "Oracle"): PINNED, bit for bit, against the reference's own code compiled here --
+ *   oracle/_ref/ref_harness_* (the headers where they lie in /root/reference):
  *       Sphere/Plane/TriObj::IntersectRay + TraceBVHNode + Box::IntersectRay, cyBVH build,
  *       Node::ToNodeCoords/FromNodeCoords, Halton, Color24, PhotonMap balance + kNN
- *       (EstimateIrradiance<400>), Photon pack/decode.
- *   PARITY UNPINNED (FIN/main.cpp textually includes viewport.cpp, which needs <GL/glut.h>;
- *   that header is absent from this image, so main.cpp is unbuildable here):
- *       TraceNode, GenLight::Shadow, PointLight::Illuminate, MtlBlinn::Shade, RenderPixel.
- *   Those are restated line by line with the file:line they follow.
+ *       (EstimateIrradiance<400>), Photon pack/decode, PointLight::Illuminate, RandomPhotonBounce, textures;
+ *   oracle/_ref/ref_main_harness_* (main.cpp of RayTracingFinal / RayTracingProj13 itself, compiled with only its
+ *   `#include "viewport.cpp"` and `ShowViewport();` lines removed: no GL header needed):
+ *       TraceNode, GenLight::Shadow, MtlBlinn::Shade, RenderPixel, PhotonTracing / CausticTracing, RandomPhoton.
+ *   The Shade variants of RayTracingProj12 / 6 / 3 are restated from snapshots that are not compiled here.
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H

@@ -1238,7 +1238,8 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     double ray_factor = 0, query_factor = 0;           // 0 = worst case
     if (!worst_case && getenv("RT_QUEUE_WORST_CASE") == nullptr) {
         // floors: how many rays k_wavefront cannot keep in LDS depends on timing, and a view change can bring glass into a
-        // frame that had none -- one ray and a quarter of a query per sample cost 1.4 GB per working set and cover both
+        // frame that had none -- one ray (160 B of queue) and a quarter of a query (12 B) per sample: 1.4 GB per 8 Mi-sample working
+        // set of a job, 11.5 GB per 64 Mi-sample one of a device-side render -- and cover both
         if (hist_ok) { ray_factor = std::max(2.0 * H.rays_per_sample, 1.0); query_factor = std::max(2.0 * H.queries_per_sample, 0.25); }
         else if (sync || job) {
             // first render of a kind: from the model's fan-out.  k_wavefront keeps the ray tree in LDS (the global queue only sees
@@ -1247,7 +1248,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
             // ungated reflection / refraction pairs of the P13-family Shade, which double level by level inside glass
             // (P13/main.cpp:633-751: measured 2.5 rays per sample on the fullest level of a Cornell chunk that holds the glass
             // sphere, bounce 8) -- four per sample on top of the hemisphere rays, 640 B per sample of queue memory
-            const bool wf = (p->shade_model == RT_SHADE_FIN || p->shade_model == RT_SHADE_P13) && getenv("RT_TRACER") == nullptr;
+            const bool wf = (p->shade_model == RT_SHADE_FIN || p->shade_model == RT_SHADE_P13) && getenv("RT_TRACER") == nullptr;     // (P12 through k_wavefront keeps the per-level figure: its overflow is scene-dependent)
             ray_factor = wf ? 1.0 : (p->shade_model == RT_SHADE_P12 ? (double)std::max(p->hemisphere_sample, 1) + 3.0 : 4.0);
             query_factor = 0.5;
         }

@@ -13,11 +13,13 @@
 //                                      leaf's triangles are contiguous
 //              tri_face[ ]             face id per leaf-ordered triangle (read on accepted hits)
 //              nrm[ ]                  36 B per face: the three vertex normals (read once per ray)
-//   photons    slots in sub-leaf-major order, 32 slots per SUB-LEAF (padded with +inf positions),
-//              pa = (pos.xyz, dir.x), pb = (dir.y, dir.z, maxPower, colour bytes); sbox = tight box
-//              of every sub-leaf; four consecutive sub-leaves (128 slots, two median splits apart)
-//              form a LEAF of the tree the queries walk: tbox = heap-ordered boxes of the complete
-//              binary tree over the leaves (root = 1, leaves at [n_leaves, 2 n_leaves))
+//   photons    slots in sub-leaf-major order, RT_SUB_PHOTONS (16) slots per SUB-LEAF (padded with +inf
+//              positions), pa = (pos.xyz, dir.x), pb = (dir.y, dir.z, maxPower, colour bytes); sbox =
+//              tight box of every sub-leaf; RT_LEAF_SUBS (8) consecutive sub-leaves (128 slots, three
+//              median splits apart) form a LEAF of the tree the queries walk: tbox = heap-ordered
+//              boxes of the complete binary tree over the leaves (root = 1, leaves at [n_leaves,
+//              2 n_leaves)).  Built on the GPU (rt_photon_build.hip); tbox and sbox are the head and the
+//              last level of ONE array of the boxes of all heap nodes.
 #ifndef RT_DEV_H
 #define RT_DEV_H
 
@@ -26,7 +28,7 @@
 
 #define RT_MAX_DEPTH      8      // scene-graph nesting supported on the device
 #define RT_MAX_OBJECTS    4096
-#define RT_BVH_STACK      32     // per-lane traversal stack entries (LDS)
+#define RT_BVH_STACK      32     // per-lane traversal stack entries (LDS) of the per-level kernels; k_wavefront keeps 24 (rt_kernels.hip)
 #define RT_BLOCK          256    // threads per workgroup of the trace/shade kernels
 #ifndef RT_SUB_PHOTONS
 #define RT_SUB_PHOTONS    16     // photon slots per sub-leaf (16 or 32): a wavefront examines 64 / RT_SUB_PHOTONS sub-leaves per step
@@ -72,10 +74,10 @@ struct DevMesh {
 };
 
 struct DevPhotonMap {
-    const float4 *pa;            // [n_sub*32]  position.xyz, direction.x
+    const float4 *pa;            // [(n_sub + 1) * RT_SUB_PHOTONS]  position.xyz, direction.x (the last sub-leaf: all slots empty)
     const float4 *pb;            //             direction.yz, GetMaxPower(), colour bytes r|g<<8|b<<16 (as uint bits)
     const float4 *tbox;          // [2*n_leaves][2]: (lo.xyz, -), (hi.xyz, -)
-    const float4 *sbox;          // [n_sub][2], n_sub = 4 * n_leaves: sub-leaf j of leaf l is 4*l + j
+    const float4 *sbox;          // [n_sub][2], n_sub = RT_LEAF_SUBS * n_leaves: sub-leaf j of leaf l is RT_LEAF_SUBS*l + j
     uint32_t n_leaves;           // power of two, 0 = no photon map
     uint32_t n_photons;          // photons stored in the leaves
     // coarse density grid (photon count per cubic cell of side `cell`) used only to pick the first

@@ -1321,22 +1321,21 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
 // Configuration: the texture-free instantiations run THREE workgroups per CU (3 waves/SIMD: the traversal waits on dependent
 // loads for 0.44 of its wave cycles at two) -- 168 VGPRs, and per workgroup at most 53 760 B of LDS (160 KB / 3 in 1280-byte
 // granules): 24 BVH stack entries per lane (24.6 KB; meshes deeper than that take the per-level kernels, see
-// rtk_launch_primary) + a 592-ray stack of 48-byte records (28.4 KB) + two 64-entry Halton tables.  The textured ones need
-// 255 VGPRs anyway: two workgroups per CU, 32-entry BVH stacks, 1008 rays.
+// rtk_launch_primary) + a 592-ray stack of 48-byte records (28.4 KB) + two 64-entry Halton tables.  The textured
+// instantiations get the same configuration (the compiler would take 255 VGPRs for them; held to 168 the texture lookups'
+// temporaries go to scratch, which costs less than the third wave buys).  RT_WF_WAVES=2 / RT_WF_TEX_WAVES=2: two workgroups
+// per CU, 32-entry BVH stacks, 1008 rays (A/B builds).
 #ifndef RT_WF_WAVES
 #define RT_WF_WAVES 3          // waves per SIMD = workgroups per CU of the texture-free instantiations
 #endif
-#ifndef RT_WF_BVH
-#define RT_WF_BVH (RT_WF_WAVES >= 3 ? 24 : RT_BVH_STACK)
-#endif
-#ifndef RT_WF_STACK
-#define RT_WF_STACK (RT_WF_WAVES >= 3 ? 592 : 1008)
+#ifndef RT_WF_TEX_WAVES
+#define RT_WF_TEX_WAVES 3      // ... of the textured ones (measured on the 102 k-triangle frame under a PNG sky: 40.5 ms at two, 31.2 ms at three)
 #endif
 #define RT_WF_HALTON 64
 template <bool TEX> struct WfCfg {
-    static constexpr int WAVES = TEX ? 2 : RT_WF_WAVES;
-    static constexpr int BVH = TEX ? RT_BVH_STACK : RT_WF_BVH;
-    static constexpr int STACK = TEX ? 1008 : RT_WF_STACK;
+    static constexpr int WAVES = TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES;
+    static constexpr int BVH = WAVES >= 3 ? 24 : RT_BVH_STACK;
+    static constexpr int STACK = WAVES >= 3 ? 592 : 1008;
     // pop a round as soon as a round of primary rays (two children each) could no longer be sure to fit
     static constexpr int POP = STACK - 2 * RT_BLOCK + 1 < RT_BLOCK ? STACK - 2 * RT_BLOCK + 1 : RT_BLOCK;
     static_assert(BVH * RT_BLOCK * 4 + STACK * 48 + 2 * RT_WF_HALTON * 4 + 16 <= (WAVES >= 3 ? 53760 : 81920), "LDS budget of the occupancy the kernel is built for");
@@ -1352,7 +1351,7 @@ __device__ __forceinline__ uint32_t sample_of_slot(const SlotMap &M, uint32_t sl
     return ((uint32_t)y * (uint32_t)M.width + (uint32_t)x) * (uint32_t)M.max_sample + j;
 }
 template <int MODEL, bool TEX>
-__attribute__((amdgpu_waves_per_eu(TEX ? 2 : RT_WF_WAVES, TEX ? 2 : RT_WF_WAVES))) __global__ __launch_bounds__(RT_BLOCK) void k_wavefront(ShadeCtx C, PrimaryArgs A)
+__attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES))) __global__ __launch_bounds__(RT_BLOCK) void k_wavefront(ShadeCtx C, PrimaryArgs A)
 {
     using Cfg = WfCfg<TEX>;
     __shared__ uint32_t s_stack[Cfg::BVH * RT_BLOCK];
@@ -1408,7 +1407,7 @@ __attribute__((amdgpu_waves_per_eu(TEX ? 2 : RT_WF_WAVES, TEX ? 2 : RT_WF_WAVES)
                 // exp(-absorption.r * z) (P13/main.cpp:728)
                 const float *ab = C.S.materials[pk >> 16].absorption;
                 in.absorb = (MODEL == RT_SHADE_FIN) ? ld3(ab) : mk(ab[0], 0, 0);
-                if (C.S.stochastic) in.sample = sample_of_slot(C.sm, in.slot);
+                if (C.S.stochastic || MODEL == RT_SHADE_P12) in.sample = sample_of_slot(C.sm, in.slot);     // P12 draws its hemisphere rays
                 if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
             }
             __syncthreads();                              // all pops read before anything is pushed over them
@@ -1809,7 +1808,7 @@ __device__ __forceinline__ void wave_sync()
 struct GatherLds {
     uint16_t leaves[RT_GATHER_BATCH][RT_LEAFLIST_CAP];   // per query (lane) leaf ids
     uint32_t subs[RT_SUBLIST_CAP + RT_SUBS_PER_STEP];    // the current query's sub-leaf ids, padded to whole steps with the dummy sub-leaf
-    union {                                              // never live at the same time:
+    union alignas(16) {                                  // never live at the same time:
         uint32_t hist[256];                              //   the distance-key histogram while the k-th photon's bin is located
         struct { float sel_d[64]; uint32_t sel_i[64]; uint32_t sel_n; };   //   then that bin's photons for the exact rank selection
     };
@@ -2169,7 +2168,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 auto accumulate = [&](const float4 &pa, const float4 &pb, bool take) { accumulate5(pa.w, pb.x, pb.y, pb.z, __float_as_uint(pb.w), take); };
 
                 uint32_t M = 0;                            // accepted photons (wave-uniform: popcount of the ballots)
-                for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
+                *(uint4 *)&L.hist[4 * lane] = make_uint4(0u, 0u, 0u, 0u);     // the 256 bins in one 16-byte store per lane
                 wave_sync();
                 // pass 1: count + histogram of every accepted photon.  Photons closer than t_lo (safely inside the
                 // k nearest if the prediction holds) are summed right away; those between t_lo and t_hi, the band
@@ -2236,7 +2235,8 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     uint32_t in_bin = 0;
                     for (;;) {
                         wave_sync();
-                        const uint32_t h0 = L.hist[4 * lane], h1 = L.hist[4 * lane + 1], h2 = L.hist[4 * lane + 2], h3 = L.hist[4 * lane + 3];
+                        const uint4 h4 = *(const uint4 *)&L.hist[4 * lane];
+                        const uint32_t h0 = h4.x, h1 = h4.y, h2 = h4.z, h3 = h4.w;
                         const uint32_t mine = h0 + h1 + h2 + h3;
                         const uint32_t incl = wave_scan_add_u(mine);
                         const uint32_t excl = incl - mine;
@@ -2258,7 +2258,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         // one more level: histogram of the next 8 bits over the photons inside this bin
                         shift -= 8;
                         wave_sync();
-                        for (int i = lane; i < 256; i += 64) L.hist[i] = 0;
+                        *(uint4 *)&L.hist[4 * lane] = make_uint4(0u, 0u, 0u, 0u);
                         wave_sync();
                         const uint32_t hi_mask = ~((1u << (shift + 8)) - 1u) & 0xFFFFFFu;
                         for_each([&](const Cand &cd, uint32_t) {
@@ -2633,8 +2633,14 @@ static bool wavefront_usable(const DevScene &S, const rt_params &P, bool tex)
 {
     static int wavefront = -1;
     if (wavefront < 0) { const char *e = getenv("RT_TRACER"); wavefront = (e && !strcmp(e, "levels")) ? 0 : 1; }
-    if (!wavefront || !(P.shade_model == RT_SHADE_FIN || P.shade_model == RT_SHADE_P13)) return false;
-    return S.max_bvh_depth <= (tex ? RT_BVH_STACK : RT_WF_BVH);
+    // P12 (live GI): a hit spawns its hemisphere rays next to the reflection / refraction pair -- one per hit below the first
+    // level, hemisphere_sample on it; with up to two of them the LDS stacks hold the tree like FIN's (what does not fit
+    // takes the global queue as always).  RT_P12_TRACER=levels: the per-level kernels (A/B)
+    static int p12 = -1;
+    if (p12 < 0) { const char *e = getenv("RT_P12_TRACER"); p12 = (e && !strcmp(e, "levels")) ? 0 : 1; }
+    const bool model_ok = P.shade_model == RT_SHADE_FIN || P.shade_model == RT_SHADE_P13 || (P.shade_model == RT_SHADE_P12 && p12 && P.hemisphere_sample <= 2);
+    if (!wavefront || !model_ok) return false;
+    return S.max_bvh_depth <= (tex ? WfCfg<true>::BVH : WfCfg<false>::BVH);
 }
 
 void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
@@ -2654,10 +2660,13 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
     // default: the whole ray tree in one persistent launch with LDS ray stacks (FIN / P13 models); RT_TRACER=levels: one
     // launch per level of the tree (round 1's structure, kept for the other models and for A/B: DESIGN.md section 3)
     if (wavefront_usable(S, P, tex)) {
-        const int wgrid = grid_for((unsigned long long)npix * ns, RT_BLOCK, 256 * (tex ? 2 : RT_WF_WAVES));      // resident workgroups per CU (LDS)
+        const int wgrid = grid_for((unsigned long long)npix * ns, RT_BLOCK, 256 * (tex ? RT_WF_TEX_WAVES : RT_WF_WAVES));      // resident workgroups per CU (LDS)
         if (P.shade_model == RT_SHADE_FIN) {
             if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
             else hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+        } else if (P.shade_model == RT_SHADE_P12) {
+            if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_P12, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+            else hipLaunchKernelGGL((k_wavefront<RT_SHADE_P12, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
         } else {
             if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_P13, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
             else hipLaunchKernelGGL((k_wavefront<RT_SHADE_P13, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
@@ -2696,10 +2705,13 @@ bool rtk_launch_wavefront_queue(hipStream_t st, const DevScene &S, const DevWork
     memset(&A, 0, sizeof A);
     A.mode = 3; A.ns = 1; A.qsrc = qin; A.qsrc_count = qin_count;
     A.div_ns = fastdiv_make(1u);
-    const int wgrid = 256 * (tex ? 2 : RT_WF_WAVES);       // the count is on the device: a full persistent grid, idle workgroups leave at once
+    const int wgrid = 256 * (tex ? RT_WF_TEX_WAVES : RT_WF_WAVES);       // the count is on the device: a full persistent grid, idle workgroups leave at once
     if (P.shade_model == RT_SHADE_FIN) {
         if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
         else hipLaunchKernelGGL((k_wavefront<RT_SHADE_FIN, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+    } else if (P.shade_model == RT_SHADE_P12) {
+        if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_P12, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
+        else hipLaunchKernelGGL((k_wavefront<RT_SHADE_P12, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
     } else {
         if (tex) hipLaunchKernelGGL((k_wavefront<RT_SHADE_P13, true>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
         else hipLaunchKernelGGL((k_wavefront<RT_SHADE_P13, false>), dim3(wgrid), dim3(RT_BLOCK), 0, st, C, A);
