@@ -259,6 +259,11 @@ def main():
     st_warm = None
     for _ in range(max(a.warmup, 0)):
         st_warm, _ = R.step()
+    if st_warm is not None and not a.sync_steps:
+        # untimed: the first ENQUEUED frame of a process pays one-off costs on the host (measured once: 60 ms inside the first
+        # asynchronous call on a fresh box) that belong to no step
+        R.step(sync=False)
+        R.finish()
     barrier()
     t0 = time.perf_counter()
     stats, step_ms = [], []

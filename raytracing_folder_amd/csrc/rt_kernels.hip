@@ -1800,9 +1800,16 @@ __device__ __forceinline__ float box_dist2(const float4 *b, float px, float py, 
 // only the compiler has to be kept from reordering, plus a wait for outstanding LDS returns.
 __device__ __forceinline__ void wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#ifndef RT_GATHER_SYNC_SCOPE
+#define RT_GATHER_SYNC_SCOPE "wavefront"
+#endif
+    // "wavefront" scope: the hardware already executes one wave's LDS instructions in issue order, so a write by one lane is
+    // seen by a later read of another lane of the SAME wave without waiting for anything; the fences only keep the compiler
+    // from moving LDS accesses across this point.  ("workgroup" scope made every one of the ~10 hand-offs per query an
+    // s_waitcnt vmcnt(0) lgkmcnt(0): it also drained the photon loads in flight.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, RT_GATHER_SYNC_SCOPE);
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, RT_GATHER_SYNC_SCOPE);
 }
 
 struct GatherLds {
@@ -1948,6 +1955,9 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     const uint32_t K = (uint32_t)G.k;
     unsigned long long visited = 0;
     uint32_t n_rounds = 0, n_slow = 0, n_reads = 0;       // wave-uniform tallies
+#ifdef RT_EXP_COUNT_FALLBACK2
+    uint32_t x_below = 0, x_above = 0, x_other = 0, x_mk = 0;
+#endif
     float pred_rk2 = 0.0f;                                // k-th squared distance of this wave's previous query (a hint only)
 
     // batches of RT_GATHER_BATCH queries are handed out dynamically (one atomic per batch): query cost varies by
@@ -2307,6 +2317,18 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         }
                     }
 #endif
+#ifdef RT_EXP_COUNT_FALLBACK2   /* tuning build: why the ring could not serve a query: rounds = k-th bin at or below the band's lower bin, slow = at or above
+                                   its upper bin, leaf_reads (x RT_SUB_PHOTONS / 32) = ring overflow or unresolved bin; visited = queries with M > K */
+                    {
+                        const uint32_t bin_lo2 = (uint32_t)(t_lo * Q.kscale) >> 16, bin_hi2 = (uint32_t)(t_hi * Q.kscale) >> 16, kbin2 = prefix >> 16;
+                        if (!from_ring) {
+                            if (n_ring > (uint32_t)RT_GATHER_RING || shift != 16 || in_bin > 64u) x_other++;
+                            else if (!(bin_lo2 < kbin2)) x_below++;
+                            else x_above++;
+                        }
+                        x_mk++;
+                    }
+#endif
 #ifdef RT_EXP_COUNT_FALLBACK    /* tuning build: ST_GATHER_SLOW counts fallbacks by ring overflow, ST_GATHER_ROUNDS the other fallbacks */
                     n_rounds--;
                     if (!from_ring) { if (n_ring > (uint32_t)RT_GATHER_RING) n_slow++; else n_rounds++; }
@@ -2438,6 +2460,9 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
             wave_sync();
         }
     }
+#ifdef RT_EXP_COUNT_FALLBACK2
+    n_rounds = x_below; n_slow = x_above; n_reads = x_other * 32u / RT_SUB_PHOTONS; visited = x_mk; 
+#endif
     if (lane == 0 && G.stats && visited) {
         atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * (unsigned long long)RT_SUB_PHOTONS);
         atomicAdd(&G.stats[ST_GATHER_ROUNDS], (unsigned long long)n_rounds);
