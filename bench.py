@@ -125,6 +125,71 @@ def cpu_baseline(scene_export, balanced, cam, params, budget_s):
                                            "build container (BASELINE.md section 2) -- other sampling, other host: context only"}}, kept
 
 
+def reference_here(raw_photons, width, height, seconds=6.0):
+    """The REFERENCE's own RenderPixel (oracle/_ref/ref_main_harness_fin: main.cpp of RayTracingFinal compiled in the build
+    container with only its viewport include removed; it travels to the GPU box as a built file) timed on THIS host, one
+    thread, on seeded 32-pixel row segments of the same Cornell frame with the same photons -- at the sample counts its
+    #defines fix (adaptive 4 -> 8, FIN/main.cpp:19-21: not the 64 spp of the timed workload, which is why `value` stays the
+    port's) -- and the port on the very same pixels and settings: how fast the port is relative to the code it restates,
+    and that it gives the same pixels.  None when the binary is absent (it needs the reference tree at build time)."""
+    import struct
+    import subprocess
+    import tempfile
+    from oracle import orc
+    from raytracing_folder_amd import workloads
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_main_harness_fin")
+    if not os.path.exists(exe) or raw_photons is None or len(raw_photons) < 2:
+        return None
+    ph = raw_photons[1:]
+    dx = ph["dir_x"].astype(np.float32) / np.float32(0x7FFF)
+    dy = ph["dir_y"].astype(np.float32) / np.float32(0x7FFF)
+    dz = np.sqrt(np.maximum(0.0, 1.0 - dx.astype(np.float64) ** 2 - dy.astype(np.float64) ** 2)).astype(np.float32)
+    dz = np.where(ph["plane_and_dirz"] & 8, -dz, dz)
+    power = ph["color"].astype(np.float32) / np.float32(255.0) * ph["power"][:, None]
+    payload = np.concatenate([ph["position"], np.stack([dx, dy, dz], 1), power], axis=1).astype(np.float32)
+    rng = np.random.default_rng(11)
+    n_seg = max(4, int(seconds * 150 / 32))                                 # about 150 px/s on one core with a 1 M-photon map
+    rows = np.sort(rng.choice(height, n_seg, replace=False))
+    segs = np.array([(int(y) * width + int(rng.integers(0, width - 32)), 32) for y in rows], np.int32)
+    data = os.path.dirname(workloads.CORNELL_XML)
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<i", len(payload)) + payload.tobytes() + struct.pack("<iii", width, height, len(segs)) + segs.tobytes())
+        try:
+            subprocess.run([exe, "pixels", os.path.basename(workloads.CORNELL_XML), fin, fout], check=True, cwd=data, timeout=20 * seconds + 60,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception as e:
+            return {"error": f"reference harness failed: {e}"}
+        out = open(fout, "rb").read()
+    n = struct.unpack_from("<i", out, 0)[0]
+    bal = np.frombuffer(out, orc.PHOTON, n + 1, 4).copy()
+    off = 4 + (n + 1) * 24 + 8
+    px = int(segs[:, 1].sum())
+    ref_rgb, ref_z = [], []
+    for _, c in segs:
+        ref_rgb.append(np.frombuffer(out, np.uint8, 3 * c, off).reshape(c, 3)); off += 3 * c
+        ref_z.append(np.frombuffer(out, np.float32, c, off)); off += 4 * c
+        off += c
+    ref_seconds = struct.unpack_from("<d", out, off)[0]
+    # the port on the same pixels, the same (reference-balanced) photons, the reference's settings, its dead hemisphere loop included
+    s, cam = workloads.load_cornell(width, height)
+    osc = orc.scene_from_export(s.export(), bal)
+    ocam, op = orc.camera_from(cam), orc.default_params()
+    orc.set_trace_discarded(True)
+    t0 = time.perf_counter()
+    same = 0
+    for (start, c), rr, rz in zip(segs, ref_rgb, ref_z):
+        y, x0 = divmod(int(start), width)
+        rgb, z, _ = orc.render(osc, ocam, op, x0, y, x0 + int(c), y + 1)
+        same += int(((rgb[y, x0:x0 + c] == rr).all(axis=1) & (z[y, x0:x0 + c] == rz)).sum())
+    port_seconds = time.perf_counter() - t0
+    orc.set_trace_discarded(False)
+    return {"what": "the reference's own RenderPixel (adaptive 4->8 spp as its #defines fix) vs the port on the same pixels, photons and settings, this host, 1 thread",
+            "pixels": px, "segments": int(len(segs)), "photons": int(n), "reference_px_per_s": round(px / ref_seconds, 1), "port_px_per_s": round(px / port_seconds, 1),
+            "port_over_reference_speed": round(ref_seconds / port_seconds, 3), "pixels_identical": same, "reference_seconds": round(ref_seconds, 2)}
+
+
 def parity_check(kept, frame):
     """The oracle's pixels of the CPU leg against the same pixels of the LAST TIMED frame (SURVEY 8c gate)."""
     rgb, z, cnt = (t.cpu().numpy() for t in frame)
@@ -229,7 +294,7 @@ def main():
         pass
     elif a.synthetic_photons:
         balanced = photons.synth_cornell_photon_map(a.photons, seed=20171203)
-    setup_ms = None
+    setup_ms, dump_path = None, None
     if a.workload == "cornell" and not a.synthetic_photons:
         # generatePhotonMap as a whole on the GPU (FIN/main.cpp:350-402; counter RNG, seed 20171203): photon pass ->
         # compaction -> the few photons balancing would put out of LocatePhotons' reach (host) -> gather structure; identical
@@ -237,6 +302,12 @@ def main():
         # viewport.cpp:442).  Run twice: the first call also pays the one-time allocations.
         s.generate_photons(a.photons, 8, seed=20171203, device=local)
         setup_ms = s.generate_photons(a.photons, 8, seed=20171203, device=local).as_dict()
+        if world == 1 and not a.no_cpu_baseline:
+            # once more with the dump generatePhotonMap leaves behind (FIN/main.cpp:397-400): the CPU leg feeds it to the
+            # reference's own binary
+            import tempfile
+            dump_path = os.path.join(tempfile.mkdtemp(prefix="rt_bench_"), "photonmap.dat")
+            s.generate_photons(a.photons, 8, seed=20171203, device=local, dat_path=dump_path)
     elif balanced is not None:
         s.set_photons(balanced)
     n_photons = s.counts()["photons"]
@@ -428,6 +499,10 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             # the checker needs the reference's balanced heap (its LocatePhotons walks it): made from the same photons on request
             out["cpu_baseline"], kept = cpu_baseline(s.export(), s.get_photons() if n_photons else None, cam, p, a.cpu_seconds)
+            if a.workload == "cornell" and n_photons:
+                # (the unbalanced photons as generated: what balancing them on the host starts from)
+                raw = capi.photons_read_dat(dump_path) if dump_path else None
+                out["cpu_baseline"]["reference_here"] = reference_here(raw, a.width, a.height)
             # the frame that was timed is the frame that is checked: the oracle's pixels against the last timed step's image
             out["parity_check"] = parity_check(kept, frame)
             failed = not out["parity_check"]["pass"]

@@ -170,7 +170,8 @@ static int cmd_shade(const char *in, const char *out)
 // in:  photons; int32 width, height (camera.imgWidth/imgHeight override; 0 = keep the file's); int32 nseg;
 //      nseg x {int32 start, count} (row-major pixel indices, ascending, disjoint)
 // out: int32 np + balanced photons; int32 width, height; per segment count x {uint8 rgb[3]}, count x float z,
-//      count x uint8 sampleCount
+//      count x uint8 sampleCount; then one double: seconds spent inside RenderPixel over all segments (bench.py's
+//      `reference_here` figure: the reference's own loop timed on the host it runs on)
 // The shared pixel index is advanced to `start` with the iterator's own public GetPixel (as SURVEY 8c notes), the
 // worker is stopped with pIt.setFlag() once `count` pixels are done; pixels it finishes beyond the segment are ignored.
 static int cmd_pixels(const char *in, const char *out)
@@ -188,6 +189,7 @@ static int cmd_pixels(const char *in, const char *out)
     o.put(w); o.put(h);
     pIt.Init();
     int next = 0;                                         // the iterator's next index
+    double render_seconds = 0;
     srand(4242);
     for (int s = 0; s < nseg; s++) {
         const int start = seg[2 * s], count = seg[2 * s + 1];
@@ -196,6 +198,7 @@ static int cmd_pixels(const char *in, const char *out)
         int x, y;
         while (next < start) { if (!pIt.GetPixel(x, y)) { fprintf(stderr, "iterator ran out\n"); return 3; } next++; }
         const int before = renderImage.GetNumRenderedPixels();
+        const auto t0 = std::chrono::steady_clock::now();
         std::thread th(RenderPixel, std::ref(pIt));
         // the segment is complete when `count` pixels have been COUNTED; P13 does not count the rows its debug skip
         // (main.cpp:219) passes over, so segments there must start at row 327 or below
@@ -203,11 +206,14 @@ static int cmd_pixels(const char *in, const char *out)
         pIt.setFlag();
         th.join();
         const int done = renderImage.GetNumRenderedPixels() - before;
+        // (the worker finishes the pixel it is in: `done` pixels were rendered in this time, `count` are reported)
+        render_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * (double)count / (double)(done > 0 ? done : 1);
         next = start + done;                              // every counted pixel took one index (no skipped rows inside a segment)
         o.bytes(renderImage.GetPixels() + start, (size_t)count * 3);
         o.bytes(renderImage.GetZBuffer() + start, (size_t)count * 4);
         o.bytes(renderImage.GetSampleCount() + start, (size_t)count);
     }
+    o.put(render_seconds);
     return 0;
 }
 

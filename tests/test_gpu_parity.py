@@ -1061,6 +1061,53 @@ def test_queue_overflow_is_an_error_with_or_without_stats(monkeypatch):
     assert (np.abs(rgb.cpu().numpy().astype(int) - ref.astype(int)) <= 1).all()
 
 
+def test_async_render_keeps_its_inputs_and_its_overflow_verdict(monkeypatch):
+    """(1) An asynchronous render still reads the scene tables and the photon structure when its call returns: a setter that
+    follows (same-sized photon map, other materials) must not reach the device before it has finished -- frame 1 equals the
+    synchronous render of the OLD inputs, frame 2 shows the new ones.  (2) An asynchronous render that dropped rays keeps
+    its verdict although a synchronous render (which clears and reads the shared drop counter) ran after it:
+    rt_render_check still reports it."""
+    import torch
+    s, cam = scenes.load_cornell(256, 192)
+    a = photons.synth_cornell_photon_map(30000, seed=2)
+    b = a.copy()
+    b["power"] *= 3.0                                            # same size, same positions: the device buffers are re-used in place
+    s.set_photons(a)
+    p = capi.default_params(min_sample=16, max_sample=16, threshold=-1.0)
+    ref_a, z_a, _, _, _ = s.render(cam, p)
+    dev = torch.device("cuda", 0)
+    def planes():
+        return (torch.zeros((192, 256, 3), dtype=torch.uint8, device=dev), torch.zeros((192, 256), dtype=torch.float32, device=dev),
+                torch.zeros((192, 256), dtype=torch.uint8, device=dev))
+    r1, r2 = planes(), planes()
+    tiles = capi.TileRange(32, 8, 0, 1)
+    s.render_tiles_device(cam, p, tiles, 0, r1[0].data_ptr(), r1[1].data_ptr(), r1[2].data_ptr(), sync=False, want_stats=False)
+    s.set_photons(b)                                             # while frame 1 may still be in flight
+    mats = s.export()["materials"].copy()
+    mats["diffuse"] *= 0.5
+    s.set_materials(mats)
+    s.render_tiles_device(cam, p, tiles, 0, r2[0].data_ptr(), r2[1].data_ptr(), r2[2].data_ptr(), sync=True, want_stats=False)
+    s.render_check(0)
+    f1, f2 = r1[0].cpu().numpy(), r2[0].cpu().numpy()
+    assert (r1[1].cpu().numpy() == z_a).all() and (np.abs(f1.astype(int) - ref_a.astype(int)) <= 1).all()
+    assert (np.abs(f2.astype(int) - ref_a.astype(int)).max(axis=2) > 2).mean() > 0.3      # darker walls, brighter photon term
+    # (2)
+    s2, cam2 = scenes.load_cornell(96, 64)
+    s2.set_photons(photons.synth_cornell_photon_map(4000, seed=2))
+    p2 = capi.default_params(min_sample=4, max_sample=4, threshold=-1.0)
+    s2.render(cam2, p2)                                          # history: the asynchronous render below is sized from it
+    q = planes()
+    args = (cam2, p2, tiles, 0, q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr())
+    monkeypatch.setenv("RT_QUEUE_CAP", "64")
+    s2.render_tiles_device(*args, sync=False, want_stats=False)  # drops rays; nobody has looked yet
+    monkeypatch.delenv("RT_QUEUE_CAP")
+    s2.render_tiles_device(*args, sync=True, want_stats=True)    # a clean synchronous render with statistics in between
+    with pytest.raises(capi.RtError) as e:
+        s2.render_check(0)                                       # the asynchronous frame WAS wrong: still reported
+    assert e.value.status == -6
+    s2.render_check(0)
+
+
 def test_single_stage_calls_are_refused_while_a_job_owns_the_device(monkeypatch):
     """rt_trace_rays / rt_shade_rays / rt_estimate_irradiance / rt_photon_pass share the device's scratch buffers,
     counters and statistics with a render: while a job is live they fail with RT_ERR_STATE instead of racing"""
