@@ -64,6 +64,10 @@
 #ifndef RT_GATHER_CELLSTART
 #define RT_GATHER_CELLSTART 1  // 1: a query inside the density grid starts its tree walk at its cell's start node (DevPhotonMap::cell_start)
 #endif
+#ifndef RT_GATHER_SPARSE
+#define RT_GATHER_SPARSE 1     // 1: a query whose cell last saw no more than k photons inside the full radius sums everything in one plain pass
+                               // (no histogram, no ring, no selection); the normal path runs after it if more than k turn up
+#endif
 #ifndef RT_GATHER_CELL_GUESS
 #define RT_GATHER_CELL_GUESS RT_GATHER_GUESS    // first trial radius^2 of a query whose cell remembers a k-th distance: that distance times this
 #endif
@@ -2020,6 +2024,9 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 cell_pred = G.cell_rk2[cell_index];
                 // a cell that has seen a query also knows a better first radius than the density estimate: a little above its k-th distance
                 if (cell_pred > 0.0f) r2cur = fminf(fmaxf(cell_pred * RT_GATHER_CELL_GUESS, r2 * 1.0e-4f), r2);
+#if RT_GATHER_SPARSE
+                else if (cell_pred < 0.0f) r2cur = r2;       // "sparse here": the full radius at once
+#endif
             }
 #endif
         }
@@ -2178,6 +2185,23 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 auto accumulate = [&](const float4 &pa, const float4 &pb, bool take) { accumulate5(pa.w, pb.x, pb.y, pb.z, __float_as_uint(pb.w), take); };
 
                 uint32_t M = 0;                            // accepted photons (wave-uniform: popcount of the ballots)
+                float area_d2 = rq2;
+                bool done_plain = false;
+#if RT_GATHER_SPARSE && RT_GATHER_CELLPRED && !defined(RT_EXP_LOADONLY)
+                // "Sparse here": the cell's last query found no more than k photons inside the FULL radius.  Then all accepted
+                // photons count and dist2[0] stays radius^2 (cyPhotonMap.h:309-326): one plain pass sums them -- no histogram, no ring,
+                // no selection.  If more than k turn up after all, the sums are dropped and the normal path below does the query.
+                if (final_round && lane_f(cell_pred, q) < 0.0f) {
+                    for_each([&](const Cand &cd, uint32_t) {
+                        M += (uint32_t)__popcll(ballot64(cd.d2 < rq2));
+                        accumulate(cd.pa, cd.pb, cd.d2 < rq2);
+                    });
+                    visited += n_sub;
+                    if (M <= K) done_plain = true;
+                    else { M = 0; s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0; n_reads += n_sub; }
+                }
+#endif
+                if (!done_plain) {
                 *(uint4 *)&L.hist[4 * lane] = make_uint4(0u, 0u, 0u, 0u);     // the 256 bins in one 16-byte store per lane
                 wave_sync();
                 // pass 1: count + histogram of every accepted photon.  Photons closer than t_lo (safely inside the
@@ -2232,7 +2256,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     if (lane == q) r2cur = fminf(rq2 * grow, r2);
                     continue;
                 }
-                float area_d2 = rq2;                       // dist2[0]; only reached with rq2 == r2 when M <= K
+                area_d2 = rq2;                             // dist2[0]; only reached with rq2 == r2 when M <= K
 #ifdef RT_EXP_NOSELECT          /* cost attribution build: no bin search, ring, selection or fallback pass; results are garbage */
                 if (false) {
 #else
@@ -2410,6 +2434,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     }
                 }
 #endif
+                }
                 // the query is done: its six sums and r_k^2 go to ITS lane; what follows from them (area, normalisation, the
                 // weighted add into the sample) is the same scalar arithmetic for every query, so it is done for all the
                 // queries a round finished at once, one per lane, after the loop -- not 64 lanes wide per query
@@ -2428,7 +2453,13 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 float irr_r = f_pr, irr_g = f_pg, irr_b = f_pb, dx = f_dx, dy = f_dy, dz = f_dz;
 #if RT_GATHER_CELLPRED
                 // remember the k-th distance for the next query of this cell (only when more than k qualified: f_area < r2)
-                if (G.cell_rk2 && n_leaves > 1 && f_area > 0.0f && f_area < r2) G.cell_rk2[cell_index] = f_area;
+                // (or that no more than k were inside the full radius: f_area is then radius^2, or negative without any photon)
+                if (G.cell_rk2 && n_leaves > 1) {
+                    if (f_area > 0.0f && f_area < r2) G.cell_rk2[cell_index] = f_area;
+#if RT_GATHER_SPARSE
+                    else if (r2cur >= r2) G.cell_rk2[cell_index] = -1.0f;
+#endif
+                }
 #endif
                 if (f_area >= 0.0f) {
                     const float area = (float)M_PI * f_area;               // :326
