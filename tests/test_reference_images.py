@@ -9,7 +9,7 @@ RenderImage::ComputeZBufferImage -> PNG:
   tests/golden/ref_prj13_boxzbuff.png = /root/reference/RayTracingProj13/prj13_boxzbuff.png
       z image of the Cornell scene (tests/golden/cornell.xml) by the RayTracingProj13 code: adaptive 4 -> 64
       samples, so a pixel carries the z of sample 3 (no second batch) or of sample 63 (second batch taken).
-      Which pixels took the second batch depends on Shade (unpinned), so the test asks: every pixel equals the
+      Which pixels took the second batch depends on the colours of the state of the code that made the image (not reproducible), so the test asks: every pixel equals the
       4-sample or the 64-sample level, and >= 99.9 % equal the 4-sample one (measured: 479 807 of 480 000,
       the other 193 all equal the 64-sample level).
   tests/golden/ref_prj5_zbuff.png = /root/reference/RayTracingProj5/RayTracingProj5/prj5_zbuff.png
