@@ -290,6 +290,8 @@ def main():
         a.width, a.height = 800, 600                       # BASELINE config C3's size unless another one was asked for
     if a.workload == "balls":
         s, cam = workloads.make_balls_scene(a.width, a.height)
+    elif a.workload == "gi":
+        s, cam = workloads.load_cornell_gi(a.width, a.height)
     else:
         s, cam = workloads.load_cornell(a.width, a.height)
     if a.workload in ("balls", "gi"):
@@ -478,7 +480,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("C5 stand-in: 128 tessellated spheres (102 402 triangles, half mirrors) on a ground quad under a PNG sky "
                                     f"(environment + background), FIN shading, {a.width}x{a.height}, {a.spp} spp fixed, no photon map, bounce 4") if a.workload == "balls" else
-                                   (f"C3: Cornell box, RayTracingProj12 shading (live path-traced GI: one cosine-hemisphere ray per hit), {a.width}x{a.height}, "
+                                   (f"C3: the Cornell box RayTracingProj12's main() loads (glass teapot, glossy sphere), its shading (live path-traced GI: one cosine-hemisphere ray per hit), {a.width}x{a.height}, "
                                     f"{a.spp} spp fixed, bounce 8, no photon map") if a.workload == "gi" else
                                    f"Cornell box, FIN shading, {a.width}x{a.height}, {a.spp} spp fixed, "
                                    f"{n_photons}-photon map ({'sprinkled on the walls' if a.synthetic_photons else 'GPU photon pass, Philox seed 20171203, 8 bounces'}), "

@@ -724,6 +724,82 @@ def gen_main_photontrace():
     np.savez_compressed(os.path.join(GOLD, "main_photontrace.npz"), **res)
 
 
+OLD_HARNESS = {m: os.path.join(ROOT, "oracle", "_ref", f"ref_main_harness_{m}") for m in ("p12", "p6", "p3")}
+OLD_SCENE = {"p12": (os.path.join(REF, "RayTracingProj13", "RayTracingProj13"), "scene.xml"),      # the Cornell file (RayTracingProj12's own loader reads it)
+             "p6": (os.path.join(REF, "RayTracingProj6", "RayTracingProj6"), "scene.xml"),
+             "p3": (os.path.join(REF, "RayTracingProj3", "RayTracingProj3"), "input2.xml")}
+
+
+def gen_main_shade_old(model):
+    """TraceNode + MtlBlinn::Shade + GenLight::Shadow of the main.cpp of RayTracingProj12 (live GI: its rand() draws captured
+    per case), RayTracingProj6 and RayTracingProj3 (see oracle/ref_main_harness_old.cpp)"""
+    rng = np.random.default_rng({"p12": 301, "p6": 302, "p3": 303}[model])
+    if model == "p3":
+        # RayTracingProj3's Shade takes V = camera.pos - p (main.cpp:152-190): every ray starts at the camera of input2.xml
+        cam_pos = np.array([0, -60, 12], float)
+        tgt = np.stack([rng.uniform(-20, 20, 1500), rng.uniform(-5, 20, 1500), rng.uniform(-2, 26, 1500)], 1)
+        dd = tgt - cam_pos
+        dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        rays = np.concatenate([np.broadcast_to(cam_pos, (1500, 3)), dd], 1).astype(np.float32)
+        bounce = np.zeros(1500, np.int32)
+        light = np.array([0, 0, 22], np.float32)
+    else:
+        cam_pos = np.array([0, -60, 12], float)
+        counts = ({8: (40, 10), 5: (60, 40), 4: (100, 100), 3: (150, 150), 2: (150, 150), 1: (150, 150), 0: (100, 100)} if model == "p12"
+                  else {5: (500, 100), 4: (100, 150), 3: (100, 150), 2: (100, 150), 1: (100, 150), 0: (100, 100)})
+        rr, bb = [], []
+        for b, (nc, nb) in counts.items():
+            r = main_rays(rng, cam_pos, nc, nb)
+            rr.append(r)
+            bb.append(np.full(len(r), b, np.int32))
+        rays, bounce = np.concatenate(rr), np.concatenate(bb)
+        light = np.array([0, 0, 22], np.float32)
+    n = len(rays)
+    cases = np.zeros(n, np.dtype([("ray", "<f4", 6), ("bounce", "<i4"), ("seed", "<u4")]))
+    cases["ray"], cases["bounce"], cases["seed"] = rays, bounce, rng.integers(1, 2 ** 31, n)
+    cwd, xml = OLD_SCENE[model]
+    capture = 400000 if model == "p12" else 16
+
+    def run_old(sh):
+        with tempfile.TemporaryDirectory() as td:
+            fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+            with open(fin, "wb") as f:
+                f.write(struct.pack("<i", n) + cases.tobytes() + struct.pack("<i", len(sh)) + sh.tobytes() + struct.pack("<i", capture))
+            subprocess.run([OLD_HARNESS[model], "shade", xml, fin, fout], check=True, cwd=cwd)
+            return open(fout, "rb").read()
+    out = run_old(np.zeros((0, 7), np.float32))
+    hits = np.frombuffer(out, MAINHIT, n, 0)
+    hp = hits["p"][hits["hit"] == 1]
+    ns = 1024
+    src = hp[rng.integers(0, len(hp), ns)]
+    sh = np.zeros((ns, 7), np.float32)
+    sh[:, :3], sh[:, 3:6], sh[:, 6] = src, light - src, 1.0
+    k = ns // 4
+    sh[:k, 3:6] = rng.normal(size=(k, 3)) * rng.choice([0.3, 1.0, 20.0], size=(k, 1))
+    sh[:k, 6] = rng.choice([1.0, 1.0e30], k)
+    out = run_old(sh)
+    off = 0
+    hits = np.frombuffer(out, MAINHIT, n, off).copy(); off += n * MAINHIT.itemsize
+    rgb = np.frombuffer(out, np.float32, 3 * n, off).reshape(n, 3).copy(); off += 12 * n
+    consumed = np.frombuffer(out, np.int32, n, off).copy(); off += 4 * n
+    assert (consumed >= 0).all(), "rand() capture too small"
+    raw = np.frombuffer(out, np.int32, int(consumed.sum()), off).copy(); off += 4 * int(consumed.sum())
+    shadow = np.frombuffer(out, np.float32, ns, off).copy()
+    assert off + 4 * ns == len(out)
+    # the rand() values a case consumed are NOT stored: they are srand(seed)'s first `consumed` outputs, restated in
+    # oracle/orc.py (glibc_rand) -- checked here against what the reference run really drew
+    sys.path.insert(0, ROOT)
+    from oracle import orc
+    at = 0
+    for i in np.flatnonzero(consumed > 0):
+        assert (orc.glibc_rand(cases["seed"][i], consumed[i]) == raw[at:at + consumed[i]]).all(), i
+        at += consumed[i]
+    np.savez_compressed(os.path.join(GOLD, f"main_shade_{model}.npz"), rays=rays, bounce=bounce, seed=cases["seed"], hits=hits, rgb=rgb, consumed=consumed,
+                        shadow_rays=sh, shadow=shadow)
+    print(f"main_shade_{model}: {n} cases, {int(hits['hit'].sum())} hits, {int(consumed.sum())} rand() values kept (max {int(consumed.max())} per case), "
+          f"shadow {ns} rays / {int((shadow == 0).sum())} occluded, nodes {sorted(set(hits['node'][hits['hit'] == 1]))}")
+
+
 def gen_main():
     for m in ("fin", "p13"):
         if not os.path.exists(MAIN_HARNESS[m]):
@@ -733,6 +809,8 @@ def gen_main():
     gen_main_pixels("fin")
     gen_main_pixels("p13")
     gen_main_photontrace()
+    for m in ("p12", "p6", "p3"):
+        gen_main_shade_old(m)
 
 
 def main():

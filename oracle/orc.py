@@ -262,6 +262,52 @@ def shade_cases(scene, params, rays, bounces):
     return hit, hits, rgb
 
 
+def glibc_rand(seed, n):
+    """What glibc's srand(seed) followed by n calls of rand() returns (the TYPE_3 additive feedback generator of random_r:
+    r[i] = r[i-3] + r[i-31] over a state seeded by the Lehmer generator 16807, first 310 outputs discarded, top 31 bits).
+    The reference draws from it; fixtures of rand()-dependent cases keep the seed and the number of values consumed, and
+    oracle/gen_golden.py checks this restatement against the captured stream of the reference run."""
+    r = np.zeros(int(n) + 344, np.int64)
+    seed = int(seed) & 0xFFFFFFFF
+    r[0] = seed if seed else 1
+    for i in range(1, 31):
+        prev = int(r[i - 1])
+        if prev >= 2 ** 31:
+            prev -= 2 ** 32
+        hi, lo = divmod(prev, 127773)
+        w = 16807 * lo - 2836 * hi
+        r[i] = w + 2147483647 if w < 0 else w
+    for i in range(31, 34):
+        r[i] = r[i - 31]
+    rl = r.tolist()
+    for i in range(34, len(rl)):
+        rl[i] = (rl[i - 31] + rl[i - 3]) & 0xFFFFFFFF
+    return (np.array(rl[344:], np.int64) >> 1).astype(np.int32)
+
+
+def shade_cases_scripted(scene, params, rays, bounces, seeds, consumed):
+    """shade_cases with the reference's rand() stream: case i runs with the first consumed[i] values of srand(seeds[i]) as its
+    script; returns (hit flags, hit records, rgb, values the oracle consumed per case)"""
+    rays = _c(rays, np.float32).reshape(-1, 6)
+    n = len(rays)
+    rgb = np.zeros((n, 3), np.float32)
+    hit = np.zeros(n, np.int32)
+    hits = np.zeros(n, HIT)
+    used = np.zeros(n, np.int32)
+    for i in range(n):
+        h = hits[i:i + 1]
+        hit[i] = lib().orc_trace(C.byref(scene.c), params.shade_model, _p(rays[i]), C.c_void_p(h.ctypes.data))
+        if not hit[i]:
+            continue
+        raw = glibc_rand(seeds[i], int(consumed[i]) + 4)
+        lib().orc_script_begin(_p(raw), len(raw), None, 0, None, 0)
+        lib().orc_shade(C.byref(scene.c), C.byref(params), _p(rays[i]), C.c_void_p(h.ctypes.data), int(bounces[i]), _p(rgb[i]))
+        u = C.c_int()
+        lib().orc_script_end(C.byref(u))
+        used[i] = u.value
+    return hit, hits, rgb, used
+
+
 def shadow(scene, model, rays, t_max):
     """GenLight::Shadow(ray, t_max) per ray"""
     rays = _c(rays, np.float32).reshape(-1, 6)

@@ -67,7 +67,8 @@ static void rng2_at(uint32_t seed, uint32_t sample, uint32_t node, uint32_t purp
  * consumed and the values its Shadow double returned; while a script is active every random draw
  * takes the next raw value exactly the way the reference's expression does
  * (`rand() / (float) RAND_MAX`, or the double forms of P13/include/lights.h:73-74) and orc_shadow
- * logs its ray and returns the next scripted value instead of tracing. */
+ * logs its ray and returns the next scripted value instead of tracing (when shadow values or a log are handed over:
+ * a script of rand() values alone -- a whole Shade of RayTracingProj12 under its captured stream -- traces its shadow rays). */
 static struct { const int32_t *raw; int n, i; const float *sh; int nsh, ish; float *log; int log_cap, nlog; int on; } g_script;
 void orc_script_begin(const int32_t *raw_rand, int n_rand, const float *shadow_values, int n_shadow, float *shadow_log, int log_cap)
 {
@@ -492,7 +493,7 @@ float orc_shadow(const orc_scene *s, int model, const float ray[6], float t_max)
 {
     float bias = 1e-14f;
     orc_hit h;
-    if (g_script.on) {                                      /* test hook, see orc_script_begin */
+    if (g_script.on && (g_script.nsh > 0 || g_script.log)) {   /* test hook, see orc_script_begin; a script of rand() values alone leaves Shadow tracing */
         if (g_script.log && g_script.nlog < g_script.log_cap) { memcpy(g_script.log + 7 * g_script.nlog, ray, 24); g_script.log[7 * g_script.nlog + 6] = t_max; }
         g_script.nlog++;
         return g_script.nsh > 0 ? g_script.sh[(g_script.ish++) % g_script.nsh] : 1.0f;
@@ -521,7 +522,8 @@ void orc_light_direction(const rt_light *l, const float p[3], float out[3]) { st
  *   Point  : FIN/include/lights.h:67-131 -- 4 samples on a disc of radius `size`; with size==0
  *            every sample ray is position-p exactly (xv1.Length() == 0), the mean is 0 or 1 and
  *            the 16-sample refinement never runs.  size>0 draws rand() (statistical only).
- *            P13 variant (P13/include/lights.h:65-91) also collapses to position-p at size 0. */
+ *            P13 variant (P13/include/lights.h:65-91) also collapses to position-p at size 0;
+ *            RayTracingProj12's (include/lights.h:66-89) is P13's without the division by distance^2. */
 void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
                     const float p_[3], const float N_[3], float out[3])
 {
@@ -567,6 +569,7 @@ void orc_illuminate(const orc_scene *s, const rt_params *P, const rt_light *l,
             shadow_coef += orc_shadow(s, model, ray, 1);
         }
         v3 avg_shadow = vdivs(vscale(I, shadow_coef), (float)ns);   /* intensity*coef/SAMPLES */
+        if (model == RT_SHADE_P12) { st3(out, avg_shadow); return; }   /* RayTracingProj12/include/lights.h:86-88: no fall-off yet */
         float distance = vlen2(vsub(p, position));
         st3(out, vdivs(avg_shadow, distance));
         return;

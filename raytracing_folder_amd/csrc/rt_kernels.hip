@@ -600,7 +600,8 @@ __device__ __forceinline__ V3 light_direction(const rt_light &l, V3 p)
 // with s = |xv|+|yv| (the reference adds the two LENGTHS to every coordinate, :103), xv,yv a random
 // point of the disc of radius `size`; if their mean is neither 0 nor 1, MAX_SHADOW_SAMPLES (16) more
 // replace them; result intensity*shadow/dist^2.  Point, P13 (P13/include/lights.h:65-91): 4 rays
-// towards position + (dx,dy,dz), radius sqrt(Halton(i,2))*size, two random angles.
+// towards position + (dx,dy,dz), radius sqrt(Halton(i,2))*size, two random angles; P12 the same without
+// the division by dist^2 (RayTracingProj12/include/lights.h:66-89).
 // Each shadow ray is an any-hit query (GenLight::Shadow, FIN/main.cpp:499-513: occluded iff
 // 1e-14 < z < t_max).  With size == 0 all samples coincide and ONE query decides them.
 template <int MODEL>
@@ -633,6 +634,7 @@ __device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &
         const bool occ = trace<true, MODEL>(S, p, position - p, 1.0f, dummy, stack, cnt);
         float coefsum = 0.0f;
         for (int i = 0; i < ns; i++) coefsum += occ ? 0.0f : 1.0f;     // the ns identical samples
+        if (MODEL == RT_SHADE_P12) return (I * coefsum) / (float)ns;    // no fall-off yet in RayTracingProj12 (include/lights.h:86-88)
         if (MODEL != RT_SHADE_FIN) return ((I * coefsum) / (float)ns) / len2(p - position);
         const float shadow = coefsum / (float)ns;
         return (I * shadow) / len2(p - position);                       // lights.h:130
@@ -651,7 +653,8 @@ __device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &
             cnt.shadow++;
             coef += trace<true, MODEL>(S, p, lp - p, 1.0f, dummy, stack, cnt) ? 0.0f : 1.0f;
         }
-        return ((I * coef) / (float)ns) / len2(p - position);
+        if (MODEL == RT_SHADE_P12) return (I * coef) / (float)ns;       // RayTracingProj12/include/lights.h:86-88: avg_shadow, undivided
+        return ((I * coef) / (float)ns) / len2(p - position);          // P13/include/lights.h:86-90: inverse square fall-off
     }
     const V3 dir = position - p;
     V3 v1 = dot(dir, mk(1, 0, 0)) > 0.8f ? cross(mk(0, 1, 0), dir) : cross(mk(1, 0, 0), dir);

@@ -1,8 +1,9 @@
 """Workload inputs of the render path, as the product ships them (bench.py, __graft_entry__.smoke() and the
 tests all build their scenes here):
 
-  * the Cornell box of the reference's photon-mapping snapshots (BASELINE configs C3/C4): data/cornell.xml +
-    data/teapot_tri.obj, loaded through the product's own XML/OBJ loader;
+  * the Cornell box of the reference's photon-mapping snapshots (BASELINE config C4): data/cornell.xml +
+    data/teapot_tri.obj, loaded through the product's own XML/OBJ loader; data/cornell_gi.xml is the variant
+    RayTracingProj12's main() loads (config C3, live path-traced GI);
   * the stand-in for the absent christmas_balls.obj: 128 tessellated spheres
     (102 402 triangles with the ground quad) in two meshes, one of them mirrors, under a PNG sky that is both
     environment and background -- written as OBJ + PNG + XML and loaded the same way.
@@ -16,12 +17,24 @@ from . import capi
 
 DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 CORNELL_XML = os.path.join(DATA, "cornell.xml")
+CORNELL_GI_XML = os.path.join(DATA, "cornell_gi.xml")
 
 
 def load_cornell(width=None, height=None):
     """(scene, camera) of the Cornell box; width/height override the file's 800 x 600"""
     s = capi.Scene()
     s.load_xml(CORNELL_XML)
+    cam = s.camera()
+    if width:
+        cam.width, cam.height = int(width), int(height)
+    return s, cam
+
+
+def load_cornell_gi(width=None, height=None):
+    """(scene, camera) of BASELINE config C3: the scene RayTracingProj12's main() loads (its scene-2.xml: glass teapot, glossy
+    sphere, point light 0.5 -- that snapshot's PointLight has no fall-off, include/lights.h:86-88), for shade model P12"""
+    s = capi.Scene()
+    s.load_xml(CORNELL_GI_XML)
     cam = s.camera()
     if width:
         cam.width, cam.height = int(width), int(height)

@@ -12,6 +12,7 @@ CORNELL = workloads.CORNELL_XML
 
 
 load_cornell = workloads.load_cornell
+load_cornell_gi = workloads.load_cornell_gi
 oracle_scene = orc.scene_from_export        # orc.Scene over the very arrays the product exports
 oracle_camera = orc.camera_from
 oracle_params = orc.params_from

@@ -614,8 +614,8 @@ def test_p12_live_gi_model(cornell):
     """RayTracingProj12 semantics (BASELINE config 3): P13's ray tree + cosine-hemisphere GI rays at every
     hit (HEMISPHERE_SAMPLE at the primary hit, 1 below), all = ambient + (direct/pi + idr)*Kd, BOUNCE 8.
     Same counter RNG on both sides -> ray-by-ray agreement; long diffuse chains amplify libm ulps."""
-    s, cam, e = cornell
-    osc = scenes.oracle_scene(e)
+    s, cam = scenes.load_cornell_gi()           # the scene RayTracingProj12's main() loads (glass teapot, light 0.5 without fall-off)
+    osc = scenes.oracle_scene(s.export())
     # (the oracle walks the reference's full 3^bounce tree, zero-weight children included: keep it small)
     p = capi.default_params(shade_model=capi.SHADE_P12, bounce=5, hemisphere_sample=3, seed=1212,
                             min_sample=4, max_sample=8, threshold=1e-2)
@@ -630,7 +630,7 @@ def test_p12_live_gi_model(cornell):
     _, rgb0, _ = s.shade_rays(capi.default_params(shade_model=capi.SHADE_P12, bounce=0), rays)
     assert rgb.mean() > 1.2 * rgb0.mean()
     # small adaptive frame
-    s2, cam2 = scenes.load_cornell(48, 36)
+    s2, cam2 = scenes.load_cornell_gi(48, 36)
     p.hemisphere_sample = 1
     frame, z2, cnt, st, _ = s2.render(cam2, p)
     oframe, oz2, ocnt = orc.render(osc, scenes.oracle_camera(cam2), scenes.oracle_params(p))
@@ -639,14 +639,15 @@ def test_p12_live_gi_model(cornell):
 
 
 def test_config3_live_gi_at_its_stated_size():
-    """BASELINE config C3 at size: the Cornell box with RayTracingProj12's live path-traced GI (its Shade, main.cpp:341-588;
+    """BASELINE config C3 at size: the Cornell box RayTracingProj12's main() loads (scene-2.xml's constants: glass teapot,
+    glossy sphere, light 0.5 without fall-off) with that snapshot's live path-traced GI (its Shade, main.cpp:341-588;
     BOUNCE 8, HEMISPHERE_SAMPLE 1, :17-25), 800 x 600, 64 spp fixed.  No CPU oracle can follow that (it walks the
     reference's full ray tree: hours), so size-independent properties: every pixel is rendered exactly once, the frame is the
     same twice (same counter RNG; float atomics move the last ulp only), the tiles of two interleaved ranks compose it, a
     quarter-size frame agrees with it statistically -- and the queues sized from the model's fan-out hold the first frame
     (the library's render-twice fallback is NOT the normal path: attempts == 1)."""
     W, H, SPP = 800, 600, 64
-    s, cam = scenes.load_cornell(W, H)
+    s, cam = scenes.load_cornell_gi(W, H)
     p = capi.default_params(shade_model=capi.SHADE_P12, bounce=8, hemisphere_sample=1, min_sample=SPP, max_sample=SPP, threshold=-1.0,
                             seed=1212, photon_count=0)
     rgb, z, cnt, st, progress = s.render(cam, p)
@@ -1446,6 +1447,79 @@ def test_trace_and_shade_against_the_reference_main(gold, model, tag):
     err = np.abs(rgb - want)
     assert (err <= 2e-5 * np.abs(want) + 1e-6).all(), (err.max(), np.unravel_index(err.argmax(), err.shape))
     assert (want.max(axis=1) > 0).mean() > 0.5
+
+
+def _old_snapshot_scene(tag):
+    if tag == "p12":
+        return scenes.load_cornell()
+    return _load({"p6": "p6_scene.xml", "p3": "p3_spheres.xml"}[tag])
+
+
+def _same_trace(s, g, model):
+    ref = g["hits"]
+    got = s.trace_rays(g["rays"], model)
+    h = ref["hit"].astype(bool)
+    assert (got["hit"].astype(bool) == h).all()
+    for f in ("z", "p", "N"):
+        assert got[f][h].tobytes() == ref[f][h].tobytes(), f
+    assert (got["node"][h] == ref["node"][h]).all() and (got["front"][h] == ref["front"][h]).all()
+    return h
+
+
+@pytest.mark.parametrize("model,tag", [(capi.SHADE_P6, "p6"), (capi.SHADE_P3, "p3")])
+def test_early_snapshots_against_their_reference_main(gold, model, tag):
+    """the shading models of BASELINE configs C2 / C1 against the main.cpp of RayTracingProj6 / RayTracingProj3 themselves
+    (tests/golden/main_shade_p6.npz, main_shade_p3.npz): rt_trace_rays BIT-EXACT; rt_shade_rays at every bounceCount of the
+    fixture (neither Shade reads a global bounce limit) within 2e-5 relative."""
+    g = gold(f"main_shade_{tag}.npz")
+    s, cam = _old_snapshot_scene(tag)
+    h = _same_trace(s, g, model)
+    n = 0
+    for b in sorted(set(g["bounce"])):
+        sel = g["bounce"] == b
+        hit, rgb, z = s.shade_rays(capi.default_params(shade_model=model, bounce=int(b)), g["rays"][sel])
+        assert (hit.astype(bool) == h[sel]).all() and z[h[sel]].tobytes() == g["hits"]["z"][sel & h].tobytes()
+        want = g["rgb"][sel]
+        err = np.abs(rgb - want)
+        assert (err <= 2e-5 * np.abs(want) + 1e-6).all(), (b, err.max(), np.unravel_index(err.argmax(), err.shape))
+        n += int(sel.sum())
+    assert n >= 1500 and (g["rgb"].max(axis=1) > 0).mean() > 0.5
+
+
+def test_live_gi_against_the_reference_main(gold):
+    """shade model P12 against RayTracingProj12's own main.cpp (tests/golden/main_shade_p12.npz; the CPU suite holds the
+    oracle to it bit for bit, rand() stream included).  The device draws from its counter RNG, so:
+      * rt_trace_rays: hit records BIT-EXACT;
+      * bounceCount 0 (direct light only; PointLight::Illuminate of that snapshot has NO fall-off): colours within 2e-5;
+      * bounceCount 1, 2, 3: the reference's ONE draw per case against the device's mean over 48 seeds of the same case --
+        sum over the cases of (reference - device mean), in units of its standard deviation estimated from the device's
+        own samples: |z| < 4.5 per channel (a wrong weight, a missing 1/pi or cosine shows as tens of sigmas)."""
+    g = gold("main_shade_p12.npz")
+    s, cam = _old_snapshot_scene("p12")
+    h = _same_trace(s, g, capi.SHADE_P12)
+    b0 = g["bounce"] == 0
+    hit, rgb, z = s.shade_rays(capi.default_params(shade_model=capi.SHADE_P12, bounce=0, hemisphere_sample=1), g["rays"][b0])
+    want = g["rgb"][b0]
+    err = np.abs(rgb - want)
+    assert (hit.astype(bool) == h[b0]).all() and (err <= 2e-5 * np.abs(want) + 1e-6).all(), err.max()
+    assert (want.max(axis=1) > 0).mean() > 0.4
+    S = 48
+    for b in (1, 2, 3):
+        sel = (g["bounce"] == b) & h
+        # diffuse receivers only: behind glass or a mirror one draw decides between paths of very different brightness
+        sel &= g["hits"]["node"] <= 7
+        rays = g["rays"][sel]
+        acc = np.zeros((S, len(rays), 3))
+        for k in range(S):
+            _, c, _ = s.shade_rays(capi.default_params(shade_model=capi.SHADE_P12, bounce=b, hemisphere_sample=1, seed=9000 + 17 * k), rays)
+            acc[k] = c
+        mean, var = acc.mean(axis=0), acc.var(axis=0, ddof=1)
+        d = (g["rgb"][sel] - mean).sum(axis=0)
+        sd = np.sqrt((var * (1 + 1.0 / S)).sum(axis=0))
+        zscore = d / sd
+        assert len(rays) >= 150 and (np.abs(zscore) < 4.5).all(), (b, zscore, d / len(rays), mean.mean(axis=0))
+        # and the indirect term is not small against the direct one (so the test has teeth)
+        assert mean.mean() > 1.05 * g["rgb"][b0 & h & (g["hits"]["node"] <= 7)].mean()
 
 
 @pytest.mark.parametrize("model,tag", [(capi.SHADE_FIN, "fin"), (capi.SHADE_P13, "p13")])
