@@ -2,6 +2,11 @@ import os
 import sys
 
 import pytest
+# torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and the product library is
+# linked against /opt/rocm's: whichever is loaded first serves the whole process.  The tests that hand device memory from torch
+# to the library (the distributed path does the same: raytracing_folder_amd/dist.py imports torch first) need torch's own,
+# so it is loaded before anything else -- whatever subset of the tests is selected.
+import torch  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
