@@ -800,6 +800,25 @@ def gen_main_shade_old(model):
           f"shadow {ns} rays / {int((shadow == 0).sum())} occluded, nodes {sorted(set(hits['node'][hits['hit'] == 1]))}")
 
 
+def gen_main_pixels_old(model):
+    """the WHOLE frame of BASELINE config C1 (RayTracingProj3, input2.xml, 640 x 480) / C2 (RayTracingProj6, scene.xml,
+    800 x 600) from the snapshot's own RenderPixel (oracle/ref_main_harness_old.cpp `pixels`): Color24 image and z buffer"""
+    cwd, xml = OLD_SCENE[model]
+    size = {"p3": (640, 480), "p6": (800, 600)}[model]
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<ii", *size))                      # RayTracingProj3's input2.xml says 800 x 600: BASELINE config C1 is 640 x 480
+        subprocess.run([OLD_HARNESS[model], "pixels", xml, fin, fout], check=True, cwd=cwd)
+        out = open(fout, "rb").read()
+    w, h = struct.unpack("<ii", out[:8])
+    assert (w, h) == size and len(out) == 8 + 7 * w * h
+    rgb = np.frombuffer(out, np.uint8, w * h * 3, 8).reshape(h, w, 3).copy()
+    z = np.frombuffer(out, np.float32, w * h, 8 + 3 * w * h).reshape(h, w).copy()
+    np.savez_compressed(os.path.join(GOLD, f"main_pixels_{model}.npz"), rgb=rgb, z=z)
+    print(f"main_pixels_{model}: {w} x {h}, {int((z < 1e29).sum())} pixels hit, mean level {rgb.mean():.1f}")
+
+
 def gen_main():
     for m in ("fin", "p13"):
         if not os.path.exists(MAIN_HARNESS[m]):
@@ -811,6 +830,8 @@ def gen_main():
     gen_main_photontrace()
     for m in ("p12", "p6", "p3"):
         gen_main_shade_old(m)
+    gen_main_pixels_old("p6")
+    gen_main_pixels_old("p3")
 
 
 def main():

@@ -12,6 +12,7 @@
 // stream), so that the oracle can be fed the very same draws in the very same order.
 //
 // usage: ref_main_harness_old shade <scene.xml> <in.bin> <out.bin>      (cwd = the scene's directory)
+//        ref_main_harness_old pixels <scene.xml> <in.bin> <out.bin>     (RayTracingProj6 / 3: see cmd_pixels)
 // in:  int32 n; n x {float ray[6]; int32 bounce; uint32 seed}; int32 ns; ns x {float ray[6]; float t_max}; int32 capture
 // out: n x HitRec; n x float rgb[3]; n x int32 consumed (rand() calls of the case's Shade; -1: more than `capture`);
 //      sum(consumed) x int32 raw rand values, case after case; ns x float shadow
@@ -64,11 +65,40 @@ static std::vector<const Node *> g_order;
 struct HitRec { int32_t hit; float z; float p[3]; float N[3]; int32_t front; int32_t node; };
 struct ShadowProbe : public GenLight { static float call(Ray r, float t_max) { return Shadow(r, t_max); } };
 
+// ---- pixels <scene.xml> <in> <out> (RayTracingProj6 / RayTracingProj3 only) ----------------------------------------
+// The snapshot's own RenderPixel(pixelIterator &) (RayTracingProj6 main.cpp:102-153, RayTracingProj3 main.cpp:85-129: one ray
+// through the pixel centre, Shade, Color24) run over the WHOLE frame on this thread -- their iterators cannot be stopped
+// (RayTracingProj3 has no flag, RayTracingProj6's GetPixel returns true without a pixel once its flag is set, :38).
+// in:  int32 width, height (camera.imgWidth / imgHeight override; 0 = the file's)
+// out: int32 width, height; width*height x uint8 rgb[3]; width*height x float z
+#if defined(REF_P6) || defined(REF_P3)
+static int cmd_pixels(const char *in, const char *out)
+{
+    std::vector<char> b = slurp(in);
+    int32_t w = *(const int32_t *)b.data(), h = *(const int32_t *)(b.data() + 4);
+    if (w > 0 && h > 0) { camera.imgWidth = w; camera.imgHeight = h; renderImage.Init(w, h); }
+    w = camera.imgWidth; h = camera.imgHeight;
+    pIt.Init();
+    RenderPixel(pIt);
+    FILE *fo = fopen(out, "wb");
+    if (!fo) return 3;
+    fwrite(&w, 4, 1, fo); fwrite(&h, 4, 1, fo);
+    fwrite(renderImage.GetPixels(), 3, (size_t)w * h, fo);
+    fwrite(renderImage.GetZBuffer(), 4, (size_t)w * h, fo);
+    fclose(fo);
+    return renderImage.GetNumRenderedPixels() == w * h ? 0 : 4;
+}
+#endif
+
 int main(int argc, char **argv)
 {
-    if (argc < 5 || strcmp(argv[1], "shade")) { fprintf(stderr, "usage: ref_main_harness_old shade scene.xml in out\n"); return 1; }
+    if (argc < 5 || (strcmp(argv[1], "shade") && strcmp(argv[1], "pixels"))) { fprintf(stderr, "usage: ref_main_harness_old <shade|pixels> scene.xml in out\n"); return 1; }
     if (!freopen("/dev/null", "w", stdout)) return 2;
     if (!LoadScene(argv[2])) { fprintf(stderr, "LoadScene(%s) failed\n", argv[2]); return 2; }
+#if defined(REF_P6) || defined(REF_P3)
+    if (!strcmp(argv[1], "pixels")) return cmd_pixels(argv[3], argv[4]);
+#endif
+    if (strcmp(argv[1], "shade")) { fprintf(stderr, "this snapshot's harness has no `%s`\n", argv[1]); return 1; }
     walk(&rootNode, g_order);
     std::vector<char> b = slurp(argv[3]);
     const char *c = b.data();

@@ -1486,6 +1486,26 @@ def test_early_snapshots_against_their_reference_main(gold, model, tag):
     assert n >= 1500 and (g["rgb"].max(axis=1) > 0).mean() > 0.5
 
 
+@pytest.mark.parametrize("model,tag,bounce", [(capi.SHADE_P6, "p6", 5), (capi.SHADE_P3, "p3", 0)])
+def test_config1_and_config2_frames_against_the_reference_render_pixel(gold, model, tag, bounce):
+    """BASELINE configs C2 (800 x 600) and C1 (640 x 480), whole frames, against the image and z buffer the snapshot's own
+    RenderPixel loop produced (tests/golden/main_pixels_p6.npz / _p3.npz): z EXACT on every pixel, colours within one level on
+    >= 99.9 % (C1: equal on > 99 % -- its unbiased spheres let a last-ulp difference flip a grazing shadow ray)."""
+    g = gold(f"main_pixels_{tag}.npz")
+    s, cam = _old_snapshot_scene(tag)
+    assert (cam.height, cam.width) == g["z"].shape
+    p = capi.default_params(shade_model=model, min_sample=1, max_sample=1, threshold=-1.0, gamma=1.0, bounce=bounce)
+    rgb, z, cnt, st, progress = s.render(cam, p)
+    assert progress == cam.width * cam.height and st.rays_primary == progress
+    assert z.tobytes() == g["z"].tobytes()
+    d = np.abs(rgb.astype(int) - g["rgb"].astype(int)).max(axis=2)
+    if model == capi.SHADE_P3:
+        assert (d == 0).mean() > 0.99
+    else:
+        assert (d <= 1).mean() > 0.999 and st.rays_reflect > 0 and st.rays_refract > 0
+    assert (d > 8).mean() < 0.01
+
+
 def test_live_gi_against_the_reference_main(gold):
     """shade model P12 against RayTracingProj12's own main.cpp (tests/golden/main_shade_p12.npz; the CPU suite holds the
     oracle to it bit for bit, rand() stream included).  The device draws from its counter RNG, so:
