@@ -1966,6 +1966,19 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     uint32_t x_below = 0, x_above = 0, x_other = 0, x_mk = 0;
 #endif
     float pred_rk2 = 0.0f;                                // k-th squared distance of this wave's previous query (a hint only)
+#ifdef RT_EXP_TIME_PHASEA
+    unsigned long long xa_total = 0, xa_fullsum = 0;
+    const unsigned long long xa_start = __builtin_readcyclecounter();
+#endif
+#ifdef RT_EXP_TIME_PARTS        /* tuning build: wave cycles per part of phase B, /1024: =1: visited = sub-leaf listing, leaf_reads = pass 1 (or the plain pass), slow = everything after pass 1 of a query; =2: visited = the k-th bin search, leaf_reads = ring scan or pass 2, slow = selection + wave sums; rounds = the kernel */
+    unsigned long long xp0 = 0, xp1 = 0, xp2 = 0, xpt = 0;
+    const unsigned long long xp_start = __builtin_readcyclecounter();
+#define XP_MARK() (xpt = __builtin_readcyclecounter())
+#define XP_ADD(which, v) do { if (RT_EXP_TIME_PARTS == (which)) { const unsigned long long n_ = __builtin_readcyclecounter(); (v) += n_ - xpt; xpt = n_; } } while (0)
+#else
+#define XP_MARK() ((void)0)
+#define XP_ADD(which, v) ((void)0)
+#endif
 
     // batches of RT_GATHER_BATCH queries are handed out dynamically (one atomic per batch): query cost varies by
     // two orders of magnitude with the local photon density, so a static split leaves a long tail
@@ -2035,6 +2048,10 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
         }
 
         while (ballot64(pending)) {
+#ifdef RT_EXP_TIME_PHASEA       /* tuning build: wave cycles spent in phase A (visited), of them in batches with a full-radius query (leaf_reads), and in the kernel (rounds), in units of 1024 cycles */
+            const unsigned long long xa0 = __builtin_readcyclecounter();
+            const bool xa_full = ballot64(pending && r2cur >= r2) != 0;
+#endif
             // ---------------- phase A: pending lanes list the leaves inside their trial radius ----
             // Two lanes walk for one query: lane l and lane l + 32 hold the same point and radius, keep the same walk state
             // and split the box tests of every visit between them (grandchildren 0-1 / 2-3, child 0 / 1); one
@@ -2103,6 +2120,9 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 }
             }
             wave_sync();
+#ifdef RT_EXP_TIME_PHASEA
+            { const unsigned long long dt = __builtin_readcyclecounter() - xa0; xa_total += dt; if (xa_full) xa_fullsum += dt; }
+#endif
 #ifdef RT_EXP_PHASEA            /* cost attribution build: phase A only, results are garbage */
             pending = false;
 #endif
@@ -2126,6 +2146,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 const uint32_t dummy_sub = n_sub_total;    // one more sub-leaf after the real ones, every slot empty
                 uint32_t n_sub = 0;
                 wave_sync();                               // the previous query's passes are done with L.subs
+                XP_MARK();
                 if (!slow) {
                     for (uint32_t base = 0; base < qnl * RT_LEAF_SUBS; base += 64u) {
                         const uint32_t e = base + (uint32_t)lane;
@@ -2147,6 +2168,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     }
                 }
                 n_rounds++; n_slow += slow ? 1u : 0u; n_reads += n_sub;
+                XP_ADD(1, xp0);
                 // run one pass over the query's sub-leaves
                 auto for_each = [&](auto &&f) {
                     if (!slow) { scan_subleaves(G.pm, L.subs, n_sub, lane, Q, f); return; }
@@ -2200,6 +2222,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         accumulate(cd.pa, cd.pb, cd.d2 < rq2);
                     });
                     visited += n_sub;
+                    XP_ADD(1, xp1); XP_MARK();
                     if (M <= K) done_plain = true;
                     else { M = 0; s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0; n_reads += n_sub; }
                 }
@@ -2247,6 +2270,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 });
 #endif
                 visited += n_sub;
+                XP_ADD(1, xp1); XP_MARK();
 #ifdef RT_EXP_PASS1ONLY         /* cost attribution build: nothing after pass 1; results are garbage */
                 if (G.mode == 1 && s_pr == 12345.678f && lane == 0) G.out_irr[0] = s_pr + (float)M + (float)n_ring;
                 if (lane == q) pending = false;
@@ -2304,6 +2328,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         });
                     }
                     const uint32_t bin_mask = ~((1u << shift) - 1u) & 0xFFFFFFu;
+                    XP_ADD(2, xp0);
                     wave_sync();                           // the histogram is dead from here on: its LDS now holds the selection
                     if (lane == 0) L.sel_n = 0;
                     wave_sync();
@@ -2390,6 +2415,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         accumulate(cd.pa, cd.pb, take);
                     });
                     }
+                    XP_ADD(2, xp1);
                     wave_sync();
                     if (in_bin <= 64u) {
                         // exact selection: rank by (d2, list position); take ranks < need
@@ -2451,6 +2477,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         pending = false;
                     }
                 }
+                XP_ADD(1, xp2); XP_ADD(2, xp2);
             }
             if (finish) {
                 float irr_r = f_pr, irr_g = f_pg, irr_b = f_pb, dx = f_dx, dy = f_dy, dz = f_dz;
@@ -2494,6 +2521,12 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
             wave_sync();
         }
     }
+#ifdef RT_EXP_TIME_PARTS
+    visited = (xp0 >> 10) / RT_SUB_PHOTONS; n_reads = (uint32_t)((xp1 >> 10) * 32u / RT_SUB_PHOTONS); n_slow = (uint32_t)(xp2 >> 10); n_rounds = (uint32_t)((__builtin_readcyclecounter() - xp_start) >> 10);
+#endif
+#ifdef RT_EXP_TIME_PHASEA
+    visited = (xa_total >> 10) / RT_SUB_PHOTONS; n_reads = (uint32_t)((xa_fullsum >> 10) * 32u / RT_SUB_PHOTONS); n_rounds = (uint32_t)((__builtin_readcyclecounter() - xa_start) >> 10);
+#endif
 #ifdef RT_EXP_COUNT_FALLBACK2
     n_rounds = x_below; n_slow = x_above; n_reads = x_other * 32u / RT_SUB_PHOTONS; visited = x_mk; 
 #endif
