@@ -1889,7 +1889,11 @@ __device__ __forceinline__ void scan_subleaves(const DevPhotonMap &pm, const uin
         const uint32_t off = (mine[RT_SUBS_PER_STEP * it] * (RT_SUB_PHOTONS * 16u)) | lane_off;   // < 2^32: checked at upload
         slot = off;
         a = *(const float4 *)(pa + off);
+#ifdef RT_EXP_HALFLOAD          /* cost attribution build: the second 16 bytes of a photon are not read (made up from the first); results are garbage */
+        b = make_float4(a.x * 0.001f, -0.5f, 1.0e-6f, __uint_as_float(0x00808080u));
+#else
         b = *(const float4 *)(pb + off);
+#endif
     };
 #if RT_GATHER_AHEAD == 0
     for (uint32_t it = 0; it < n_iter; it++) {
