@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0        # aggregate L2 rate of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
+L1_PEAK_GBS = 64.0 * 256 * 2.4     # the vector L1s: 64 bytes per clock and CU (a 16-byte-per-lane wave load = 16 L1 accesses), 256 CUs at 2.4 GHz
 VALU_PEAK_GINST = 1024 * 2.4 / 2      # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs at 2.4 GHz, one per 2 cycles (32 lanes per cycle; the
                                       # 157.3 TF f32 vector peak is exactly that with fma).  One WAVE issues at most one per 4 cycles.
 PARITY_NOTE = ("oracle pinned bit for bit to the reference's own code on the whole path: primitives / BVH / kNN / photon balance (compiled "
@@ -216,7 +217,7 @@ def profile_figures(default_workload):
     5 %, the figures are reported as STALE instead of quoted (main() then emits frac: null, stale_profile: true)."""
     import glob
     from raytracing_folder_amd import buildinfo
-    out = {"hbm": {}, "hbm_launches": {}, "valu_insts": {}, "file_launch_us": {}, "hbm_source": None, "valu_source": None,
+    out = {"hbm": {}, "hbm_launches": {}, "valu_insts": {}, "l1_accesses": {}, "file_launch_us": {}, "hbm_source": None, "valu_source": None,
            "build": buildinfo.kernel_source_sha16(), "stale": []}
     if not default_workload:
         return out
@@ -238,6 +239,8 @@ def profile_figures(default_workload):
                 elif "SQ_INSTS_VALU" in v and v.get("avg_launch_us"):
                     # wave instructions and microseconds per profiled FRAME (the counter passes profile exactly one frame)
                     out["valu_insts"][name] = float(v["SQ_INSTS_VALU"]) * float(v.get("launches", 1))
+                    if "TCP_TOTAL_CACHE_ACCESSES_sum" in v:      # 64-byte accesses of the vector L1s
+                        out["l1_accesses"][name] = float(v["TCP_TOTAL_CACHE_ACCESSES_sum"]) * float(v.get("launches", 1))
                     out["file_launch_us"][name] = float(v["avg_launch_us"]) * float(v.get("launches", 1))
             out[key + "_source"] = os.path.basename(files[-1])
         except Exception as e:
@@ -434,6 +437,9 @@ def main():
                     # NOT clamped: a value above 1 would show the peak is mispriced.
                     live_us = c["ms"] * 1e3                                     # this class, per frame, exclusive
                     row["valu_frac"] = round(figs["valu_insts"][q0] / (live_us * 1e3) / VALU_PEAK_GINST, 4)
+                    if q0 in figs["l1_accesses"]:
+                        # the vector-memory pipe: 64-byte L1 accesses counted in the profile / live time, against 64 B per clock and CU
+                        row["l1_frac"] = round(figs["l1_accesses"][q0] * 64.0 / (live_us * 1e-6) / 1e9 / L1_PEAK_GBS, 4)
                     row["live_us_per_frame"] = round(live_us, 1)
                     row["profile_us_per_frame"] = round(figs["file_launch_us"][q0], 1)
                     # (the tracer class also holds the k_bounce launches behind k_wavefront: compared with a wider margin)
@@ -443,7 +449,7 @@ def main():
                 table[name] = row
             dom = max(classes, key=lambda k: classes[k]["ms"])
             d, c = table[dom], classes[dom]
-            fr = {"hbm": d.get("hbm_frac"), "l2": d["l2_frac"], "valu": d.get("valu_frac")}
+            fr = {"hbm": d.get("hbm_frac"), "l2": d["l2_frac"], "valu": d.get("valu_frac"), "l1": d.get("l1_frac")}
             bound = max((k for k in fr if fr[k] is not None), key=lambda k: fr[k])
             launches = max(c["launches"], 1.0)
             sec_launch = c["ms"] * 1e-3 / launches
@@ -451,12 +457,14 @@ def main():
                 ach, peak, unit = d["hbm_bytes_per_frame"] / (c["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
             elif bound == "l2":
                 ach, peak, unit = d["l2_GBps"], L2_PEAK_GBS, "GB/s"
+            elif bound == "l1":
+                ach, peak, unit = fr["l1"] * L1_PEAK_GBS, L1_PEAK_GBS, "GB/s"
             else:
                 ach, peak, unit = fr["valu"] * VALU_PEAK_GINST, VALU_PEAK_GINST, "Gwave-inst/s"
             stale = bool(figs["stale"])
             if stale:
                 # counter-derived fractions belong to other kernels than the ones that just ran: not quoted
-                fr = {"hbm": None, "l2": fr["l2"], "valu": None}
+                fr = {"hbm": None, "l2": fr["l2"], "valu": None, "l1": None}
             roof = {"kernel": dom, "bound": bound if not stale else "l2", "achieved": round(ach, 2) if not stale else d["l2_GBps"],
                     "peak": round(peak, 1) if not stale else L2_PEAK_GBS, "unit": unit if not stale else "GB/s",
                     "frac": round(fr[bound], 4) if not stale else None, "stale_profile": stale, "stale_reasons": figs["stale"],
