@@ -222,7 +222,7 @@ def profile_figures(default_workload):
     if not default_workload:
         return out
     for key, pat in (("hbm", "_bench_pmc_hbm.json"), ("valu", "_bench_sq_counters.json")):
-        # tags of the headline workload carry no workload suffix: r03s_bench_..., not r03s_balls_bench_...
+        # tags of the headline workload carry no workload suffix: r03v_bench_..., not r03v_balls_bench_...
         import re
         files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*" + pat)) if re.match(r"^r\d+[a-z]*" + re.escape(pat) + "$", os.path.basename(f)))
         if not files:
