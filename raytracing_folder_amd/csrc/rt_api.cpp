@@ -723,6 +723,7 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
         if (len > RT_MAX_DEPTH) return fail(RT_ERR_LIMIT, "node %d is nested %d deep; the device supports %d levels", i, len, RT_MAX_DEPTH);
         o.chain_len = len;
         for (int c = 0; c < len; c++) o.chain[c] = chain[len - 1 - c];      // root .. self
+        memcpy(o.own_itm, n.itm, 36); memcpy(o.own_pos, n.pos, 12);         // the node's own ToNodeCoords transform, beside the rest
         {   // bounds in the ROOT node's coordinates (where every ray is taken first): the 8 corners of the
             // local extent through tm*p + pos of self .. the root's child (double), inflated by 1e-3 of
             // the extent (the exact test runs in float in local space)

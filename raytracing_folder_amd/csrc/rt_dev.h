@@ -41,17 +41,22 @@
 
 struct DevNodeXf { float itm[9]; float pos[3]; float tm[9]; float pad[3]; };
 
+// 128 bytes, read through the scalar cache by the wave-uniform object loop of trace(): everything an iteration needs of the
+// object sits in this ONE record -- bounds, kind, the chain of its ancestors and a copy of its OWN node's ToNodeCoords
+// transform -- so the loads of an iteration are issued together and waited for once (the loop used to chase
+// object -> chain entry -> node transform through three dependent scalar loads per object and ray batch).
 struct DevObject {
-    int32_t type, mesh, material, node;
-    int32_t chain_len;
-    int32_t chain[RT_MAX_DEPTH];
     // conservative bounds of the object in the root node's coordinates (its local extent taken through
     // FromNodeCoords of every ancestor below the root, inflated): a ray that misses them, or enters them
     // beyond its closest hit so far, cannot be given a hit by the exact local-space test, so the
     // object's transforms are skipped
     float wlo[3], whi[3];
-    int32_t pad;
+    int32_t type, mesh;
+    int32_t chain_len, material, node, pad;
+    int32_t chain[RT_MAX_DEPTH];       // root .. self
+    float own_itm[9], own_pos[3];      // DevNodeXf::itm / pos of chain[chain_len - 1]
 };
+static_assert(sizeof(DevObject) == 128, "one object = two 64-byte scalar loads");
 
 struct DevBvhNode {              // 64 bytes
     float lo0[3], hi0[3];

@@ -356,7 +356,24 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
 // ancestor in turn (scene.h:502-508; direction NOT renormalised, so t is shared by all spaces),
 // and the closest hit is brought back through FromNodeCoords of each ancestor (scene.h:509-513).
 // ------------------------------------------------------------------------------------------------
+#ifdef RT_EXP_WF_TIME           /* tuning build: instance_visits = wave kilo-cycles in closest-hit traces (x64), bvh_nodes = in any-hit (shadow) traces, tris = in shade_path as a whole */
+template <bool ANY, int MODEL, bool TEX>
+__device__ bool trace_impl(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt);
 template <bool ANY, int MODEL, bool TEX = false>
+__device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt)
+{
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    Counters dummy = {0, 0, 0, 0};
+    const bool r = trace_impl<ANY, MODEL, TEX>(S, o, d, zinit, h, stack, dummy);
+    const uint32_t dt = (uint32_t)((__builtin_readcyclecounter() - t0) >> 6);
+    if (ANY) cnt.nodes += dt; else cnt.inst += dt;
+    return r;
+}
+#define trace trace_impl
+template <bool ANY, int MODEL, bool TEX>
+#else
+template <bool ANY, int MODEL, bool TEX = false>
+#endif
 __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt)
 {
     float z = zinit;
@@ -389,25 +406,43 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
     const V3 winv = mk(__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y), __builtin_amdgcn_rcpf(d0.z));
     for (int oi = 0; oi < S.n_objects; oi++) {
         const DevObject *obp = S.objects + oi;
+        // Everything this iteration needs of the object comes from its one 128-byte record, fetched by two 64-byte scalar loads
+        // issued back to back and waited for ONCE.  Written as inline assembly because the compiler, short of scalar registers
+        // in these kernels, otherwise sinks every field's load to its first use: five dependent scalar-cache round trips per
+        // object (bounds -> chain length -> group id -> chain entry -> node transform) in a loop three waves per SIMD cannot hide.
+        typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+        u32x16 r0, r1;
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r0), "=&s"(r1) : "s"(obp) : "memory");
+        static_assert(offsetof(DevObject, type) == 24 && offsetof(DevObject, chain_len) == 32 && offsetof(DevObject, chain) == 48 && offsetof(DevObject, own_itm) == 80, "record layout the loads assume");
+        const float wlo[3] = {__uint_as_float(r0[0]), __uint_as_float(r0[1]), __uint_as_float(r0[2])}, whi[3] = {__uint_as_float(r0[3]), __uint_as_float(r0[4]), __uint_as_float(r0[5])};
+        const int ob_type = (int)r0[6], ob_mesh = (int)r0[7], ob_chain_len = (int)r0[8], n1 = (int)r0[13];
+        M9 own_itm;
+        own_itm.m[0] = __uint_as_float(r1[4]); own_itm.m[1] = __uint_as_float(r1[5]); own_itm.m[2] = __uint_as_float(r1[6]);
+        own_itm.m[3] = __uint_as_float(r1[7]); own_itm.m[4] = __uint_as_float(r1[8]); own_itm.m[5] = __uint_as_float(r1[9]);
+        own_itm.m[6] = __uint_as_float(r1[10]); own_itm.m[7] = __uint_as_float(r1[11]); own_itm.m[8] = __uint_as_float(r1[12]);
+        const V3 own_pos = mk(__uint_as_float(r1[13]), __uint_as_float(r1[14]), __uint_as_float(r1[15]));
         // skip the object when no lane's ray can reach its bounds before that lane's closest hit so far
-        const float wlo[3] = {cld(obp->wlo), cld(obp->wlo + 1), cld(obp->wlo + 2)}, whi[3] = {cld(obp->whi), cld(obp->whi + 1), cld(obp->whi + 2)};
         if (!__any(box_entry(wlo, whi, p0, winv, z) < 2.0e30f)) continue;
-        const int ob_type = cld(&obp->type), ob_chain_len = cld(&obp->chain_len);
         V3 lp = p0, ldir = d0;
         int c = 1;
         if (ob_chain_len > 2) {
-            const int n1 = cld(&obp->chain[1]);
             if (n1 != cached1) { p1 = p0; d1 = d0; to_node(n1, p1, d1); cached1 = n1; }
             lp = p1; ldir = d1; c = 2;
         }
-        for (; c < ob_chain_len; c++) to_node(cld(&obp->chain[c]), lp, ldir);
+        for (; c < ob_chain_len - 1; c++) to_node(cld(&obp->chain[c]), lp, ldir);     // levels between the group and the object: deeper scene graphs only
+        if (ob_chain_len > 1) {
+            // the object's own level, Node::ToNodeCoords with the copy of its transform in the record (same arithmetic as to_node)
+            const V3 rp = mmul(own_itm.m, lp - own_pos);
+            ldir = mmul(own_itm.m, (lp + ldir) - own_pos) - rp;
+            lp = rp;
+        }
         cnt.inst++;
         V3 hp, hN;
         int fr = 1;
         bool hit = false;
         if (ob_type == RT_OBJ_SPHERE) hit = (MODEL == RT_SHADE_P3) ? sphere_hit_p3(lp, ldir, z, hp, hN) : sphere_hit(lp, ldir, z, hp, hN, fr);
         else if (ob_type == RT_OBJ_PLANE) hit = plane_hit(MODEL, lp, ldir, z, hp, hN, fr);
-        else if (ob_type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes + cld(&obp->mesh), lp, ldir, z, hp, hN, fr, stack, cnt, (TEX && S.use_uvw) ? &uvw : nullptr);
+        else if (ob_type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes + ob_mesh, lp, ldir, z, hp, hN, fr, stack, cnt, (TEX && S.use_uvw) ? &uvw : nullptr);
         if (hit) {
             if (ANY) return true;
             best = oi; bp = hp; bN = hN; bfront = fr;
@@ -429,6 +464,9 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
     h.z = z; h.p = bp; h.N = bN; h.node = ob.node; h.front = bfront;
     return true;
 }
+#ifdef RT_EXP_WF_TIME
+#undef trace
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Counter-based random numbers for the stochastic effects.  The reference calls
@@ -1338,6 +1376,9 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
 #ifndef RT_WF_TEX_WAVES
 #define RT_WF_TEX_WAVES 3      // ... of the textured ones (measured on the 102 k-triangle frame under a PNG sky: 40.5 ms at two, 31.2 ms at three)
 #endif
+#ifndef RT_WF_PERWAVE
+#define RT_WF_PERWAVE 1        // 1: for the P12 model every wave of k_wavefront runs its own rounds on its own part of the LDS ray stack (no workgroup barriers); 0: the four waves always share stack and rounds
+#endif
 #define RT_WF_HALTON 64
 template <bool TEX> struct WfCfg {
     static constexpr int WAVES = TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES;
@@ -1365,6 +1406,109 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
     __shared__ float4 s_qa[Cfg::STACK], s_qb[Cfg::STACK], s_qc[Cfg::STACK];
     __shared__ uint32_t s_count, s_batch;
     __shared__ float s_h2[RT_WF_HALTON], s_h3[RT_WF_HALTON];
+  if constexpr (RT_WF_PERWAVE && MODEL == RT_SHADE_P12) {
+    // RayTracingProj12's paths (one hemisphere ray per hit, eight levels deep: every round is a pop round): every WAVE runs its
+    // own rounds on its own quarter of the ray stack, no workgroup barrier anywhere in the loop.  A round's length varies by
+    // an order of magnitude with what its 64 rays meet, and with a shared stack the four waves of a workgroup meet at three
+    // barriers per round (C3: 307 -> 272 ms).  Not for the FIN / P13 trees: their glass doubles the rays level by level, a
+    // quarter stack overflows into the global queue and its per-level launches (Cornell tracer 16.8 -> 32.2 ms, measured).
+    constexpr int NW = RT_BLOCK / 64;
+    constexpr uint32_t STACK_W = (uint32_t)Cfg::STACK / NW;
+    constexpr uint32_t POP_W = STACK_W > 128u ? (STACK_W - 127u < 64u ? STACK_W - 127u : 64u) : 1u;   // pop before a round of primaries (two children each) could overflow
+    __shared__ uint32_t s_countw[NW];
+    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    float4 *qa = s_qa + wv * STACK_W, *qb = s_qb + wv * STACK_W, *qc = s_qc + wv * STACK_W;
+    uint32_t *stack = s_stack + threadIdx.x;
+    Counters cnt = {0, 0, 0, 0};
+    uint32_t nprim = 0, nrefl = 0, nrefr = 0;
+    const uint32_t npix = (A.mode == 1) ? C.W.counts[CNT_PIXLIST] : A.npix;
+    const unsigned long long total = A.mode == 3 ? (unsigned long long)min(*A.qsrc_count, A.qsrc.cap)
+                                                 : (unsigned long long)npix * (unsigned long long)A.ns;
+    const unsigned long long n_batches = (total + 63ull) / 64ull;
+    const bool h_table = A.mode < 2 && A.ns <= RT_WF_HALTON;
+    uint32_t *next_batch = C.W.counts + (A.mode == 3 ? CNT_WF2_NEXT : CNT_PRIMARY_NEXT);
+    if (h_table && (int)threadIdx.x < A.ns) { s_h2[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 2); s_h3[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 3); }
+    if (lane == 0) s_countw[wv] = 0;
+    C.lds_a = qa; C.lds_b = qb; C.lds_c = qc; C.lds_count = &s_countw[wv]; C.lds_cap = STACK_W;
+    __syncthreads();                                      // the Halton table (the only thing the waves share)
+    (void)s_count; (void)s_batch;
+    auto wsync = []() {                                   // LDS operations of one wave complete in issue order: only the compiler has to be held
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    bool more_primaries = true;                           // wave-uniform
+    for (;;) {
+        wsync();                                          // last round's pushes are complete
+        uint32_t waiting = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_countw[wv]);
+        if (waiting > STACK_W) waiting = STACK_W;         // the excess went to the global queue
+        const bool pop = waiting >= POP_W || (!more_primaries && waiting > 0);
+        if (!pop && !more_primaries) break;
+        PathIn in;
+        bool active;
+        if (pop) {
+            const uint32_t n = min(waiting, 64u);
+            active = (uint32_t)lane < n;
+            in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
+            in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0; in.spec = 0;
+            in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
+            if (active) {
+                const uint32_t src = waiting - 1u - (uint32_t)lane;       // newest (deepest) first: the stack stays shallow
+                const float4 a = qa[src], b = qb[src], c = qc[src];
+                in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
+                in.thr = mk(b.z, b.w, c.x);
+                in.slot = __float_as_uint(c.y);
+                const uint32_t pk = __float_as_uint(c.z);
+                in.bounce = (int)(pk & 0xFu); in.kind = (pk >> 4) & 0xFu; in.spec = (pk >> 8) & 0xFFu; in.node = __float_as_uint(c.w);
+                const float *ab = C.S.materials[pk >> 16].absorption;
+                in.absorb = (MODEL == RT_SHADE_FIN) ? ld3(ab) : mk(ab[0], 0, 0);
+                if (C.S.stochastic || MODEL == RT_SHADE_P12) in.sample = sample_of_slot(C.sm, in.slot);     // P12 draws its hemisphere rays
+                if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
+            }
+            wsync();                                      // all pops read before anything is pushed over them
+            if (lane == 0) s_countw[wv] = waiting - n;
+        } else {
+            uint32_t bt = 0;
+            if (lane == 0) { bt = atomicAdd(next_batch, 1u); if (s_countw[wv] > STACK_W) s_countw[wv] = STACK_W; }
+            const unsigned long long batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt);
+            if (batch >= n_batches) { more_primaries = false; continue; }
+            if (A.mode == 3) {
+                const unsigned long long src = batch * 64ull + (unsigned)lane;
+                active = src < total;
+                in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
+                in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0; in.spec = 0;
+                in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
+                if (active) {
+                    const float4 a = A.qsrc.a[src], b = A.qsrc.b[src], c = A.qsrc.c[src];
+                    const uint4 dd = A.qsrc.d[src];
+                    in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
+                    in.thr = mk(b.z, b.w, c.x); in.absorb = mk(c.y, c.z, c.w);
+                    in.slot = dd.x; in.bounce = (int)(dd.y & 0xFFu); in.kind = (dd.y >> 8) & 0xFFu; in.spec = (dd.y >> 16) & 0xFFu; in.node = dd.z; in.sample = dd.w;
+                    if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
+                }
+            } else {
+                active = primary_setup(C, A, batch * 64ull + (unsigned)lane, total, h_table, s_h2, s_h3, in);
+                if (active) nprim++;
+            }
+        }
+        wsync();                                          // the count is settled before this round's pushes
+#ifdef RT_EXP_WF_TIME
+        const unsigned long long xt0 = __builtin_readcyclecounter();
+#endif
+        shade_path<MODEL, TEX>(C, in, active, stack, cnt);
+#ifdef RT_EXP_WF_TIME
+        cnt.tris += (uint32_t)((__builtin_readcyclecounter() - xt0) >> 6);
+        cnt.shadow = 0;
+#endif
+    }
+    flush_counters(C.W.stats, cnt, nprim, nrefl, nrefr);
+  } else {
+#ifdef RT_EXP_WF_TIME           /* rays_shadow = wave kilo-cycles (x64) spent at the workgroup barriers of the round loop */
+    uint32_t xbar = 0;
+#define XSYNC() do { const unsigned long long b0_ = __builtin_readcyclecounter(); __syncthreads(); xbar += (uint32_t)((__builtin_readcyclecounter() - b0_) >> 6); } while (0)
+#else
+#define XSYNC() __syncthreads()
+#endif
     uint32_t *stack = s_stack + threadIdx.x;
     Counters cnt = {0, 0, 0, 0};
     uint32_t nprim = 0, nrefl = 0, nrefr = 0;
@@ -1381,7 +1525,7 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
     C.lds_a = s_qa; C.lds_b = s_qb; C.lds_c = s_qc; C.lds_count = &s_count; C.lds_cap = Cfg::STACK;
     bool more_primaries = true;                           // workgroup-uniform
     for (;;) {
-        __syncthreads();                                  // last round's pushes are complete
+        XSYNC();                                  // last round's pushes are complete
         uint32_t waiting = s_count;
         if (waiting > (uint32_t)Cfg::STACK) waiting = Cfg::STACK;   // the excess went to the global queue
         // pop a full workgroup's worth when there is one -- and already earlier when a round of primary rays (up to two
@@ -1389,7 +1533,7 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
         // per-level launches, the slow path (measured: 5 ms per Cornell frame before this rule)
         const bool pop = waiting >= (uint32_t)Cfg::POP || (!more_primaries && waiting > 0);
         if (!pop && !more_primaries) break;
-        __syncthreads();                                  // everyone has read s_count
+        XSYNC();                                  // everyone has read s_count
         PathIn in;
         bool active;
         if (pop) {
@@ -1417,11 +1561,11 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
                 if (C.S.stochastic || MODEL == RT_SHADE_P12) in.sample = sample_of_slot(C.sm, in.slot);     // P12 draws its hemisphere rays
                 if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
             }
-            __syncthreads();                              // all pops read before anything is pushed over them
+            XSYNC();                              // all pops read before anything is pushed over them
             if (threadIdx.x == 0) s_count = waiting - n;
         } else {
             if (threadIdx.x == 0) { s_batch = atomicAdd(next_batch, 1u); if (s_count > (uint32_t)Cfg::STACK) s_count = Cfg::STACK; }
-            __syncthreads();
+            XSYNC();
             const unsigned long long batch = s_batch;
             if (batch >= n_batches) { more_primaries = false; continue; }
             if (A.mode == 3) {
@@ -1443,10 +1587,18 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
                 if (active) nprim++;
             }
         }
-        __syncthreads();                                  // s_count settled before this round's pushes
+        XSYNC();                                  // s_count settled before this round's pushes
+#ifdef RT_EXP_WF_TIME
+        const unsigned long long xt0 = __builtin_readcyclecounter();
+#endif
         shade_path<MODEL, TEX>(C, in, active, stack, cnt);
+#ifdef RT_EXP_WF_TIME
+        cnt.tris += (uint32_t)((__builtin_readcyclecounter() - xt0) >> 6);
+        cnt.shadow = xbar;
+#endif
     }
     flush_counters(C.W.stats, cnt, nprim, nrefl, nrefr);
+  }
 }
 
 // K2 alone: n closest-hit queries (rt_trace_rays)
