@@ -30,6 +30,7 @@ bool rtk_launch_wavefront_queue(hipStream_t, const DevScene &, const DevWork &, 
                                 const DevRayQueue &, uint32_t *, const DevCamera &, const DevTiles &, uint32_t, int, int);
 void rtk_launch_gather(hipStream_t, const DevPhotonMap &, const float4 *, const float4 *, const float4 *, const uint32_t *,
                        uint32_t, int, float, float *, float *, float *, int, unsigned long long *, int, uint32_t *, float *);
+bool rtk_wavefront_usable(const DevScene &, const rt_params &);
 void rtk_launch_resolve(hipStream_t, const DevScene &, const DevWork &, const DevCamera &, const DevTiles &, uint32_t, uint32_t, int, int,
                         float, float, int, const float *, uint8_t *, float *, uint8_t *, void *, int);
 void rtk_launch_unpack_tiles(hipStream_t, const void *, int, int, int, int, int, int, uint8_t *, float *, uint8_t *);
@@ -138,11 +139,12 @@ struct DevMeshBufs { DevBuf nodes, tris, tri_face, nrm, tex; };
 #define RT_STREAMS 4                    /* slots compiled in; render_streams() says how many are used */
 struct Workspace {
     DevBuf sample_rgb, sample_z, sample_hit, rq[2][5], pq[3], cq[3], counts, pixel_list;
+    DevBuf bvh_spill;                   // traversal-stack entries beyond the kernels' LDS stacks (only for scenes whose BVHs can need them)
     size_t samples = 0; uint32_t rq_cap = 0, pq_cap = 0;
     hipStream_t stream = nullptr;       // slot 0 runs on the caller's / the device's main stream instead
     void release()
     {
-        for (DevBuf *b : {&sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list}) b->release();
+        for (DevBuf *b : {&sample_rgb, &sample_z, &sample_hit, &counts, &pixel_list, &bvh_spill}) b->release();
         for (int i = 0; i < 2; i++) for (int k = 0; k < 5; k++) rq[i][k].release();
         for (int k = 0; k < 3; k++) { pq[k].release(); cq[k].release(); }
         if (stream) (void)hipStreamDestroy(stream);
@@ -158,9 +160,11 @@ struct DeviceState {
     DevBuf pa, pb, box4, grid;                  // the gather structure of the photon map (rt_photon_build.hip)
     DevBuf cpa, cpb, cbox4, cgrid;              // ... of the caustic map
     DevBuf raw_photons;                         // 24-byte photons of the last photon pass on this device (1-based)
+    DevBuf bvh_spill;                           // DevScene::bvh_spill of the single-stage entry points (rt_trace_rays, the photon pass); renders use their working set's
     // per density-grid cell, the k-th squared distance of the last query k_gather answered there: predicts the next one's (a
     // hint that only steers which of two exact paths a query takes); zeroed whenever the structure is rebuilt
     DevBuf cell_rk2, ccell_rk2;
+    int rk2_k = 0, rk2_k_c = 0; float rk2_radius = 0, rk2_radius_c = 0;     // the gather parameters the two hint tables were filled under (0: empty)
     DevBuf cell_start, ccell_start;             // DevPhotonMap::cell_start of the two maps (built for the gather radius in use)
     DevScene scene{};
     Workspace ws[RT_STREAMS];
@@ -182,7 +186,7 @@ struct DeviceState {
     void release()
     {
         for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &box4, &grid, &cpa, &cpb, &cbox4, &cgrid,
-                          &raw_photons, &cell_rk2, &ccell_rk2, &cell_start, &ccell_start, &stats, &t_in}) b->release();
+                          &raw_photons, &bvh_spill, &cell_rk2, &ccell_rk2, &cell_start, &ccell_start, &stats, &t_in}) b->release();
         for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
         for (Workspace &w : ws) w.release();
         for (int k = 0; k < 6; k++) t_out[k].release();
@@ -212,6 +216,11 @@ struct rt_scene {
     // Non-empty photons_raw takes precedence over data.photons; rt_scene_set_photons clears it.
     std::vector<rt_photon> photons_raw;
     std::vector<uint32_t> photons_skip;
+    // A map made by the photon pass (rt_scene_generate_photons, rt_render_begin) is DERIVED from the scene: whatever it was
+    // traced through (nodes, meshes, materials, lights, another XML) changing drops it, and rt_render_begin makes a new one when
+    // there is none or when the render asks for another count / bounce limit / seed -- the reference runs generatePhotonMap() on
+    // every BeginRender (FIN/main.cpp:984-990).  A map handed over with rt_scene_set_photons is the caller's: it stays.
+    struct Generated { bool valid = false; uint32_t count = 0; int bounce = 0; uint32_t seed = 0; } gen;
     std::string photon_dump;            // where rt_render_begin's photon pass writes its .dat ("" = nowhere)
     std::mutex gen_mu;                  // jobs started together on several devices: ONE of them runs the photon pass, the others wait for it
     std::mutex mu;
@@ -221,6 +230,12 @@ struct rt_scene {
     void invalidate(bool scene, bool photons, bool caustic = false)
     {
         for (DeviceState *d : devs) { if (scene) d->scene_valid = false; if (photons) d->photons_valid = false; if (caustic) d->caustic_valid = false; }
+    }
+    // geometry, materials or lights changed (caller holds mu): re-upload, and a generated photon map is no longer this scene's
+    void geometry_changed()
+    {
+        if (gen.valid) { photons_raw.clear(); photons_skip.clear(); data.photons.clear(); gen.valid = false; invalidate(true, true); }
+        else invalidate(true, false);
     }
 };
 
@@ -281,7 +296,7 @@ extern "C" rt_status rt_scene_set_nodes(rt_scene *s, const rt_node *nodes, int32
     }
     std::lock_guard<std::mutex> lk(s->mu);
     s->data.nodes.assign(nodes, nodes + n);
-    s->invalidate(true, false);
+    s->geometry_changed();
     return RT_OK;
 }
 
@@ -306,7 +321,7 @@ extern "C" rt_status rt_scene_set_mesh(rt_scene *s, int32_t mesh, const float *v
     m.vn.assign(vn, vn + 3 * (size_t)nvn); m.fn.assign(fn, fn + 3 * (size_t)nf);
     m.nodes.assign(nodes, nodes + nnodes); m.elements.assign(elements, elements + nf);
     m.vt.clear(); m.ft.clear();
-    s->invalidate(true, false);
+    s->geometry_changed();
     return RT_OK;
 }
 
@@ -344,7 +359,7 @@ extern "C" rt_status rt_scene_set_materials(rt_scene *s, const rt_blinn *m, int3
     if (n < 0 || (n > 0 && !m)) return fail(RT_ERR_ARG, "rt_scene_set_materials: bad array");
     std::lock_guard<std::mutex> lk(s->mu);
     s->data.materials.assign(m, m + n);
-    s->invalidate(true, false);
+    s->geometry_changed();
     return RT_OK;
 }
 
@@ -357,7 +372,7 @@ extern "C" rt_status rt_scene_set_lights(rt_scene *s, const rt_light *l, int32_t
         if (l[i].type < RT_LIGHT_AMBIENT || l[i].type > RT_LIGHT_POINT) return fail(RT_ERR_ARG, "rt_scene_set_lights: light %d has unknown type", i);
     std::lock_guard<std::mutex> lk(s->mu);
     s->data.lights.assign(l, l + n);
-    s->invalidate(true, false);
+    s->geometry_changed();
     return RT_OK;
 }
 
@@ -488,7 +503,7 @@ extern "C" rt_status rt_scene_set_photons(rt_scene *s, const rt_photon *photons,
     if (st) return st;
     if (n_stored > 0 && !photons) return fail(RT_ERR_ARG, "rt_scene_set_photons: photons is NULL");
     std::lock_guard<std::mutex> lk(s->mu);
-    s->photons_raw.clear(); s->photons_skip.clear();
+    s->photons_raw.clear(); s->photons_skip.clear(); s->gen.valid = false;
     if (n_stored == 0) s->data.photons.clear();
     else s->data.photons.assign(photons, photons + (size_t)n_stored + 1);
     s->invalidate(false, true);
@@ -518,9 +533,9 @@ extern "C" rt_status rt_scene_load_xml(rt_scene *s, const char *path)
     rt::SceneData d;
     if (!rt::Lower(graph, d, &err)) return fail(RT_ERR_ARG, "rt_scene_load_xml(%s): %s", path, err.c_str());
     std::lock_guard<std::mutex> lk(s->mu);
-    d.photons = s->data.photons;
+    if (!s->gen.valid) d.photons = s->data.photons;      // a map the caller set stays; a generated one belonged to the old scene
     s->data = std::move(d);
-    s->invalidate(true, false);
+    s->geometry_changed();
     return RT_OK;
 }
 
@@ -648,6 +663,7 @@ extern "C" rt_status rt_photon_unreachable(const rt_photon *in, uint32_t n, uint
 }
 
 // ---- lowering to the device ---------------------------------------------------------------------------
+static const size_t SPILL_BYTES = (size_t)RT_SPILL_BLOCKS * RT_BLOCK * RT_BVH_SPILL * 4;     // DevScene::bvh_spill / DevWork::bvh_spill
 static DeviceState *device_state(rt_scene *s, int device)
 {
     for (DeviceState *d : s->devs) if (d->device == device) return d;
@@ -657,7 +673,68 @@ static DeviceState *device_state(rt_scene *s, int device)
     return d;
 }
 
-// reference node tree -> device BVH: children's boxes live in the parent, triangles in leaf order
+// reference node tree -> device BVH: children's boxes live in the parent, triangles in leaf order.  stack_need = the most
+// traversal-stack entries a ray can have pending in this tree (near-first, the other hit children pushed).
+#if RT_BVH_WIDTH == 4
+// Four-wide: a device node stands for a binary node of the reference's tree (cyBVH.h:76-106; root id 1, children adjacent)
+// and holds its GRANDCHILDREN -- a child that is a leaf stays one child -- in the reference's child1-before-child2 order.
+// Same boxes, same leaves, same triangle order inside a leaf: the traversal tests the same triangles as on the binary tree.
+static rt_status convert_bvh(const rt::MeshData &m, std::vector<DevBvhNode> &out, uint32_t &root_ref, int &stack_need)
+{
+    struct Rec {
+        const rt::MeshData &m; std::vector<DevBvhNode> &out; int max_levels = 0; bool bad = false; size_t visited = 0;
+        static uint32_t LEAFREF(uint32_t off, uint32_t cnt) { return 0x80000000u | ((cnt - 1) << 28) | (off & 0x0FFFFFFFu); }
+        bool ok_id(uint32_t id) const { return id != 0 && id < m.nodes.size(); }
+        bool is_leaf(uint32_t id) const { return (m.nodes[id].data & 0x80000000u) != 0; }
+        uint32_t leaf_ref(uint32_t id)
+        {
+            const rt_bvh_node &n = m.nodes[id];
+            const uint32_t cnt = ((n.data >> 28) & 7u) + 1, off = n.data & 0x0FFFFFFFu;
+            if ((size_t)off + cnt > m.elements.size()) { bad = true; return LEAFREF(0, 1); }
+            return LEAFREF(off, cnt);
+        }
+        // children of binary node `id` (internal): its two child ids, or bad
+        bool kids(uint32_t id, uint32_t k[2])
+        {
+            const uint32_t c = m.nodes[id].data & 0x7FFFFFFFu;
+            if (c == 0 || (size_t)c + 1 >= m.nodes.size()) { bad = true; return false; }
+            k[0] = c; k[1] = c + 1;
+            return true;
+        }
+        uint32_t go(uint32_t id, int level)          // id: an INTERNAL binary node; returns the device node index
+        {
+            // a well-formed tree visits every node once: more visits than input nodes means a cycle
+            if (bad || !ok_id(id) || level > 256 || ++visited > m.nodes.size()) { bad = true; return 0; }
+            if (level > max_levels) max_levels = level;
+            const uint32_t me = (uint32_t)out.size();
+            out.push_back(DevBvhNode{});
+            uint32_t ch[4]; int n = 0;
+            uint32_t k[2];
+            if (!kids(id, k)) return 0;
+            for (int i = 0; i < 2; i++) {
+                if (!ok_id(k[i])) { bad = true; return 0; }
+                if (is_leaf(k[i])) ch[n++] = k[i];
+                else { uint32_t g[2]; if (!kids(k[i], g)) return 0; if (!ok_id(g[0]) || !ok_id(g[1])) { bad = true; return 0; } ch[n++] = g[0]; ch[n++] = g[1]; }
+            }
+            DevBvhNode d;
+            memset(&d, 0, sizeof d);
+            const float nan = std::nanf("");
+            for (int i = 0; i < 4; i++) {
+                for (int a = 0; a < 3; a++) { d.lo[a][i] = i < n ? m.nodes[ch[i]].box[a] : nan; d.hi[a][i] = i < n ? m.nodes[ch[i]].box[a + 3] : nan; }
+                d.c[i] = i < n ? (is_leaf(ch[i]) ? leaf_ref(ch[i]) : go(ch[i], level + 1)) : LEAFREF(0, 1);
+            }
+            out[me] = d;
+            return me;
+        }
+    } r{m, out};
+    if (m.nodes.size() < 2) return fail(RT_ERR_ARG, "mesh BVH is empty");
+    if (r.is_leaf(1)) { root_ref = r.leaf_ref(1); stack_need = 0; }
+    else { root_ref = r.go(1, 1); stack_need = 3 * r.max_levels; }
+    if (r.bad) return fail(RT_ERR_ARG, "mesh BVH is malformed (child/element index out of range)");
+    if (out.size() >= 0x10000000u) return fail(RT_ERR_LIMIT, "mesh BVH too large");
+    return RT_OK;
+}
+#else
 static rt_status convert_bvh(const rt::MeshData &m, std::vector<DevBvhNode> &out, uint32_t &root_ref, int &depth_out)
 {
     struct Rec {
@@ -692,6 +769,7 @@ static rt_status convert_bvh(const rt::MeshData &m, std::vector<DevBvhNode> &out
     if (r.bad) return fail(RT_ERR_ARG, "mesh BVH is malformed (child/element index out of range)");
     return RT_OK;
 }
+#endif
 
 static rt_status upload_scene(rt_scene *s, DeviceState *D)
 {
@@ -777,7 +855,8 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
         uint32_t root_ref = 0;
         int depth = 0;
         if ((st = convert_bvh(m, bn, root_ref, depth))) return st;
-        if (depth > RT_BVH_STACK) return fail(RT_ERR_LIMIT, "mesh %zu: BVH depth %d exceeds the device traversal stack (%d)", mi, depth, RT_BVH_STACK);
+        // (the smallest LDS stack of any tracing kernel is 24 entries; RT_BVH_SPILL more per thread wait in HBM: spill buffers below)
+        if (depth > 24 + RT_BVH_SPILL) return fail(RT_ERR_LIMIT, "mesh %zu: the BVH can need %d traversal-stack entries, the device provides %d", mi, depth, 24 + RT_BVH_SPILL);
         max_depth = std::max(max_depth, depth);
         const size_t nf = m.f.size() / 3;
         std::vector<DevTri> tris(nf);
@@ -840,6 +919,11 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
     S.env_map = sd.env_map; S.bg_map = sd.bg_map;
     S.use_uvw = sd.material_maps.empty() ? 0 : 1;
     S.max_bvh_depth = max_depth;
+    S.bvh_spill = nullptr;
+    if (max_depth > 24) {
+        if ((st = D->bvh_spill.ensure(SPILL_BYTES))) return st;
+        S.bvh_spill = (uint32_t *)D->bvh_spill.p;
+    }
     S.stochastic = 0;
     for (const rt_light &l : sd.lights) if (l.type == RT_LIGHT_POINT && l.size != 0) S.stochastic = 1;
     for (const rt_blinn &m : sd.materials) if (m.reflection_glossiness != 0 || m.refraction_glossiness != 0) S.stochastic = 1;
@@ -859,10 +943,15 @@ static rt_status build_photon_structure(DeviceState *D, bool caustic, const rt_p
 {
     using clk = std::chrono::steady_clock;
     DevPhotonMap &pm = caustic ? D->scene.cm : D->scene.pm;
+    bool &valid = caustic ? D->caustic_valid : D->photons_valid;
+    // nothing is published before the build and its final synchronisation have succeeded: a failure leaves the device WITHOUT a
+    // valid map, so the next render tries again (and fails as loudly) instead of rendering without global illumination
     memset(&pm, 0, sizeof pm);
-    (caustic ? D->caustic_valid : D->photons_valid) = true;
+    valid = false;
+    struct TempBuf : DevBuf { ~TempBuf() { release(); } };      // released on every path out of this function
     DevBuf &b_pa = caustic ? D->cpa : D->pa, &b_pb = caustic ? D->cpb : D->pb, &b_box = caustic ? D->cbox4 : D->box4, &b_grid = caustic ? D->cgrid : D->grid;
-    if (n_src <= n_skip) return RT_OK;
+    if (n_src <= n_skip) { valid = true; return RT_OK; }
+    if (n_skip > 8) return fail(RT_ERR_LIMIT, "photon structure: %u photons to leave out, the device copy takes at most 8 (rt::UnreachablePhotons yields at most 4)", n_skip);
     const uint32_t n = n_src - n_skip;
     uint32_t n_leaves = 1;
     while ((size_t)n_leaves * RT_LEAF_SUBS * RT_SUB_PHOTONS < n) n_leaves <<= 1;
@@ -873,7 +962,7 @@ static rt_status build_photon_structure(DeviceState *D, bool caustic, const rt_p
     rt_status st;
     hipStream_t stream = D->stream;
     const auto t0 = clk::now();
-    DevBuf staged, compacted, scratch;
+    TempBuf staged, compacted, scratch;
     const rt_photon *ph = src_dev;
     if (!ph) {
         if ((st = staged.ensure((size_t)n_src * sizeof(rt_photon)))) return st;
@@ -881,7 +970,7 @@ static rt_status build_photon_structure(DeviceState *D, bool caustic, const rt_p
         ph = (const rt_photon *)staged.p;
     }
     if (n_skip) {
-        if ((st = compacted.ensure((size_t)n * sizeof(rt_photon)))) { staged.release(); return st; }
+        if ((st = compacted.ensure((size_t)n * sizeof(rt_photon)))) return st;
         rtk_photon_copy_skipping(stream, ph, n_src, skip, n_skip, (rt_photon *)compacted.p);
         ph = (const rt_photon *)compacted.p;
     }
@@ -891,24 +980,28 @@ static rt_status build_photon_structure(DeviceState *D, bool caustic, const rt_p
     const size_t slots = ((size_t)n_sub + 1) * RT_SUB_PHOTONS;
     const size_t sbytes = rtk_photon_structure_scratch(n, n_sub);
     if ((st = b_pa.ensure(slots * sizeof(float4))) || (st = b_pb.ensure(slots * sizeof(float4))) || (st = b_box.ensure((size_t)4 * n_sub * sizeof(float4))) ||
-        (st = b_grid.ensure((size_t)64 * 64 * 64 * 4)) || (st = scratch.ensure(sbytes))) { staged.release(); compacted.release(); scratch.release(); return st; }
+        (st = b_grid.ensure((size_t)64 * 64 * 64 * 4)) || (st = scratch.ensure(sbytes))) return st;
     PhotonGridOut g;
     const hipError_t e = rtk_photon_structure(stream, ph, n, n_sub, (float4 *)b_pa.p, (float4 *)b_pb.p, (float4 *)b_box.p, (uint32_t *)b_grid.p, &g, scratch.p, sbytes);
     hipError_t e2 = hipStreamSynchronize(stream);
-    staged.release(); compacted.release(); scratch.release();
     if (e != hipSuccess || e2 != hipSuccess) return fail(RT_ERR_DEVICE, "photon structure build failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-    pm.pa = (const float4 *)b_pa.p; pm.pb = (const float4 *)b_pb.p;
-    pm.tbox = (const float4 *)b_box.p; pm.sbox = (const float4 *)b_box.p + 2 * (size_t)n_sub;
-    pm.n_leaves = n_leaves; pm.n_photons = n;
-    pm.grid = (const uint32_t *)b_grid.p;
-    for (int a = 0; a < 3; a++) { pm.grid_min[a] = g.min[a]; pm.grid_dim[a] = g.dim[a]; }
-    pm.cell = g.cell; pm.inv_cell = 1.0f / g.cell;
+    DevPhotonMap built;
+    memset(&built, 0, sizeof built);
+    built.pa = (const float4 *)b_pa.p; built.pb = (const float4 *)b_pb.p;
+    built.tbox = (const float4 *)b_box.p; built.sbox = (const float4 *)b_box.p + 2 * (size_t)n_sub;
+    built.n_leaves = n_leaves; built.n_photons = n;
+    built.grid = (const uint32_t *)b_grid.p;
+    for (int a = 0; a < 3; a++) { built.grid_min[a] = g.min[a]; built.grid_dim[a] = g.dim[a]; }
+    built.cell = g.cell; built.inv_cell = 1.0f / g.cell;
     {
         DevBuf &b_rk = caustic ? D->ccell_rk2 : D->cell_rk2;
         if ((st = b_rk.ensure((size_t)64 * 64 * 64 * 4))) return st;
         HIP_TRY(hipMemsetAsync(b_rk.p, 0, (size_t)64 * 64 * 64 * 4, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    pm = built;
+    valid = true;
+    (caustic ? D->rk2_k_c : D->rk2_k) = 0;          // the hint table is empty: no gather parameters recorded yet
     const auto t2 = clk::now();
     if (ms_upload) *ms_upload += std::chrono::duration<double, std::milli>(t1 - t0).count();
     if (ms_build) *ms_build += std::chrono::duration<double, std::milli>(t2 - t1).count();
@@ -1011,6 +1104,7 @@ static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int 
     for (int k = 0; k < 3; k++) if ((st = w.pq[k].ensure((size_t)pq_cap * 16))) return st;
     if (caustic) for (int k = 0; k < 3; k++) if ((st = w.cq[k].ensure((size_t)pq_cap * 16))) return st;
     if ((st = w.counts.ensure(CNT_TOTAL * 4))) return st;
+    if (D->scene.max_bvh_depth > 24 && (st = w.bvh_spill.ensure(SPILL_BYTES))) return st;
     if ((st = w.pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
     if (!D->stats.p) { if ((st = D->stats.ensure(ST_COUNT * 8))) return st; }
     if (slot > 0 && !w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
@@ -1030,6 +1124,7 @@ static DevWork make_work(DeviceState *D, int slot)
     W.pq.qa = (float4 *)w.pq[0].p; W.pq.qb = (float4 *)w.pq[1].p; W.pq.qc = (float4 *)w.pq[2].p; W.pq.cap = w.pq_cap;
     W.cq.qa = (float4 *)w.cq[0].p; W.cq.qb = (float4 *)w.cq[1].p; W.cq.qc = (float4 *)w.cq[2].p; W.cq.cap = w.cq[0].p ? w.pq_cap : 0;
     W.counts = (uint32_t *)w.counts.p; W.pixel_list = (uint32_t *)w.pixel_list.p;
+    W.bvh_spill = D->scene.max_bvh_depth > 24 ? (uint32_t *)w.bvh_spill.p : nullptr;
     W.stats = (unsigned long long *)D->stats.p;
     return W;
 }
@@ -1098,9 +1193,17 @@ static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const 
 
 // DevPhotonMap::cell_start for the radius the gather is about to use: built on first use and again when a larger radius comes
 // (a table built for a radius serves every smaller one), on the stream the gather will run on
-static rt_status ensure_cell_start(DeviceState *D, bool caustic, float radius, hipStream_t st)
+static rt_status ensure_cell_start(DeviceState *D, bool caustic, int k, float radius, hipStream_t st)
 {
     DevPhotonMap &pm = caustic ? D->scene.cm : D->scene.pm;
+    {
+        // the per-cell k-th distances (DeviceState::cell_rk2) are hints of ONE gather configuration: what queries with another k
+        // or radius left there is dropped, so that it cannot steer this render's choice between the (exact) gather paths
+        int &hk = caustic ? D->rk2_k_c : D->rk2_k; float &hr = caustic ? D->rk2_radius_c : D->rk2_radius;
+        DevBuf &b_rk = caustic ? D->ccell_rk2 : D->cell_rk2;
+        if (b_rk.p && hk != 0 && (hk != k || hr != radius)) HIP_TRY(hipMemsetAsync(b_rk.p, 0, (size_t)64 * 64 * 64 * 4, st));
+        hk = k; hr = radius;
+    }
     if (pm.n_leaves < 2 || (pm.cell_start && radius <= pm.start_radius)) return RT_OK;
     DevBuf &b = caustic ? D->ccell_start : D->cell_start;
     rt_status s = b.ensure((size_t)64 * 64 * 64 * 4);
@@ -1118,6 +1221,7 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
                               int max_sample, int mode, const float *rays_dev)
 {
     const int max_blocks = 256 * 5;
+    static_assert(256 * 5 <= RT_SPILL_BLOCKS, "DevScene::bvh_spill is sized for RT_SPILL_BLOCKS workgroups");
     auto mark = [&](int cls) -> rt_status {
         if (!tm) return RT_OK;
         hipEvent_t e;
@@ -1143,13 +1247,13 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
         rtk_launch_bounce(st, D->scene, W, P, W.rq[level & 1], W.rq[(level + 1) & 1], W.counts + level + 1, level, max_blocks);
     if ((s = mark(1))) return s;
     rt_status cs;
-    if ((cs = ensure_cell_start(D, false, P.knn_radius, st))) return cs;
+    if ((cs = ensure_cell_start(D, false, P.knn_k, P.knn_radius, st))) return cs;
     if (D->scene.pm.n_leaves) {
         rtk_launch_gather(st, D->scene.pm, W.pq.qa, W.pq.qb, W.pq.qc, W.counts + CNT_PHOTONQ, W.pq.cap, P.knn_k, P.knn_radius,
                           W.sample_rgb, nullptr, nullptr, 0, W.stats, GATHER_BLOCKS, W.counts + CNT_GATHER_NEXT, (float *)D->cell_rk2.p);
         if ((s = mark(2))) return s;
     }
-    if (D->scene.cm.n_leaves && P.caustic_k > 0 && W.cq.cap && (cs = ensure_cell_start(D, true, P.caustic_radius, st))) return cs;
+    if (D->scene.cm.n_leaves && P.caustic_k > 0 && W.cq.cap && (cs = ensure_cell_start(D, true, P.caustic_k, P.caustic_radius, st))) return cs;
     if (D->scene.cm.n_leaves && P.caustic_k > 0 && W.cq.cap) {
         // the P13-family models queued their caustic lookups separately: same kernel on the second map
         rtk_launch_gather(st, D->scene.cm, W.cq.qa, W.cq.qb, W.cq.qc, W.counts + CNT_CAUSTICQ, W.cq.cap, P.caustic_k, P.caustic_radius,
@@ -1249,7 +1353,9 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
             // ungated reflection / refraction pairs of the P13-family Shade, which double level by level inside glass
             // (P13/main.cpp:633-751: measured 2.5 rays per sample on the fullest level of a Cornell chunk that holds the glass
             // sphere, bounce 8) -- four per sample on top of the hemisphere rays, 640 B per sample of queue memory
-            const bool wf = (p->shade_model == RT_SHADE_FIN || p->shade_model == RT_SHADE_P13) && getenv("RT_TRACER") == nullptr;     // (P12 through k_wavefront keeps the per-level figure: its overflow is scene-dependent)
+            // (the kernels' own predicate: a scene k_wavefront does not take -- a BVH beyond its traversal stack, RT_TRACER=levels -- goes
+            // through the per-level kernels and gets their figure; P12 through k_wavefront keeps the per-level figure too: its overflow is scene-dependent)
+            const bool wf = (p->shade_model == RT_SHADE_FIN || p->shade_model == RT_SHADE_P13) && rtk_wavefront_usable(D->scene, *p);
             ray_factor = wf ? 1.0 : (p->shade_model == RT_SHADE_P12 ? (double)std::max(p->hemisphere_sample, 1) + 3.0 : 4.0);
             query_factor = 0.5;
         }
@@ -1309,8 +1415,8 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         HIP_TRY(hipMemsetAsync(Ws[0].stats + ST_PEAK_RAYS, 0, 16, stream));
     }
     // the gathers' start tables are built on `stream` before the slots fork from it
-    if ((st = ensure_cell_start(D, false, p->knn_radius, stream))) return st;
-    if (use_caustic && (st = ensure_cell_start(D, true, p->caustic_radius, stream))) return st;
+    if ((st = ensure_cell_start(D, false, p->knn_k, p->knn_radius, stream))) return st;
+    if (use_caustic && (st = ensure_cell_start(D, true, p->caustic_k, p->caustic_radius, stream))) return st;
     // slot 0 runs on `stream` itself; the other slots' streams start after everything already queued on
     // `stream` (fork) and `stream` waits for them at the end (join), so the call keeps stream-order semantics
     auto slot_stream = [&](int slot) { return slot == 0 ? stream : D->ws[slot].stream; };
@@ -1601,7 +1707,13 @@ extern "C" rt_status rt_render_begin(rt_scene *s, const rt_camera *cam, const rt
                 std::lock_guard<std::mutex> gen(s->gen_mu);         // one job per device may have been started: the first one generates
                 bool have_map, have_source = false;
                 std::string dump;
-                { std::lock_guard<std::mutex> lk(s->mu); have_map = s->photon_count() != 0; dump = s->photon_dump; }
+                {
+                    std::lock_guard<std::mutex> lk(s->mu);
+                    // a generated map serves only the parameters it was generated with (see rt_scene::gen)
+                    const bool stale = s->gen.valid && (s->gen.count != (uint32_t)pv.photon_count || s->gen.bounce != pv.photon_bounce || s->gen.seed != pv.seed);
+                    have_map = s->photon_count() != 0 && !stale;
+                    dump = s->photon_dump;
+                }
                 for (const rt_light &l : s->data.lights) if (l.type == RT_LIGHT_POINT) have_source = true;
                 if (!have_map && have_source && !job->stop.load()) {
                     const rt_status g = generate_photons(s, device, (uint32_t)pv.photon_count, pv.photon_bounce, pv.seed, dump.empty() ? nullptr : dump.c_str(),
@@ -1714,7 +1826,7 @@ extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, 
     if ((st = D->t_out[3].ensure((size_t)n * 12))) return st;
     if ((st = D->t_out[4].ensure((size_t)n * 12))) return st;
     if ((st = D->t_in.upload(cnt, sizeof cnt))) return st;
-    if ((st = ensure_cell_start(D, false, radius, D->stream))) return st;
+    if ((st = ensure_cell_start(D, false, k, radius, D->stream))) return st;
     rtk_launch_gather(D->stream, D->scene.pm, (const float4 *)D->t_out[0].p, (const float4 *)D->t_out[1].p, (const float4 *)D->t_out[2].p,
                       (const uint32_t *)D->t_in.p, cnt[0], k, radius, nullptr, (float *)D->t_out[3].p, (float *)D->t_out[4].p, 1, nullptr, GATHER_BLOCKS,
                       (uint32_t *)D->t_in.p + 1, nullptr);
@@ -1786,6 +1898,7 @@ static rt_status photon_pass_device(rt_scene *s, DeviceState *D, uint32_t max_co
     if (!have_source) return fail(RT_ERR_STATE, "%s: the scene has no photon source (point light)", who);
     rt_status st;
     const uint32_t batch = 1u << 18;
+    static_assert((1u << 18) / RT_BLOCK <= RT_SPILL_BLOCKS, "DevScene::bvh_spill is sized for RT_SPILL_BLOCKS workgroups");
     const uint32_t out_cap = max_count + 8 + 1;                 // index 0 unused, up to 7 photons of overshoot
     if ((st = D->t_out[0].ensure((size_t)batch * 8 * 9 * 4))) return st;
     if ((st = D->t_out[1].ensure((size_t)batch * 4))) return st;
@@ -1894,6 +2007,7 @@ static rt_status generate_photons(rt_scene *s, int device, uint32_t max_photons,
         s->data.photons.clear();
         s->photons_raw.swap(raw);
         s->photons_skip.swap(skip);
+        s->gen.valid = true; s->gen.count = max_photons; s->gen.bounce = photon_bounce; s->gen.seed = seed;
         for (DeviceState *d : s->devs) if (d != D) d->photons_valid = false;
     }
     T.total = ms(t_begin, clk::now());

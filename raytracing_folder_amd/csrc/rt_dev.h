@@ -58,12 +58,31 @@ struct DevObject {
 };
 static_assert(sizeof(DevObject) == 128, "one object = two 64-byte scalar loads");
 
+#ifndef RT_BVH_WIDTH
+#define RT_BVH_WIDTH 4           // children per device BVH node: 4 = two levels of the reference's binary tree per visit (128-byte nodes); 2 = the binary tree as it is (64-byte nodes; A/B)
+#endif
+#if RT_BVH_WIDTH == 4
+// 128 bytes: the boxes of up to four children, one axis after the other (lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4]: six
+// 16-byte loads), and their refs.  Collapsed from the reference's binary tree (cyBVH.h:76-106) on the host: a node's children
+// are the grandchildren of the binary node it stands for (a child that is a leaf stays one child), in the reference's
+// child1-before-child2 order.  An unused child has NaN bounds (never entered).  One visit = ONE dependent read for two levels.
+struct DevBvhNode {
+    float lo[3][4], hi[3][4];
+    uint32_t c[4];               // bit31: leaf (bits28-30 count-1, bits0-27 first triangle slot); else the index of a DevBvhNode
+    uint32_t pad[4];
+};
+static_assert(sizeof(DevBvhNode) == 128, "one visit = one 128-byte record");
+#else
 struct DevBvhNode {              // 64 bytes
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
     uint32_t c0, c1;             // bit31: leaf (bits28-30 count-1, bits0-27 first triangle slot)
     uint32_t pad[2];
 };
+#endif
+#define RT_BVH_SPILL 16          // traversal-stack entries per thread beyond the kernel's LDS stack, in HBM (DevScene::bvh_spill): touched only by a
+                                 // traversal deeper than the LDS stack (a four-wide node leaves up to three entries per level)
+#define RT_SPILL_BLOCKS 1280     // workgroups the spill buffer is sized for (every tracing launch stays within it)
 
 struct DevTri { float A[3], B[3], C[3], N[3]; };   // 48 bytes
 
@@ -115,7 +134,8 @@ struct DevScene {
     const rt_texmap *material_maps;          // 2 per material, or NULL
     rt_texmap env_map, bg_map;
     int32_t use_uvw;
-    int32_t max_bvh_depth;       // deepest mesh BVH (levels): which tracer kernels' traversal stacks it fits
+    int32_t max_bvh_depth;       // traversal-stack entries the deepest mesh BVH can need (binary tree: its depth; four-wide: 3 per level): which tracer kernels' stacks it fits
+    uint32_t *bvh_spill;         // [RT_SPILL_BLOCKS * RT_BLOCK][RT_BVH_SPILL]: stack entries beyond a kernel's LDS stack; set per launch (NULL: the LDS stack always suffices)
     int32_t stochastic;          // some light has a size or some material a glossy reflection/refraction: shading draws random numbers
 };
 
@@ -199,6 +219,7 @@ struct DevWork {
     uint32_t *counts;         // see the CNT_* indices below
     uint32_t *pixel_list;     // pixels (chunk-local) that take the second sample batch
     unsigned long long *stats;
+    uint32_t *bvh_spill;      // DevScene::bvh_spill of this working set's launches
 };
 #define CNT_PHOTONQ 16
 #define CNT_GATHER_NEXT 17     // work counters of k_gather, one per XCD (8): query batches handed out so far from each segment

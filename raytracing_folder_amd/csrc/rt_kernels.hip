@@ -76,6 +76,9 @@
 #else
 #define RT_FP_CONTRACT
 #endif
+#ifndef RT_WF_PERWAVE
+#define RT_WF_PERWAVE 1        // 1: for the P12 model every wave of k_wavefront runs its own rounds on its own part of the LDS ray stack (no workgroup barriers); 0: the four waves always share stack and rounds
+#endif
 #define RT_SUBS_PER_STEP (64 / RT_SUB_PHOTONS)                  // sub-leaves a wavefront examines per step
 #define RT_SUBLIST_CAP (RT_LEAFLIST_CAP * RT_LEAF_SUBS)         // sub-leaf ids of one query
 
@@ -107,7 +110,7 @@ __device__ __forceinline__ float gray(V3 c) { return (c.x + c.y + c.z) / 3.0f; }
 #define RMAX(a, b) ((a) > (b) ? (a) : (b))     // the reference's macros, scene.h:48-54
 #define RMIN(a, b) ((a) < (b) ? (a) : (b))
 
-struct Counters { uint32_t inst, nodes, tris, shadow; };
+struct Counters { uint32_t inst, nodes, tris, shadow; uint32_t occ; };     // occ: 1 + the object that occluded this lane's last shadow ray (0: none)
 
 // Halton, FIN/include/scene.h:131-140
 __device__ __forceinline__ float halton(int index, int base)
@@ -285,11 +288,37 @@ __device__ __forceinline__ rt_light cld_light(const rt_light *p)
 }
 __device__ __forceinline__ M9 cld9(const float *p) { M9 r; for (int i = 0; i < 9; i++) r.m[i] = cld(p + i); return r; }
 
+// A thread's BVH traversal stack: `cap` entries in LDS (entry i of this thread at lds[i * RT_BLOCK]) and RT_BVH_SPILL more in
+// HBM behind them (spill, this thread's own 64 bytes; NULL when the scene's trees cannot outgrow the LDS part -- the host
+// checks DevScene::max_bvh_depth against cap + RT_BVH_SPILL).  The spill part is touched only by a traversal that is
+// deeper than the LDS part: a four-wide node can leave three entries per level.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;      // the LDS part is addressed as LDS (ds_read / ds_write), never through flat instructions
+struct BvhStack { lds_u32 *lds; uint32_t *spill; uint32_t cap; };
+__device__ __forceinline__ BvhStack bvh_stack(uint32_t *lds_base, uint32_t cap, uint32_t *spill_base)
+{
+    BvhStack st;
+    st.lds = (lds_u32 *)lds_base + threadIdx.x; st.cap = cap;
+    st.spill = spill_base ? spill_base + ((size_t)blockIdx.x * RT_BLOCK + threadIdx.x) * RT_BVH_SPILL : nullptr;
+    return st;
+}
+__device__ __forceinline__ void bvh_push(const BvhStack &st, uint32_t &sp, uint32_t v)
+{
+    if (sp < st.cap) st.lds[sp * RT_BLOCK] = v;
+    else if (st.spill && sp < st.cap + RT_BVH_SPILL) st.spill[sp - st.cap] = v;
+    sp++;
+}
+__device__ __forceinline__ uint32_t bvh_pop(const BvhStack &st, uint32_t &sp)
+{
+    --sp;
+    if (sp < st.cap) return st.lds[sp * RT_BLOCK];
+    return st.spill[sp - st.cap];
+}
+
 // TriObj::IntersectRay -> TraceBVHNode (FIN/include/objects.h:127-133, 271-302) as an iterative,
 // near-first traversal with a per-lane stack in LDS.  ANY: stop at the first accepted triangle.
 template <bool ANY, int MODEL>
 __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN, int &front,
-                         uint32_t *stack, Counters &cnt, V3 *uvw = nullptr)
+                         const BvhStack &stack, Counters &cnt, V3 *uvw = nullptr)
 {
     // the mesh record is the same for every lane: over the scalar cache (see cld), so that the array bases live in SGPRs
     DevMesh M;
@@ -299,7 +328,7 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     if (box_entry(M.root_box, M.root_box + 3, o, inv, z) > 2.0e30f) return false;
     uint32_t cur = M.root_ref;
-    int sp = 0;
+    uint32_t sp = 0;
     bool any = false;
     uint32_t best_slot = 0;
     V3 bc = mk(0, 0, 0);
@@ -311,6 +340,29 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
     const uint32_t DONE = 0xFFFFFFFFu;                  // has LEAF_BIT set: ends the inner loop
     while (cur != DONE) {
         while (!(cur & LEAF_BIT)) {
+#if RT_BVH_WIDTH == 4
+            // one 128-byte record = the boxes of four children (two levels of the reference's tree): six 16-byte loads of
+            // bounds, one of refs, issued together -- ONE dependent round trip where the binary tree takes two
+            const float4 *np = (const float4 *)(M.nodes + cur);
+            const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+            const uint4 cr = *(const uint4 *)(np + 6);
+            cnt.nodes++;
+            const float l0[3] = {lx.x, ly.x, lz.x}, h0[3] = {hx.x, hy.x, hz.x}, l1[3] = {lx.y, ly.y, lz.y}, h1[3] = {hx.y, hy.y, hz.y};
+            const float l2[3] = {lx.z, ly.z, lz.z}, h2[3] = {hx.z, hy.z, hz.z}, l3[3] = {lx.w, ly.w, lz.w}, h3[3] = {hx.w, hy.w, hz.w};
+            float e0 = box_entry(l0, h0, o, inv, z), e1 = box_entry(l1, h1, o, inv, z);
+            float e2 = box_entry(l2, h2, o, inv, z), e3 = box_entry(l3, h3, o, inv, z);      // an unused child's bounds are NaN: never entered
+            uint32_t c0 = cr.x, c1 = cr.y, c2 = cr.z, c3 = cr.w;
+            // nearest first: sort the four (entry distance, ref) pairs (misses carry 3e30 and end up last); equal distances keep
+            // the reference's child order
+#define RT_CSWAP(ea, ca, eb, cb) do { const bool s_ = (eb) < (ea); const float te_ = s_ ? (eb) : (ea); const uint32_t tc_ = s_ ? (cb) : (ca); \
+                                      (eb) = s_ ? (ea) : (eb); (cb) = s_ ? (ca) : (cb); (ea) = te_; (ca) = tc_; } while (0)
+            RT_CSWAP(e0, c0, e1, c1); RT_CSWAP(e2, c2, e3, c3); RT_CSWAP(e0, c0, e2, c2); RT_CSWAP(e1, c1, e3, c3); RT_CSWAP(e1, c1, e2, c2);
+#undef RT_CSWAP
+            if (e3 < 2.0e30f) bvh_push(stack, sp, c3);
+            if (e2 < 2.0e30f) bvh_push(stack, sp, c2);
+            if (e1 < 2.0e30f) bvh_push(stack, sp, c1);
+            cur = (e0 < 2.0e30f) ? c0 : (sp ? bvh_pop(stack, sp) : DONE);
+#else
             const DevBvhNode nd = M.nodes[cur];
             cnt.nodes++;
             const float e0 = box_entry(nd.lo0, nd.hi0, o, inv, z);
@@ -318,11 +370,12 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
             const bool h0 = e0 < 2.0e30f, h1 = e1 < 2.0e30f;
             if (h0 && h1) {
                 const bool first0 = e0 <= e1;
-                if (sp < RT_BVH_STACK) stack[(sp++) * RT_BLOCK] = first0 ? nd.c1 : nd.c0;
+                bvh_push(stack, sp, first0 ? nd.c1 : nd.c0);
                 cur = first0 ? nd.c0 : nd.c1;
             } else if (h0) cur = nd.c0;
             else if (h1) cur = nd.c1;
-            else cur = sp ? stack[(--sp) * RT_BLOCK] : DONE;
+            else cur = sp ? bvh_pop(stack, sp) : DONE;
+#endif
         }
         if (cur == DONE) break;
         const uint32_t count = ((cur >> 28) & 7u) + 1;
@@ -335,7 +388,7 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
             if (h) { any = true; best_slot = first + i; }
         }
         if (ANY && any) return true;
-        cur = sp ? stack[(--sp) * RT_BLOCK] : DONE;
+        cur = sp ? bvh_pop(stack, sp) : DONE;
     }
     if (!any) return false;
     // cyTriMesh::GetNormal = vn[fn0]*bc.x + vn[fn1]*bc.y + vn[fn2]*bc.z (cyTriMesh.h:167,191)
@@ -358,12 +411,12 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
 // ------------------------------------------------------------------------------------------------
 #ifdef RT_EXP_WF_TIME           /* tuning build: instance_visits = wave kilo-cycles in closest-hit traces (x64), bvh_nodes = in any-hit (shadow) traces, tris = in shade_path as a whole */
 template <bool ANY, int MODEL, bool TEX>
-__device__ bool trace_impl(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt);
+__device__ bool trace_impl(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, const BvhStack &stack, Counters &cnt);
 template <bool ANY, int MODEL, bool TEX = false>
-__device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt)
+__device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, const BvhStack &stack, Counters &cnt)
 {
     const unsigned long long t0 = __builtin_readcyclecounter();
-    Counters dummy = {0, 0, 0, 0};
+    Counters dummy = {0, 0, 0, 0, 0};
     const bool r = trace_impl<ANY, MODEL, TEX>(S, o, d, zinit, h, stack, dummy);
     const uint32_t dt = (uint32_t)((__builtin_readcyclecounter() - t0) >> 6);
     if (ANY) cnt.nodes += dt; else cnt.inst += dt;
@@ -374,7 +427,7 @@ template <bool ANY, int MODEL, bool TEX>
 #else
 template <bool ANY, int MODEL, bool TEX = false>
 #endif
-__device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32_t *stack, Counters &cnt)
+__device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, const BvhStack &stack, Counters &cnt)
 {
     float z = zinit;
     int best = -1, bfront = 1;
@@ -404,7 +457,13 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
     // reciprocal direction (in the root's coordinates) for the bounds cull only: approximate is fine, the
     // bounds are inflated
     const V3 winv = mk(__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y), __builtin_amdgcn_rcpf(d0.z));
-    for (int oi = 0; oi < S.n_objects; oi++) {
+    // any-hit queries: the object that occluded the last shadow ray of this wave is tried first (its neighbours' rays mostly end on
+    // the same occluder, and the first accepted hit ends a lane's query: the order of the objects does not change the answer)
+    int hint = -1;
+    if (ANY) { hint = __builtin_amdgcn_readfirstlane((int)cnt.occ) - 1; if (hint >= S.n_objects) hint = -1; }
+    for (int it = (hint >= 0 ? -1 : 0); it < S.n_objects; it++) {
+        const int oi = it < 0 ? hint : it;
+        if (it >= 0 && oi == hint) continue;
         const DevObject *obp = S.objects + oi;
         // Everything this iteration needs of the object comes from its one 128-byte record, fetched by two 64-byte scalar loads
         // issued back to back and waited for ONCE.  Written as inline assembly because the compiler, short of scalar registers
@@ -444,7 +503,7 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, uint32
         else if (ob_type == RT_OBJ_PLANE) hit = plane_hit(MODEL, lp, ldir, z, hp, hN, fr);
         else if (ob_type == RT_OBJ_MESH) hit = mesh_hit<ANY, MODEL>(S.meshes + ob_mesh, lp, ldir, z, hp, hN, fr, stack, cnt, (TEX && S.use_uvw) ? &uvw : nullptr);
         if (hit) {
-            if (ANY) return true;
+            if (ANY) { cnt.occ = (uint32_t)oi + 1u; return true; }
             best = oi; bp = hp; bN = hN; bfront = fr;
             if (TEX && S.use_uvw) {
                 if (ob_type == RT_OBJ_SPHERE)               // objects.h:49-51, atan2/asin in double
@@ -644,7 +703,7 @@ __device__ __forceinline__ V3 light_direction(const rt_light &l, V3 p)
 // 1e-14 < z < t_max).  With size == 0 all samples coincide and ONE query decides them.
 template <int MODEL>
 __device__ V3 illuminate(const DevScene &S, const rt_params &P, const rt_light &l, int li, V3 p, const RngCtx &rc,
-                         uint32_t *stack, Counters &cnt)
+                         const BvhStack &stack, Counters &cnt)
 {
     const V3 I = ld3(l.intensity);
     if (l.type == RT_LIGHT_AMBIENT) return I;
@@ -737,21 +796,55 @@ __device__ __forceinline__ void add_sample(const ShadeCtx &C, uint32_t slot, V3 
     else { atomicAdd(dst, c.x); atomicAdd(dst + 1, c.y); atomicAdd(dst + 2, c.z); }
 }
 
-template <bool SIDE = false>
+template <bool SIDE = false, bool TWO_ENDED = false>
 __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 d, V3 thr, V3 absorb,
                                          uint32_t slot, int bounce, uint32_t kind, uint32_t node, uint32_t sample,
                                          V3 side_dir = V3{0, 0, 0}, V3 side_K = V3{0, 0, 0}, uint32_t spec = 0, uint32_t mat = 0)
 {
     if (!SIDE && C.lds_count) {
-        // workgroup-local stack first (LDS atomic, one per wave); what does not fit goes to the global queue
-        const uint32_t at = wave_push(pred, C.lds_count);
-        if (pred && at < C.lds_cap) {
-            C.lds_a[at] = make_float4(o.x, o.y, o.z, d.x);
-            C.lds_b[at] = make_float4(d.y, d.z, thr.x, thr.y);
-            C.lds_c[at] = make_float4(thr.z, __uint_as_float(slot), __uint_as_float((uint32_t)bounce | (kind << 4) | (spec << 8) | (mat << 16)), __uint_as_float(node));
+        if constexpr (TWO_ENDED) {
+            // two stacks in one array, keyed by the kind of ray (side 0: reflection rays grow up from 0, side 1: refraction and hemisphere
+            // rays grow down from the top); ONE packed counter (low half: side 0, high half: side 1) so that an add sees both fills
+            const uint32_t side = kind == KIND_REFLECT ? 0u : 1u;
+            bool stored = false;
+            for (uint32_t sd = 0; sd < 2; sd++) {
+                const bool mine = pred && side == sd;
+                const unsigned long long mask = ballot64(mine);
+                if (!mask) continue;
+                const int lane = __lane_id();
+                const int leader = __ffsll((long long)mask) - 1;
+                const uint32_t n = (uint32_t)__popcll(mask), sh = 16u * sd;
+                uint32_t base = 0, room = 0;
+                if (lane == leader) {
+                    const uint32_t old = atomicAdd(C.lds_count, n << sh);
+                    base = (old >> sh) & 0xFFFFu;
+                    const uint32_t fill = (old & 0xFFFFu) + (old >> 16);
+                    room = fill >= C.lds_cap ? 0u : C.lds_cap - fill;
+                    if (room < n) atomicSub(C.lds_count, (n - room) << sh);      // only what was stored counts
+                }
+                base = __shfl(base, leader); room = __shfl(room, leader);
+                const uint32_t off = lanes_below(mask);
+                if (mine && off < room) {
+                    const uint32_t at = sd ? C.lds_cap - 1u - (base + off) : base + off;
+                    C.lds_a[at] = make_float4(o.x, o.y, o.z, d.x);
+                    C.lds_b[at] = make_float4(d.y, d.z, thr.x, thr.y);
+                    C.lds_c[at] = make_float4(thr.z, __uint_as_float(slot), __uint_as_float((uint32_t)bounce | (kind << 4) | (spec << 8) | (mat << 16)), __uint_as_float(node));
+                    stored = true;
+                }
+            }
+            pred = pred && !stored;
+            if (!__any(pred)) return;
+        } else {
+            // the wave's own stack first (LDS atomic, one per wave); what does not fit goes to the global queue
+            const uint32_t at = wave_push(pred, C.lds_count);
+            if (pred && at < C.lds_cap) {
+                C.lds_a[at] = make_float4(o.x, o.y, o.z, d.x);
+                C.lds_b[at] = make_float4(d.y, d.z, thr.x, thr.y);
+                C.lds_c[at] = make_float4(thr.z, __uint_as_float(slot), __uint_as_float((uint32_t)bounce | (kind << 4) | (spec << 8) | (mat << 16)), __uint_as_float(node));
+            }
+            pred = pred && at >= C.lds_cap;
+            if (!__any(pred)) return;
         }
-        pred = pred && at >= C.lds_cap;
-        if (!__any(pred)) return;
     }
     const uint32_t idx = wave_push(pred, C.qout_count);
     if (pred) {
@@ -801,7 +894,7 @@ struct ShadeOut {
 // MtlBlinn::Shade, FIN/main.cpp:516-708
 template <bool TEX>
 __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
-                          ShadeOut &o, uint32_t *stack, Counters &cnt)
+                          ShadeOut &o, const BvhStack &stack, Counters &cnt)
 {
     const rt_blinn &m = S.materials[S.node_material[h.node]];
     V3 color = ld3(m.emission);                                         // :517
@@ -873,7 +966,7 @@ __device__ void shade_fin(const DevScene &S, const rt_params &P, const Hit &h, V
 // child refraction*ra_ratio*exp(-absorption.r * z_child) (z_child = BIGFLOAT on a miss).
 template <int MODEL, bool TEX>
 __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
-                          ShadeOut &o, uint32_t *stack, Counters &cnt, uint32_t spec_in)
+                          ShadeOut &o, const BvhStack &stack, Counters &cnt, uint32_t spec_in)
 {
     constexpr bool p12 = MODEL == RT_SHADE_P12;
     const rt_blinn &m = S.materials[S.node_material[h.node]];
@@ -982,7 +1075,7 @@ __device__ void shade_p13(const DevScene &S, const rt_params &P, const Hit &h, V
 // rays start at the camera, so camera.pos is the ray origin); no children
 template <bool TEX>
 __device__ void shade_p3(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_o, const RngCtx &rc, ShadeOut &o,
-                         uint32_t *stack, Counters &cnt)
+                         const BvhStack &stack, Counters &cnt)
 {
     const rt_blinn &m = S.materials[S.node_material[h.node]];
     const V3 N = h.N, Pp = h.p;
@@ -1015,7 +1108,7 @@ __device__ void shade_p3(const DevScene &S, const rt_params &P, const Hit &h, V3
 // "side" ray and is spawned when the refraction ray reports a hit.  Misses add nothing (no environment).
 template <bool TEX>
 __device__ void shade_p6(const DevScene &S, const rt_params &P, const Hit &h, V3 ray_d, int bounce, const RngCtx &rc,
-                         ShadeOut &o, uint32_t *stack, Counters &cnt)
+                         ShadeOut &o, const BvhStack &stack, Counters &cnt)
 {
     const rt_blinn &m = S.materials[S.node_material[h.node]];
     V3 N = h.N;
@@ -1093,7 +1186,7 @@ __device__ void shade_p6(const DevScene &S, const rt_params &P, const Hit &h, V3
 // the child's own hit (FIN: Attenuation(parent absorption, z) on a back-face hit, FIN/main.cpp:620,
 // 632; P13: exp(-absorption.r*z) on the refraction child, P13/main.cpp:728) is applied on arrival.
 template <int MODEL, bool TEX>
-__device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uint32_t *stack, Counters &cnt)
+__device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, const BvhStack &stack, Counters &cnt)
 {
     const DevScene &S = C.S;
     const rt_params &P = C.P;
@@ -1109,6 +1202,8 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
     o.want_side = false; o.side_dir = mk(0, 0, 1); o.side_K = mk(0, 0, 0);
     o.n_caustic = 0; o.spec_out = in.spec; o.mat = 0;
     constexpr bool p6 = MODEL == RT_SHADE_P6, p3 = MODEL == RT_SHADE_P3;
+    // the workgroup-shared ray stack of k_wavefront is two-ended (push_ray); a wave's own stack in the P12 rounds is plain
+    constexpr bool TWO = !(RT_WF_PERWAVE && MODEL == RT_SHADE_P12);
     bool spawn_side = false;
     if (active && !in.primary) {
         if (p6) {
@@ -1139,16 +1234,16 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
         o.want_photon = o.want_photon && (wp.x != 0.f || wp.y != 0.f || wp.z != 0.f);
     }
     // pushes are wave-collective: every lane of the wave reaches them
-    push_ray(C, o.want_refl, h.p, o.rdir, thr * o.rK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFLECT,
+    push_ray<false, TWO>(C, o.want_refl, h.p, o.rdir, thr * o.rK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFLECT,
              child_node(in.node, 1u), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out, o.mat);
     if (p6) {
         const V3 sK = thr * o.side_K;
         push_ray<true>(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
                        child_node(in.node, 2u), in.sample, o.side_dir, o.want_side ? sK : mk(0, 0, 0));
         // the side ray of an arriving refraction ray: same origin and level as that ray
-        push_ray(C, spawn_side, in.o, in.side_dir, in.side_K, mk(0, 0, 0), in.slot, in.bounce, KIND_REFLECT, child_node(in.node, 4u), in.sample);
+        push_ray<false, TWO>(C, spawn_side, in.o, in.side_dir, in.side_K, mk(0, 0, 0), in.slot, in.bounce, KIND_REFLECT, child_node(in.node, 4u), in.sample);
     } else
-    push_ray(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
+    push_ray<false, TWO>(C, o.want_refr, h.p, o.tdir, thr * o.tK, o.child_absorb, in.slot, in.bounce - 1, KIND_REFRACT,
              child_node(in.node, 2u), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out, o.mat);
     push_photon_query(C, o.want_photon, h.p, o.N, thr * o.kd, in.slot);
     if (p13) {
@@ -1175,7 +1270,7 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, uin
                 hd = normalize(hd);                        // Ray_idr.dir.Normalize() (:433)
                 want = (w.x != 0.f || w.y != 0.f || w.z != 0.f);
             }
-            push_ray(C, want, h.p, hd, w, mk(0, 0, 0), in.slot, in.bounce - 1, KIND_GI, child_node(in.node, 3u + (uint32_t)i), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out);
+            push_ray<false, TWO>(C, want, h.p, hd, w, mk(0, 0, 0), in.slot, in.bounce - 1, KIND_GI, child_node(in.node, 3u + (uint32_t)i), in.sample, mk(0, 0, 0), mk(0, 0, 0), o.spec_out);
         }
     }
 }
@@ -1288,8 +1383,8 @@ template <int MODEL, bool TEX>
 RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_primary(ShadeCtx C, PrimaryArgs A)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
-    uint32_t *stack = s_stack + threadIdx.x;
-    Counters cnt = {0, 0, 0, 0};
+    const BvhStack stack = bvh_stack(s_stack, RT_BVH_STACK, C.S.bvh_spill);
+    Counters cnt = {0, 0, 0, 0, 0};
     uint32_t nprim = 0;
     const uint32_t npix = (A.mode == 1) ? C.W.counts[CNT_PIXLIST] : A.npix;
     const unsigned long long total = (unsigned long long)npix * (unsigned long long)A.ns;
@@ -1315,8 +1410,8 @@ template <int MODEL, bool TEX>
 RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, DevRayQueue qin, int level)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
-    uint32_t *stack = s_stack + threadIdx.x;
-    Counters cnt = {0, 0, 0, 0};
+    const BvhStack stack = bvh_stack(s_stack, RT_BVH_STACK, C.S.bvh_spill);
+    Counters cnt = {0, 0, 0, 0, 0};
     uint32_t nrefl = 0, nrefr = 0;
     uint32_t total = C.W.counts[level];
     if (total > qin.cap) total = qin.cap;
@@ -1376,9 +1471,6 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
 #ifndef RT_WF_TEX_WAVES
 #define RT_WF_TEX_WAVES 3      // ... of the textured ones (measured on the 102 k-triangle frame under a PNG sky: 40.5 ms at two, 31.2 ms at three)
 #endif
-#ifndef RT_WF_PERWAVE
-#define RT_WF_PERWAVE 1        // 1: for the P12 model every wave of k_wavefront runs its own rounds on its own part of the LDS ray stack (no workgroup barriers); 0: the four waves always share stack and rounds
-#endif
 #define RT_WF_HALTON 64
 template <bool TEX> struct WfCfg {
     static constexpr int WAVES = TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES;
@@ -1418,8 +1510,8 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
     __shared__ uint32_t s_countw[NW];
     const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     float4 *qa = s_qa + wv * STACK_W, *qb = s_qb + wv * STACK_W, *qc = s_qc + wv * STACK_W;
-    uint32_t *stack = s_stack + threadIdx.x;
-    Counters cnt = {0, 0, 0, 0};
+    const BvhStack stack = bvh_stack(s_stack, Cfg::BVH, C.S.bvh_spill);
+    Counters cnt = {0, 0, 0, 0, 0};
     uint32_t nprim = 0, nrefl = 0, nrefr = 0;
     const uint32_t npix = (A.mode == 1) ? C.W.counts[CNT_PIXLIST] : A.npix;
     const unsigned long long total = A.mode == 3 ? (unsigned long long)min(*A.qsrc_count, A.qsrc.cap)
@@ -1509,8 +1601,8 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
 #else
 #define XSYNC() __syncthreads()
 #endif
-    uint32_t *stack = s_stack + threadIdx.x;
-    Counters cnt = {0, 0, 0, 0};
+    const BvhStack stack = bvh_stack(s_stack, Cfg::BVH, C.S.bvh_spill);
+    Counters cnt = {0, 0, 0, 0, 0};
     uint32_t nprim = 0, nrefl = 0, nrefr = 0;
     const uint32_t npix = (A.mode == 1) ? C.W.counts[CNT_PIXLIST] : A.npix;
     // mode 3: the rays that did not fit the LDS stacks of the pass before (they sit in a global queue) are the work items;
@@ -1526,8 +1618,10 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
     bool more_primaries = true;                           // workgroup-uniform
     for (;;) {
         XSYNC();                                  // last round's pushes are complete
-        uint32_t waiting = s_count;
-        if (waiting > (uint32_t)Cfg::STACK) waiting = Cfg::STACK;   // the excess went to the global queue
+        const uint32_t packed = s_count;
+        const uint32_t w0 = packed & 0xFFFFu, w1 = packed >> 16;
+        const uint32_t pside = w1 > w0 ? 1u : 0u;         // the fuller side is popped
+        const uint32_t waiting = w0 + w1;                 // never beyond the stack: a push that does not fit takes its count back (push_ray)
         // pop a full workgroup's worth when there is one -- and already earlier when a round of primary rays (up to two
         // children each) could no longer be sure to fit: rays that do not fit go through the global queue and the
         // per-level launches, the slow path (measured: 5 ms per Cornell frame before this rule)
@@ -1541,13 +1635,14 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
             // overflow was measured slower (rounds of n >= 64 / 128 / 192: Cornell trace 28.1 / 26.8 / 25.7 ms vs 24.9; with no
             // floor, rounds of a handful of rays whose children refill the stack at once: 66.5 ms) -- the few rays that do not
             // fit take the global queue
-            const uint32_t n = min(waiting, (uint32_t)RT_BLOCK);
+            const uint32_t wside = pside ? w1 : w0;
+            const uint32_t n = min(wside, (uint32_t)RT_BLOCK);
             active = threadIdx.x < n;
             in.primary = false; in.thr = mk(0, 0, 0); in.absorb = mk(0, 0, 0); in.o = mk(0, 0, 0); in.d = mk(0, 0, 1);
             in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0; in.spec = 0;
             in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
             if (active) {
-                const uint32_t src = waiting - 1u - threadIdx.x;          // newest (deepest) first: the stack stays shallow
+                const uint32_t src = pside ? (uint32_t)Cfg::STACK - wside + threadIdx.x : wside - 1u - threadIdx.x;
                 const float4 a = s_qa[src], b = s_qb[src], c = s_qc[src];
                 in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
                 in.thr = mk(b.z, b.w, c.x);
@@ -1562,9 +1657,9 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
                 if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
             }
             XSYNC();                              // all pops read before anything is pushed over them
-            if (threadIdx.x == 0) s_count = waiting - n;
+            if (threadIdx.x == 0) s_count = packed - (n << (16u * pside));
         } else {
-            if (threadIdx.x == 0) { s_batch = atomicAdd(next_batch, 1u); if (s_count > (uint32_t)Cfg::STACK) s_count = Cfg::STACK; }
+            if (threadIdx.x == 0) s_batch = atomicAdd(next_batch, 1u);
             XSYNC();
             const unsigned long long batch = s_batch;
             if (batch >= n_batches) { more_primaries = false; continue; }
@@ -1607,8 +1702,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene S, const float *ray
                                                     uint8_t *hit, float *z, float *p, float *N, int32_t *node, uint8_t *front)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
-    uint32_t *stack = s_stack + threadIdx.x;
-    Counters cnt = {0, 0, 0, 0};
+    const BvhStack stack = bvh_stack(s_stack, RT_BVH_STACK, S.bvh_spill);
+    Counters cnt = {0, 0, 0, 0, 0};
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         Hit h;
         h.z = BIGFLOAT; h.p = mk(0, 0, 0); h.N = mk(0, 0, 0); h.node = -1; h.front = 1;
@@ -1748,8 +1843,8 @@ __device__ bool random_photon_bounce(const rt_blinn &m, const Hit &h, V3 &rp, V3
 __global__ __launch_bounds__(RT_BLOCK) void k_photon_trace(DevScene S, PhotonArgs A)
 {
     __shared__ uint32_t s_stack[RT_BVH_STACK * RT_BLOCK];
-    uint32_t *stack = s_stack + threadIdx.x;
-    Counters cnt = {0, 0, 0, 0};
+    const BvhStack stack = bvh_stack(s_stack, RT_BVH_STACK, S.bvh_spill);
+    Counters cnt = {0, 0, 0, 0, 0};
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n_attempts) return;
     const unsigned long long attempt = A.first_attempt + i;
@@ -2888,7 +2983,13 @@ static bool wavefront_usable(const DevScene &S, const rt_params &P, bool tex)
     if (p12 < 0) { const char *e = getenv("RT_P12_TRACER"); p12 = (e && !strcmp(e, "levels")) ? 0 : 1; }
     const bool model_ok = P.shade_model == RT_SHADE_FIN || P.shade_model == RT_SHADE_P13 || (P.shade_model == RT_SHADE_P12 && p12 && P.hemisphere_sample <= 2);
     if (!wavefront || !model_ok) return false;
-    return S.max_bvh_depth <= (tex ? WfCfg<true>::BVH : WfCfg<false>::BVH);
+    // (the traversal stack: the kernel's LDS part plus, when the scene has the spill buffer, RT_BVH_SPILL entries per thread behind it)
+    return S.max_bvh_depth <= (tex ? WfCfg<true>::BVH : WfCfg<false>::BVH) + (S.max_bvh_depth > 24 ? RT_BVH_SPILL : 0);
+}
+
+bool rtk_wavefront_usable(const DevScene &S, const rt_params &P)
+{
+    return wavefront_usable(S, P, S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE);
 }
 
 void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, const rt_params &P,
@@ -2896,7 +2997,7 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
                         const DevTiles &tiles, uint32_t q0, uint32_t npix, int j0, int ns,
                         int max_sample, int mode, const float *rays, int max_blocks)
 {
-    ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
+    ShadeCtx C; C.S = S; C.S.bvh_spill = W.bvh_spill; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
     PrimaryArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.j0 = j0; A.ns = ns;
     A.max_sample = max_sample; A.mode = mode; A.rays = rays;
     tiles_prepare(A.tiles);
@@ -2944,7 +3045,7 @@ bool rtk_launch_wavefront_queue(hipStream_t st, const DevScene &S, const DevWork
     if (queue_pass < 0) { const char *q = getenv("RT_WF_QUEUE_PASS"); queue_pass = (q && q[0] == '0') ? 0 : 1; }
     const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
     if (!queue_pass || !wavefront_usable(S, P, tex)) return false;
-    ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
+    ShadeCtx C; C.S = S; C.S.bvh_spill = W.bvh_spill; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
     C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
     DevTiles tp = tiles;
     tiles_prepare(tp);
@@ -2971,7 +3072,7 @@ void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, cons
                        const DevRayQueue &qin, const DevRayQueue &qout, uint32_t *qout_count,
                        int level, int max_blocks)
 {
-    ShadeCtx C; C.S = S; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
+    ShadeCtx C; C.S = S; C.S.bvh_spill = W.bvh_spill; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
     C.lds_a = C.lds_b = C.lds_c = nullptr; C.lds_count = nullptr; C.lds_cap = 0;
     memset(&C.sm, 0, sizeof C.sm);
     const bool tex = S.material_maps != nullptr || S.env_map.texture != RT_MAP_NONE;
@@ -2990,7 +3091,7 @@ void rtk_launch_bounce(hipStream_t st, const DevScene &S, const DevWork &W, cons
 void rtk_launch_trace(hipStream_t st, const DevScene &S, int model, const float *rays, long long n,
                       uint8_t *hit, float *z, float *p, float *N, int32_t *node, uint8_t *front)
 {
-    const int grid = grid_for((unsigned long long)n, RT_BLOCK, 4096);
+    const int grid = grid_for((unsigned long long)n, RT_BLOCK, RT_SPILL_BLOCKS);
     if (model == RT_SHADE_P3) hipLaunchKernelGGL(k_trace<RT_SHADE_P3>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
     else if (model != RT_SHADE_FIN) hipLaunchKernelGGL(k_trace<RT_SHADE_P13>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);
     else hipLaunchKernelGGL(k_trace<RT_SHADE_FIN>, dim3(grid), dim3(RT_BLOCK), 0, st, S, rays, n, hit, z, p, N, node, front);

@@ -1312,6 +1312,52 @@ def test_generated_photon_map_equals_the_host_balanced_one(cornell):
         assert (i1.max(axis=1) > 0).mean() > 0.9
 
 
+def test_generated_photon_map_follows_the_scene_and_the_render_parameters():
+    """A map made by the photon pass is DERIVED from the scene (the reference runs generatePhotonMap() on every BeginRender,
+    FIN/main.cpp:984-990): rt_render_begin keeps it while scene and photon parameters stay, makes a new one when the render
+    asks for another count or seed, and a change of what the photons were traced through (lights, materials, another XML)
+    drops it; a map handed over with rt_scene_set_photons is the caller's and survives all of that."""
+    s, cam = scenes.load_cornell()
+    cam.width, cam.height = 64, 48
+    p = capi.default_params(min_sample=1, max_sample=1, threshold=-1.0)
+    p.photon_count, p.photon_bounce, p.seed = 5000, 8, 11
+    s.render(cam, p, photon_pass=True)
+    first = s.get_photons().copy()
+    assert s.counts()["photons"] >= 5000
+    s.render(cam, p, photon_pass=True)                                   # same scene, same parameters: the map is kept
+    assert s.get_photons().tobytes() == first.tobytes()
+    p.seed = 12
+    s.render(cam, p, photon_pass=True)                                   # another seed: generated again
+    second = s.get_photons().copy()
+    assert second.tobytes() != first.tobytes()
+    p.photon_count = 3000
+    s.render(cam, p, photon_pass=True)                                   # another count
+    assert 3000 <= s.counts()["photons"] < 3010
+    # moving the light changes what the photons see: the generated map is dropped at once ...
+    e = s.export()
+    lights = e["lights"].copy()
+    lights["position"][lights["type"] == capi.LIGHT_POINT] += np.float32(3.0)
+    s.set_lights(lights)
+    assert s.counts()["photons"] == 0
+    s.render(cam, p, photon_pass=True)                                   # ... and BeginRender makes the new scene's
+    moved = s.get_photons().copy()
+    assert 3000 <= len(moved) - 1 < 3010
+    s2, _ = scenes.load_cornell()
+    s2.set_lights(lights)
+    s2.generate_photons(3000, 8, seed=12)
+    assert s2.get_photons().tobytes() == moved.tobytes()                 # exactly the map of the moved light
+    # another XML drops a generated map, too
+    s.load_xml(scenes.CORNELL)
+    assert s.counts()["photons"] == 0
+    # a map the caller set stays through scene changes and is what BeginRender renders with
+    s.set_photons(first)
+    s.set_lights(lights)
+    s.load_xml(scenes.CORNELL)
+    assert s.get_photons().tobytes() == first.tobytes()
+    s.render(cam, p, photon_pass=True)
+    assert s.get_photons().tobytes() == first.tobytes()
+
+
 def test_full_size_frame_properties():
     """BASELINE size (1920 x 1080) with 2 fixed samples: size-independent properties"""
     s, cam = scenes.load_cornell(1920, 1080)
