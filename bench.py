@@ -33,9 +33,26 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0        # aggregate L2 rate of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
-L1_PEAK_GBS = 64.0 * 256 * 2.4     # the vector L1s: 64 bytes per clock and CU (a 16-byte-per-lane wave load = 16 L1 accesses), 256 CUs at 2.4 GHz
-VALU_PEAK_GINST = 1024 * 2.4 / 2      # wave64 VALU instructions per ns: 256 CUs x 4 SIMDs at 2.4 GHz, one per 2 cycles (32 lanes per cycle; the
-                                      # 157.3 TF f32 vector peak is exactly that with fma).  One WAVE issues at most one per 4 cycles.
+
+
+def measured_peaks():
+    """The two ceilings the guide does not give, MEASURED on an MI355X by tools_peaks.hip and committed as profiles/r*_peaks.json
+    (the newest one): wave64 v_fma_f32 issue rate of the whole chip (Gwave-inst/s, at the clock the chip holds under that load)
+    and 16-byte-per-lane loads that hit the vector L1 (GB/s; 63.4 B per clock and CU at 2.4 GHz), plus the rate of k_gather's own
+    access shape (256-byte sub-leaf pairs at its occupancy, random in a 32 KiB window per workgroup: mostly L1 hits).  The
+    line's roofline names the file (`peak_source`), so `frac` can be recomputed from that file and the counter summary."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_peaks.json")))
+    if not files:
+        return {"source": None, "valu_ginst": 1024 * 2.4 / 2, "l1_gbs": 64.0 * 256 * 2.4, "gather_shape_gbs": None}
+    d = json.load(open(files[-1]))
+    return {"source": os.path.basename(files[-1]), "valu_ginst": float(d["valu_peak_Gwave_inst_per_s"]), "l1_gbs": float(d["l1_peak_GBps"]),
+            "gather_shape_gbs": float(d["gather_shape_5_waves_per_simd"]["window_32KiB_per_workgroup"]["chip_GBps"])}
+
+
+PEAKS = measured_peaks()
+L1_PEAK_GBS = PEAKS["l1_gbs"]
+VALU_PEAK_GINST = PEAKS["valu_ginst"]
 PARITY_NOTE = ("oracle pinned bit for bit to the reference's own code on the whole path: primitives / BVH / kNN / photon balance (compiled "
                "headers) and TraceNode, GenLight::Shadow, MtlBlinn::Shade (FIN + P13), RenderPixel, PhotonTracing / CausticTracing (the reference's "
                "main.cpp compiled with only its viewport include removed: tests/golden/main_*.npz); GPU vs those fixtures in the -m gpu suite; this "
@@ -124,6 +141,62 @@ def cpu_baseline(scene_export, balanced, cam, params, budget_s):
             "reference_measured": {"px_per_s": 159, "Mray_s": 0.135, "threads": 1,
                                    "note": "the reference's own RenderPixel, FIN scene, 1 M photons, adaptive 4->8 spp, rows 400-407, "
                                            "build container (BASELINE.md section 2) -- other sampling, other host: context only"}}, kept
+
+
+def cpu_worker(path, index, stride, seconds):
+    """one worker PROCESS of cpu_baseline_threads (bench.py --cpu-worker ...): the port on its share of the seeded blocks"""
+    import pickle
+    from oracle import orc
+    from raytracing_folder_amd import capi
+    d = pickle.load(open(path, "rb"))
+    cam, params = capi.Camera.from_buffer_copy(d["cam"]), capi.Params.from_buffer_copy(d["params"])
+    osc = orc.scene_from_export(d["export"], d["balanced"])
+    ocam, op = orc.camera_from(cam), orc.params_from(params)
+    bx, by = cam.width // 2, cam.height // 2
+    order = np.random.default_rng(7).permutation(bx * by)
+    order = order[len(order) // 2 + index::stride]                                        # (the second half of the seeded order: blocks the single-thread legs do not reach)
+    orc.set_trace_discarded(True)
+    px, t0 = 0, time.perf_counter()
+    for b in order:
+        x0, y0 = (int(b) % bx) * 2, (int(b) // bx) * 2
+        orc.render(osc, ocam, op, x0, y0, x0 + 2, y0 + 2)
+        px += 4
+        if time.perf_counter() - t0 > seconds:
+            break
+    print(json.dumps({"px": px, "seconds": time.perf_counter() - t0}), flush=True)
+
+
+def cpu_baseline_threads(scene_export, balanced, cam, params, seconds=6.0):
+    """The CPU figure AS THE REFERENCE SHIPS IT: BeginRender starts hardware_concurrency() * 2 workers on the shared pixel counter
+    (FIN/main.cpp:987, 71-78).  Here: that many worker PROCESSES of the port (its RNG context is a global, so threads of one
+    process would race; the workers share nothing but the seeded block order), each on its own blocks of the same frame for
+    `seconds`; throughput = all their pixels / the slowest worker's time.  Reported beside cores: 1, never the target."""
+    import pickle
+    import subprocess
+    import tempfile
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(2, min(2 * cores, 32))                                    # (the pool allows a GPU box 16 cores: at most 32 workers)
+    td = tempfile.mkdtemp(prefix="rt_cpu_leg_")
+    path = os.path.join(td, "leg.pkl")
+    with open(path, "wb") as f:
+        pickle.dump({"export": scene_export, "balanced": balanced, "cam": bytes(cam), "params": bytes(params)}, f)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(i), str(workers), str(seconds)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT) for i in range(workers)]
+    outs = []
+    for pr in procs:
+        o, _ = pr.communicate(timeout=20 * seconds + 120)
+        try:
+            outs.append(json.loads(o.decode().strip().splitlines()[-1]))
+        except Exception:
+            pass
+    os.remove(path)
+    if len(outs) != workers:
+        return {"error": f"{workers - len(outs)} of {workers} workers failed"}
+    px, wall = sum(o["px"] for o in outs), max(o["seconds"] for o in outs)
+    return {"workers": workers, "host_cores": cores, "px_per_s": round(px / wall, 1), "pixels": px, "seconds": round(wall, 1),
+            "frame_s_extrapolated": round(cam.width * cam.height / (px / wall), 1),
+            "what": "hardware_concurrency() * 2 workers as BeginRender starts them (FIN/main.cpp:987): worker processes of the port, incl. the discarded hemisphere loop"}
 
 
 def reference_here(raw_photons, width, height, seconds=6.0):
@@ -249,6 +322,8 @@ def profile_figures(default_workload):
 
 
 def main():
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
     a = parse()
     lib_path = os.path.join(ROOT, "raytracing_folder_amd", "lib", "librt_mi355x.so")
     if not os.path.exists(lib_path):              # fresh checkout: built artefacts are git-ignored
@@ -343,23 +418,27 @@ def main():
         R.step(sync=False)
         R.finish()
     barrier()
+    async_steps = not a.sync_steps and st_warm is not None
+    if async_steps:
+        s.render_counters(local, reset=True)            # the device-side work counters now count the timed frames and nothing else
     t0 = time.perf_counter()
     stats, step_ms = [], []
     for _ in range(a.steps):
         t_step = time.perf_counter()
-        st, frame = R.step(sync=a.sync_steps or st_warm is None)            # (without a warm-up the first timed frame is the synchronous one)
+        st, frame = R.step(sync=not async_steps)                             # (without a warm-up the first timed frame is the synchronous one)
         st_warm = st if st is not None else st_warm
-        stats.append(st_warm.as_dict())                                      # the same frame every step: the last synchronous frame's counts hold
+        stats.append(st_warm.as_dict())                                      # timings / stream count of the last synchronous frame; the work counts: below
         step_ms.append(round((time.perf_counter() - t_step) * 1e3, 2))      # this rank's steps as the host saw them (enqueue time when asynchronous)
     R.finish()
     barrier()
     dt = time.perf_counter() - t0
+    timed_counts = s.render_counters(local).as_dict() if async_steps else None     # ONE read-back behind the timed region: what the K timed frames really traced
     if a.steps > 0:
         frame = tuple(t.clone() for t in frame)        # the last TIMED frame (the roofline leg below renders into the same buffers)
 
     keys = ["rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "photon_queries", "photons_visited",
             "bvh_nodes_visited", "tris_tested", "instance_visits", "gather_rounds", "gather_slow", "gather_leaf_reads"]
-    tot = {k: float(sum(x[k] for x in stats)) for k in keys}
+    tot = {k: float(timed_counts[k]) if timed_counts is not None else float(sum(x[k] for x in stats)) for k in keys}
     gather_ms = float(sum(R.gather_ms)) / max(len(R.gather_ms), 1) if getattr(R, "gather_ms", None) else 0.0
     vec = torch.tensor([dt, gather_ms] + [tot[k] for k in keys], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if world > 1:
@@ -432,14 +511,15 @@ def main():
                 q0 = parts[0]
                 if q0 in figs["valu_insts"] and sec > 0 and c["launches"] > 0:
                     # VALU issue fraction of the DOMINANT kernel of the class: counted instructions per launch (profile) / LIVE
-                    # exclusive time per launch.  Peak = one wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz (inferred
-                    # in round 2 from a build that came out at 1.17 of the 4-cycle figure; not pinned by a microbenchmark);
-                    # NOT clamped: a value above 1 would show the peak is mispriced.
+                    # exclusive time per launch, against the chip's measured v_fma_f32 issue rate (measured_peaks()); NOT clamped.
                     live_us = c["ms"] * 1e3                                     # this class, per frame, exclusive
                     row["valu_frac"] = round(figs["valu_insts"][q0] / (live_us * 1e3) / VALU_PEAK_GINST, 4)
                     if q0 in figs["l1_accesses"]:
-                        # the vector-memory pipe: 64-byte L1 accesses counted in the profile / live time, against 64 B per clock and CU
+                        # the vector-memory pipe: 64-byte L1 accesses counted in the profile / live time, against the measured rate of L1 hits;
+                        # for k_gather also against the measured rate of its own access shape (what loads alone can do at its occupancy)
                         row["l1_frac"] = round(figs["l1_accesses"][q0] * 64.0 / (live_us * 1e-6) / 1e9 / L1_PEAK_GBS, 4)
+                        if name == "k_gather" and PEAKS["gather_shape_gbs"]:
+                            row["access_shape_frac"] = round(figs["l1_accesses"][q0] * 64.0 / (live_us * 1e-6) / 1e9 / PEAKS["gather_shape_gbs"], 4)
                     row["live_us_per_frame"] = round(live_us, 1)
                     row["profile_us_per_frame"] = round(figs["file_launch_us"][q0], 1)
                     # (the tracer class also holds the k_bounce launches behind k_wavefront: compared with a wider margin)
@@ -468,7 +548,10 @@ def main():
             roof = {"kernel": dom, "bound": bound if not stale else "l2", "achieved": round(ach, 2) if not stale else d["l2_GBps"],
                     "peak": round(peak, 1) if not stale else L2_PEAK_GBS, "unit": unit if not stale else "GB/s",
                     "frac": round(fr[bound], 4) if not stale else None, "stale_profile": stale, "stale_reasons": figs["stale"],
-                    "kernel_build": figs["build"], "valu_peak_note": "one wave64 VALU instruction per 2 cycles per SIMD: inferred from measurement (round 2), unclamped",
+                    "kernel_build": figs["build"], "peak_source": PEAKS["source"],
+                    "peaks": {"hbm_GBps": HBM_PEAK_GBS, "l2_GBps": L2_PEAK_GBS, "l1_GBps": L1_PEAK_GBS, "valu_Gwave_inst_per_s": VALU_PEAK_GINST,
+                              "gather_access_shape_GBps": PEAKS["gather_shape_gbs"],
+                              "note": "hbm, l2: MI355X_MICROARCH.md; l1, valu, gather_access_shape: measured by tools_peaks.hip (peak_source)"},
                     "traffic": int(figs["hbm"][dom]) if dom in figs["hbm"] and not stale else None,
                     "traffic_source": figs["hbm_source"], "valu_source": figs["valu_source"],
                     "fractions": fr,
@@ -501,6 +584,7 @@ def main():
             "gather_ms": round(gather_ms, 3),
             "parity_note": PARITY_NOTE,
             **({"rehearsal": "all ranks on device 0, gloo gather -- not a scaling measurement"} if rehearsal else {}),
+            "ray_counts_from": "device counters read once after the timed frames (rt_render_counters)" if timed_counts is not None else "per-step statistics of the synchronous steps",
             "rays_per_frame": {k: int(tot[k] / a.steps) for k in keys[:4]},
             "photon_queries_per_frame": int(tot["photon_queries"] / a.steps),
             "gather_per_frame": {k: int(tot[k] / a.steps) for k in ("photons_visited", "gather_rounds", "gather_slow", "gather_leaf_reads")},
@@ -511,6 +595,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             # the checker needs the reference's balanced heap (its LocatePhotons walks it): made from the same photons on request
             out["cpu_baseline"], kept = cpu_baseline(s.export(), s.get_photons() if n_photons else None, cam, p, a.cpu_seconds)
+            out["cpu_baseline"]["as_shipped_multi_worker"] = cpu_baseline_threads(s.export(), s.get_photons() if n_photons else None, cam, p)
             if a.workload == "cornell" and n_photons:
                 # (the unbalanced photons as generated: what balancing them on the host starts from)
                 raw = capi.photons_read_dat(dump_path) if dump_path else None

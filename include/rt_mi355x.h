@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 typedef int rt_status;
 #define RT_OK               0
@@ -419,6 +419,13 @@ rt_status rt_tiles_unpack_device(int device, void *hip_stream, const void *gathe
 /* Waits for the asynchronous renders (sync == 0) issued so far on (scene, device) and returns
  * RT_ERR_LIMIT if any of them dropped rays or photon queries, RT_OK otherwise. */
 rt_status rt_render_check(rt_scene *s, int device);
+/* ABI 4: the device-side work counters (rays by class, traversal visits, photon queries / photons examined, gather rounds:
+ * the uint64 counting fields of rt_stats; its timings, launches and pixels stay zero) accumulated by every render on
+ * (scene, device) since they were last cleared -- a render that collects statistics (stats_out, a job) clears them at its
+ * start, asynchronous renders only add.  Waits for the renders issued so far.  `reset` != 0 clears them after the read:
+ * read-and-reset before a run of asynchronous frames and read again after it to count exactly those frames (bench.py's timed
+ * region).  The reference has no counterpart (its only statistic is the wall-clock timer of viewport.cpp:442). */
+rt_status rt_render_counters(rt_scene *s, int device, int reset, rt_stats *out);
 int       rt_render_progress(rt_job *j);      /* pixels finished so far (monotonic)       */
 rt_status rt_render_stop(rt_job *j);          /* cooperative cancel (StopRender)          */
 rt_status rt_render_wait(rt_job *j);          /* join; returns the job's final status     */

@@ -87,7 +87,7 @@ SYMBOLS = [
     "rt_scene_get_textures", "rt_scene_get_maps", "rt_image_read_rgb", "rt_image_write_png", "rt_image_zbuffer", "rt_image_sample_count", "rt_scene_load_xml", "rt_scene_get_camera", "rt_scene_counts",
     "rt_scene_get_nodes", "rt_scene_get_materials", "rt_scene_get_lights", "rt_scene_mesh_counts",
     "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photons_write_dat", "rt_photons_read_dat", "rt_photon_pass", "rt_caustic_pass", "rt_render_begin",
-    "rt_render_tiles_device", "rt_render_tiles_packed_device", "rt_tiles_packed_size", "rt_tiles_unpack_device", "rt_render_check", "rt_render_progress", "rt_render_stop", "rt_render_wait",
+    "rt_render_tiles_device", "rt_render_tiles_packed_device", "rt_tiles_packed_size", "rt_tiles_unpack_device", "rt_render_check", "rt_render_counters", "rt_render_progress", "rt_render_stop", "rt_render_wait",
     "rt_job_stats", "rt_job_setup_ms", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
     "rt_scene_generate_photons", "rt_scene_set_photon_dump", "rt_scene_get_photons", "rt_photon_unreachable",
 ]
@@ -474,6 +474,12 @@ class Scene:
         _check(lib().rt_render_tiles_packed_device(self._h, C.byref(cam), C.byref(params), C.byref(tiles), int(device), handle,
                                                    C.c_void_p(packed_ptr), C.c_uint64(int(packed_bytes)), 1 if sync else 0,
                                                    C.byref(st) if want_stats else None))
+        return st
+
+    def render_counters(self, device=0, reset=False):
+        """the device-side work counters accumulated since they were last cleared (rt_render_counters); waits for pending renders"""
+        st = Stats()
+        _check(lib().rt_render_counters(self._h, int(device), 1 if reset else 0, C.byref(st)))
         return st
 
     def render_check(self, device=0):

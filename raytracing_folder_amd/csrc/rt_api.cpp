@@ -131,7 +131,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
-struct DevMeshBufs { DevBuf nodes, tris, tri_face, nrm, tex; };
+struct DevMeshBufs { DevBuf nodes, tris, nrm, tex; };
 
 // Per-chunk working set.  A frame's chunks alternate between RT_STREAMS of these, each on its own HIP
 // stream, so that the short launches of one chunk (deep bounce levels with few rays, whose duration is
@@ -155,7 +155,7 @@ struct Workspace {
 struct DeviceState {
     int device = -1;
     bool scene_valid = false, photons_valid = false, caustic_valid = false;
-    DevBuf nodes, objects, meshes, materials, lights, node_material, textures, texels, material_maps;
+    DevBuf nodes, objects, objects_back, meshes, materials, lights, node_material, textures, texels, material_maps;
     std::vector<DevMeshBufs> mesh_bufs;
     DevBuf pa, pb, box4, grid;                  // the gather structure of the photon map (rt_photon_build.hip)
     DevBuf cpa, cpb, cbox4, cgrid;              // ... of the caustic map
@@ -185,9 +185,9 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     void release()
     {
-        for (DevBuf *b : {&nodes, &objects, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &box4, &grid, &cpa, &cpb, &cbox4, &cgrid,
+        for (DevBuf *b : {&nodes, &objects, &objects_back, &meshes, &materials, &lights, &node_material, &textures, &texels, &material_maps, &pa, &pb, &box4, &grid, &cpa, &cpb, &cbox4, &cgrid,
                           &raw_photons, &bvh_spill, &cell_rk2, &ccell_rk2, &cell_start, &ccell_start, &stats, &t_in}) b->release();
-        for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.tri_face.release(); m.nrm.release(); m.tex.release(); }
+        for (auto &m : mesh_bufs) { m.nodes.release(); m.tris.release(); m.nrm.release(); m.tex.release(); }
         for (Workspace &w : ws) w.release();
         for (int k = 0; k < 6; k++) t_out[k].release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -781,10 +781,11 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
     std::vector<DevNodeXf> xf(nn);
     std::vector<int32_t> node_mat(nn, 0);
     std::vector<DevObject> objs;
+    std::vector<DevObjectBack> backs;
+    auto xf_of = [](const rt_node &n) { DevNodeXf x; memcpy(x.itm, n.itm, 36); memcpy(x.pos, n.pos, 12); memcpy(x.tm, n.tm, 36); x.pad[0] = x.pad[1] = x.pad[2] = 0; return x; };
     for (int i = 0; i < nn; i++) {
         const rt_node &n = sd.nodes[i];
-        memcpy(xf[i].itm, n.itm, 36); memcpy(xf[i].pos, n.pos, 12); memcpy(xf[i].tm, n.tm, 36);
-        xf[i].pad[0] = xf[i].pad[1] = xf[i].pad[2] = 0;
+        xf[i] = xf_of(n);
         if (n.obj_type == RT_OBJ_NONE) continue;
         if (n.material < 0 || (size_t)n.material >= sd.materials.size())
             return fail(RT_ERR_ARG, "node %d carries an object but its material index %d is invalid", i, n.material);
@@ -833,17 +834,23 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
             }
         }
         objs.push_back(o);
+        DevObjectBack b;
+        memset(&b, 0, sizeof b);
+        b.chain_len = len; b.node = i;
+        for (int k = 0; k < RT_BACK_LEVELS && k < len - 1; k++) b.lvl[k] = xf_of(sd.nodes[chain[k]]);     // chain[] is self .. root
+        backs.push_back(b);
     }
     if (objs.size() > RT_MAX_OBJECTS) return fail(RT_ERR_LIMIT, "too many objects (%zu)", objs.size());
 
     rt_status st;
     if ((st = D->nodes.upload(xf.data(), xf.size() * sizeof(DevNodeXf)))) return st;
     if ((st = D->objects.upload(objs.data(), objs.size() * sizeof(DevObject)))) return st;
+    if ((st = D->objects_back.upload(backs.data(), backs.size() * sizeof(DevObjectBack)))) return st;
     if ((st = D->node_material.upload(node_mat.data(), node_mat.size() * 4))) return st;
     if ((st = D->materials.upload(sd.materials.data(), sd.materials.size() * sizeof(rt_blinn)))) return st;
     if ((st = D->lights.upload(sd.lights.data(), sd.lights.size() * sizeof(rt_light)))) return st;
 
-    for (auto &mb : D->mesh_bufs) { mb.nodes.release(); mb.tris.release(); mb.tri_face.release(); mb.nrm.release(); mb.tex.release(); }
+    for (auto &mb : D->mesh_bufs) { mb.nodes.release(); mb.tris.release(); mb.nrm.release(); mb.tex.release(); }
     D->mesh_bufs.assign(sd.meshes.size(), DevMeshBufs());
     std::vector<DevMesh> dm(sd.meshes.size());
     int max_depth = 0;
@@ -873,30 +880,29 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
             T.A[0] = P[0].x; T.A[1] = P[0].y; T.A[2] = P[0].z; T.B[0] = P[1].x; T.B[1] = P[1].y; T.B[2] = P[1].z;
             T.C[0] = P[2].x; T.C[1] = P[2].y; T.C[2] = P[2].z; T.N[0] = N.x; T.N[1] = N.y; T.N[2] = N.z;
         }
-        for (size_t face = 0; face < nf; face++)
-            for (int k = 0; k < 3; k++) memcpy(&nrm[9 * face + 3 * k], &m.vn[3 * (size_t)m.fn[3 * face + k]], 12);
+        for (size_t sidx = 0; sidx < nf; sidx++)                 // per triangle SLOT (leaf order), like tris
+            for (int k = 0; k < 3; k++) memcpy(&nrm[9 * sidx + 3 * k], &m.vn[3 * (size_t)m.fn[3 * (size_t)tri_face[sidx] + k]], 12);
         DevMeshBufs &mb = D->mesh_bufs[mi];
         if ((st = mb.nodes.upload(bn.data(), bn.size() * sizeof(DevBvhNode)))) return st;
         if ((st = mb.tris.upload(tris.data(), tris.size() * sizeof(DevTri)))) return st;
-        if ((st = mb.tri_face.upload(tri_face.data(), tri_face.size() * 4))) return st;
         if ((st = mb.nrm.upload(nrm.data(), nrm.size() * 4))) return st;
         dm[mi].tex = nullptr;
-        if (!m.vt.empty() && m.ft.size() == m.f.size()) {      // vt[ft0], vt[ft1], vt[ft2] per face, like nrm
+        if (!m.vt.empty() && m.ft.size() == m.f.size()) {      // vt[ft0], vt[ft1], vt[ft2] per triangle slot, like nrm
             std::vector<float> tex(9 * nf);
-            for (size_t face = 0; face < nf; face++)
-                for (int k = 0; k < 3; k++) memcpy(&tex[9 * face + 3 * k], &m.vt[3 * (size_t)m.ft[3 * face + k]], 12);
+            for (size_t sidx = 0; sidx < nf; sidx++)
+                for (int k = 0; k < 3; k++) memcpy(&tex[9 * sidx + 3 * k], &m.vt[3 * (size_t)m.ft[3 * (size_t)tri_face[sidx] + k]], 12);
             if ((st = mb.tex.upload(tex.data(), tex.size() * 4))) return st;
             dm[mi].tex = (const float *)mb.tex.p;
         }
         dm[mi].nodes = (const DevBvhNode *)mb.nodes.p; dm[mi].tris = (const DevTri *)mb.tris.p;
-        dm[mi].tri_face = (const uint32_t *)mb.tri_face.p; dm[mi].nrm = (const float *)mb.nrm.p;
+        dm[mi].nrm = (const float *)mb.nrm.p;
         memcpy(dm[mi].root_box, m.nodes[1].box, 24);
         dm[mi].root_ref = root_ref; dm[mi].n_tris = (uint32_t)nf;
     }
     if ((st = D->meshes.upload(dm.data(), dm.size() * sizeof(DevMesh)))) return st;
 
     DevScene &S = D->scene;
-    S.nodes = (const DevNodeXf *)D->nodes.p; S.objects = (const DevObject *)D->objects.p;
+    S.nodes = (const DevNodeXf *)D->nodes.p; S.objects = (const DevObject *)D->objects.p; S.objects_back = (const DevObjectBack *)D->objects_back.p;
     S.meshes = (const DevMesh *)D->meshes.p; S.materials = (const rt_blinn *)D->materials.p;
     S.lights = (const rt_light *)D->lights.p; S.node_material = (const int32_t *)D->node_material.p;
     S.n_nodes = nn; S.n_objects = (int)objs.size(); S.n_meshes = (int)sd.meshes.size();
@@ -1674,6 +1680,38 @@ extern "C" rt_status rt_render_check(rt_scene *s, int device)
         D->qhist.valid = false;                             // the next render starts from the worst case again
         if (drops) HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 0, 8));
         return fail(RT_ERR_LIMIT, "rt_render_check: a ray/photon queue overflowed (%llu drops) in an asynchronous render", drops);
+    }
+    return RT_OK;
+}
+
+extern "C" rt_status rt_render_counters(rt_scene *s, int device, int reset, rt_stats *out)
+{
+    if (!s || !out) return fail(RT_ERR_ARG, "rt_render_counters: NULL argument");
+    memset(out, 0, sizeof *out);
+    DeviceState *D = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        for (DeviceState *d : s->devs) if (d->device == device) D = d;
+    }
+    if (!D || !D->stats.p) return RT_OK;                     // nothing was ever rendered there
+    HIP_TRY(hipSetDevice(device));
+    DeviceClaim claim(D);
+    if (!claim.ok) return fail(RT_ERR_STATE, "rt_render_counters: another call on this scene is using device %d", device);
+    // (the verdict of the asynchronous renders stays with rt_render_check: last_pending is left as it is)
+    if (D->last_pending && D->last_done) HIP_TRY(hipEventSynchronize(D->last_done));
+    unsigned long long hs[ST_COUNT];
+    HIP_TRY(hipMemcpy(hs, D->stats.p, sizeof hs, hipMemcpyDeviceToHost));
+    out->rays_primary = hs[ST_RAYS_PRIMARY]; out->rays_shadow = hs[ST_RAYS_SHADOW]; out->rays_reflect = hs[ST_RAYS_REFLECT];
+    out->rays_refract = hs[ST_RAYS_REFRACT]; out->instance_visits = hs[ST_INSTANCE_VISITS]; out->bvh_nodes_visited = hs[ST_BVH_NODES];
+    out->tris_tested = hs[ST_TRIS]; out->photon_queries = hs[ST_PHOTON_QUERIES]; out->photons_visited = hs[ST_PHOTONS_VISITED];
+    out->samples = hs[ST_RAYS_PRIMARY];
+    out->gather_rounds = hs[ST_GATHER_ROUNDS]; out->gather_slow = hs[ST_GATHER_SLOW]; out->gather_leaf_reads = hs[ST_GATHER_LEAF_READS];
+    out->peak_rays = hs[ST_PEAK_RAYS]; out->peak_queries = hs[ST_PEAK_QUERIES];
+    if (reset) {
+        // the drop counter and the queue peaks belong to the overflow verdict and the queue sizing: not touched
+        static_assert(ST_QUEUE_OVERFLOW == ST_PHOTONS_VISITED + 1 && ST_GATHER_ROUNDS == ST_QUEUE_OVERFLOW + 1 && ST_PEAK_RAYS == ST_GATHER_LEAF_READS + 1, "counter layout");
+        HIP_TRY(hipMemset(D->stats.p, 0, ST_QUEUE_OVERFLOW * 8));
+        HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_GATHER_ROUNDS, 0, (ST_PEAK_RAYS - ST_GATHER_ROUNDS) * 8));
     }
     return RT_OK;
 }

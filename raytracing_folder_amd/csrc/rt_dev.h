@@ -11,8 +11,8 @@
 //                                      64-byte read, no separate child fetch)
 //              DevTri[ ]               48 B: A, B, C, unit face normal -- in LEAF order, so a
 //                                      leaf's triangles are contiguous
-//              tri_face[ ]             face id per leaf-ordered triangle (read on accepted hits)
-//              nrm[ ]                  36 B per face: the three vertex normals (read once per ray)
+//              nrm[ ]                  36 B per leaf-ordered triangle: its three vertex normals (read once per ray, on the
+//                                      final hit: indexed by the triangle's slot, no face-id hop in between)
 //   photons    slots in sub-leaf-major order, RT_SUB_PHOTONS (16) slots per SUB-LEAF (padded with +inf
 //              positions), pa = (pos.xyz, dir.x), pb = (dir.y, dir.z, maxPower, colour bytes); sbox =
 //              tight box of every sub-leaf; RT_LEAF_SUBS (8) consecutive sub-leaves (128 slots, three
@@ -66,6 +66,18 @@ static_assert(sizeof(DevObject) == 128, "one object = two 64-byte scalar loads")
 // 16-byte loads), and their refs.  Collapsed from the reference's binary tree (cyBVH.h:76-106) on the host: a node's children
 // are the grandchildren of the binary node it stands for (a child that is a leaf stays one child), in the reference's
 // child1-before-child2 order.  An unused child has NaN bounds (never entered).  One visit = ONE dependent read for two levels.
+// What a closest hit needs of its object once the loop over the objects is over: Node::FromNodeCoords (scene.h:509-513) of the
+// object's own node and of up to two ancestors below the root, INLINE -- every address depends on the object index alone, so
+// a lane's loads go out together (chasing object -> chain entry -> node transform level by level was seven dependent round
+// trips per closest hit: 8 % of k_wavefront's wave time on the Cornell frame).  lvl[0] = the object's own node, lvl[1] = its
+// parent, ...; the root (chain[0], shared by every object) comes over the scalar cache; deeper chains finish through DevObject::chain.
+#define RT_BACK_LEVELS 3
+struct DevObjectBack {
+    int32_t chain_len, node, pad[2];
+    DevNodeXf lvl[RT_BACK_LEVELS];
+};
+static_assert(sizeof(DevObjectBack) == 16 + 96 * RT_BACK_LEVELS, "layout");
+
 struct DevBvhNode {
     float lo[3][4], hi[3][4];
     uint32_t c[4];               // bit31: leaf (bits28-30 count-1, bits0-27 first triangle slot); else the index of a DevBvhNode
@@ -89,9 +101,8 @@ struct DevTri { float A[3], B[3], C[3], N[3]; };   // 48 bytes
 struct DevMesh {
     const DevBvhNode *nodes;
     const DevTri     *tris;
-    const uint32_t   *tri_face;
-    const float      *nrm;       // 9 floats per face: vn[fn0], vn[fn1], vn[fn2]
-    const float      *tex;       // 9 floats per face: vt[ft0], vt[ft1], vt[ft2]; NULL without texture vertices
+    const float      *nrm;       // 9 floats per triangle slot (leaf order, like tris): vn[fn0], vn[fn1], vn[fn2] of its face
+    const float      *tex;       // 9 floats per triangle slot: vt[ft0], vt[ft1], vt[ft2]; NULL without texture vertices
     float    root_box[6];
     uint32_t root_ref;           // child-ref encoding of the root (leaf or node index)
     uint32_t n_tris;
@@ -121,6 +132,7 @@ struct DevPhotonMap {
 struct DevScene {
     const DevNodeXf *nodes;
     const DevObject *objects;
+    const DevObjectBack *objects_back;   // [n_objects], see DevObjectBack
     const DevMesh   *meshes;
     const rt_blinn  *materials;
     const rt_light  *lights;

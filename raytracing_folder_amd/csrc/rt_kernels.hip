@@ -27,15 +27,6 @@
 #define BIGFLOAT 1.0e30f
 #define LEAF_BIT 0x80000000u
 // k_gather tuning knobs (the defaults are the measured best on MI355X)
-#ifndef RT_GATHER_AHEAD
-#define RT_GATHER_AHEAD 1      // 1: the next leaf is fetched while the current one is processed (0: 27 % slower on MI355X)
-#endif
-#ifndef RT_GATHER_BRANCHY
-#define RT_GATHER_BRANCHY 1    // 1: accepted lanes accumulate under a branch; 0: predicated, branch-free
-#endif
-#ifndef RT_GATHER_LUT
-#define RT_GATHER_LUT 0        // 1: byte / 255.0f from a 256-entry LDS table instead of the two-fma form
-#endif
 #ifndef RT_GATHER_GUESS
 #define RT_GATHER_GUESS 1.2f   // photons expected inside the first trial radius, in units of k (round 2, sub-leaves: 1.1: 42.0 ms, 1.15: 40.8, 1.2: 40.7, 1.3: 41.7, 1.45: 43.3)
 #endif
@@ -52,30 +43,12 @@
 #ifndef RT_GATHER_BATCH
 #define RT_GATHER_BATCH 32     // queries a wave lists per phase A (40 leaf ids each: lists + ring keep 5 waves/SIMD)
 #endif
-#ifndef RT_GATHER_FMA
-#define RT_GATHER_FMA 1        // 1: the photon loop's d^2, dir.N, box distances and weighted sums may contract mul+add into fma (scoped
-                               // `#pragma clang fp contract(fast)`; the rest of the file stays uncontracted: hit records are bit-exact,
-                               // the gather's gate is 2e-5)
-#endif
-#ifndef RT_GATHER_CELLPRED
-#define RT_GATHER_CELLPRED 1   // 1: the k-th distance of the last query answered in a density-grid cell predicts the band of the next one
-                               // there (a table in HBM, written racily: a hint only); 0: the wave's previous query predicts
-#endif
-#ifndef RT_GATHER_CELLSTART
-#define RT_GATHER_CELLSTART 1  // 1: a query inside the density grid starts its tree walk at its cell's start node (DevPhotonMap::cell_start)
-#endif
-#ifndef RT_GATHER_SPARSE
-#define RT_GATHER_SPARSE 1     // 1: a query whose cell last saw no more than k photons inside the full radius sums everything in one plain pass
-                               // (no histogram, no ring, no selection); the normal path runs after it if more than k turn up
-#endif
 #ifndef RT_GATHER_CELL_GUESS
 #define RT_GATHER_CELL_GUESS RT_GATHER_GUESS    // first trial radius^2 of a query whose cell remembers a k-th distance: that distance times this
 #endif
-#if RT_GATHER_FMA
+// the photon loop of k_gather may contract mul+add into fma (d^2, dir.N, box distances, weighted sums; gate there: 2e-5); the rest of the
+// file stays uncontracted: hit records are bit-exact
 #define RT_FP_CONTRACT _Pragma("clang fp contract(fast)")
-#else
-#define RT_FP_CONTRACT
-#endif
 #ifndef RT_WF_PERWAVE
 #define RT_WF_PERWAVE 1        // 1: for the P12 model every wave of k_wavefront runs its own rounds on its own part of the LDS ray stack (no workgroup barriers); 0: the four waves always share stack and rounds
 #endif
@@ -322,7 +295,7 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
 {
     // the mesh record is the same for every lane: over the scalar cache (see cld), so that the array bases live in SGPRs
     DevMesh M;
-    M.nodes = cld(&Mp->nodes); M.tris = cld(&Mp->tris); M.tri_face = cld(&Mp->tri_face); M.nrm = cld(&Mp->nrm); M.tex = cld(&Mp->tex);
+    M.nodes = cld(&Mp->nodes); M.tris = cld(&Mp->tris); M.nrm = cld(&Mp->nrm); M.tex = cld(&Mp->tex);
     for (int i = 0; i < 6; i++) M.root_box[i] = cld(Mp->root_box + i);
     M.root_ref = cld(&Mp->root_ref);
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -380,24 +353,28 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
         if (cur == DONE) break;
         const uint32_t count = ((cur >> 28) & 7u) + 1;
         const uint32_t first = cur & 0x0FFFFFFFu;
+        // the next triangle of the leaf is fetched while this one is tested (one exposed round trip per leaf, not per triangle)
+        DevTri T = M.tris[first];
         for (uint32_t i = 0; i < count; i++) {
-            const DevTri T = M.tris[first + i];
+            DevTri Tn = T;
+            if (i + 1 < count) Tn = M.tris[first + i + 1];
             cnt.tris++;
             const bool h = (MODEL != RT_SHADE_FIN) ? tri_hit_p13(T, o, d, z, hp, bc, front)
                                                    : tri_hit_fin(T, o, d, z, hp, bc, front);
             if (h) { any = true; best_slot = first + i; }
+            T = Tn;
         }
         if (ANY && any) return true;
         cur = sp ? bvh_pop(stack, sp) : DONE;
     }
     if (!any) return false;
     // cyTriMesh::GetNormal = vn[fn0]*bc.x + vn[fn1]*bc.y + vn[fn2]*bc.z (cyTriMesh.h:167,191)
-    const float *n9 = M.nrm + 9 * (size_t)M.tri_face[best_slot];
+    const float *n9 = M.nrm + 9 * (size_t)best_slot;
     const V3 Ni = ld3(n9) * bc.x + ld3(n9 + 3) * bc.y + ld3(n9 + 6) * bc.z;
     hN = (MODEL != RT_SHADE_FIN) ? normalize(Ni) : Ni;     // FIN leaves it un-normalised (:262)
     // the PROJ13 triangle also sets uvw = GetTexCoord(face, bc) (P13/include/objects.h:203)
     if (MODEL != RT_SHADE_FIN && uvw && M.tex) {
-        const float *t9 = M.tex + 9 * (size_t)M.tri_face[best_slot];
+        const float *t9 = M.tex + 9 * (size_t)best_slot;
         *uvw = ld3(t9) * bc.x + ld3(t9 + 3) * bc.y + ld3(t9 + 6) * bc.z;
     }
     return true;
@@ -409,24 +386,7 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
 // ancestor in turn (scene.h:502-508; direction NOT renormalised, so t is shared by all spaces),
 // and the closest hit is brought back through FromNodeCoords of each ancestor (scene.h:509-513).
 // ------------------------------------------------------------------------------------------------
-#ifdef RT_EXP_WF_TIME           /* tuning build: instance_visits = wave kilo-cycles in closest-hit traces (x64), bvh_nodes = in any-hit (shadow) traces, tris = in shade_path as a whole */
-template <bool ANY, int MODEL, bool TEX>
-__device__ bool trace_impl(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, const BvhStack &stack, Counters &cnt);
 template <bool ANY, int MODEL, bool TEX = false>
-__device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, const BvhStack &stack, Counters &cnt)
-{
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    Counters dummy = {0, 0, 0, 0, 0};
-    const bool r = trace_impl<ANY, MODEL, TEX>(S, o, d, zinit, h, stack, dummy);
-    const uint32_t dt = (uint32_t)((__builtin_readcyclecounter() - t0) >> 6);
-    if (ANY) cnt.nodes += dt; else cnt.inst += dt;
-    return r;
-}
-#define trace trace_impl
-template <bool ANY, int MODEL, bool TEX>
-#else
-template <bool ANY, int MODEL, bool TEX = false>
-#endif
 __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, const BvhStack &stack, Counters &cnt)
 {
     float z = zinit;
@@ -513,19 +473,32 @@ __device__ bool trace(const DevScene &S, V3 o, V3 d, float zinit, Hit &h, const 
         }
     }
     if (best < 0) return false;
-    const DevObject &ob = S.objects[best];
     h.uvw = uvw;
-    for (int c = ob.chain_len - 1; c >= 0; c--) {
-        const DevNodeXf &X = S.nodes[ob.chain[c]];
+    // Node::FromNodeCoords (scene.h:509-513) level by level, the object's own node first.  The levels below the root come inline
+    // with the object's DevObjectBack record (addresses depend on `best` alone: one round trip); the root's over the scalar cache.
+    const DevObjectBack *ob = S.objects_back + best;
+    const int len = ob->chain_len;
+    auto from_node = [&](const DevNodeXf &X) {
         bp = mmul(X.tm, bp) + ld3(X.pos);
         bN = normalize(mtmul(X.itm, bN));
+    };
+    const int inl = min(len - 1, RT_BACK_LEVELS);            // levels held inline (all but the root, up to RT_BACK_LEVELS)
+#pragma unroll
+    for (int k = 0; k < RT_BACK_LEVELS; k++) if (k < inl) from_node(ob->lvl[k]);
+    if (len - 1 > RT_BACK_LEVELS) {                          // a deeper chain: the levels between, through the object's chain
+        const DevObject &o2 = S.objects[best];
+        for (int c = len - 1 - RT_BACK_LEVELS; c >= 1; c--) from_node(S.nodes[o2.chain[c]]);
     }
-    h.z = z; h.p = bp; h.N = bN; h.node = ob.node; h.front = bfront;
+    {
+        const DevNodeXf *R = S.nodes;                        // chain[0] is the root for every object
+        const M9 tm = cld9(R->tm), itm = cld9(R->itm);
+        const V3 pos = cld3(R->pos);
+        bp = mmul(tm.m, bp) + pos;
+        bN = normalize(mtmul(itm.m, bN));
+    }
+    h.z = z; h.p = bp; h.N = bN; h.node = ob->node; h.front = bfront;
     return true;
 }
-#ifdef RT_EXP_WF_TIME
-#undef trace
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // Counter-based random numbers for the stochastic effects.  The reference calls
@@ -1424,12 +1397,7 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
         in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0; in.spec = 0;
         in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
         if (active) {
-#ifdef RT_BOUNCE_SCRAMBLE          /* experiment: destroy the queue's coherence inside 64 Ki-ray windows */
-            uint32_t src = gid;
-            if ((gid | 65535u) < total) src = (gid & ~65535u) | ((gid * 40503u) & 65535u);
-#else
             const uint32_t src = gid;
-#endif
             const float4 a = qin.a[src], b = qin.b[src], c = qin.c[src];
             const uint4 dd = qin.d[src];
             in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
@@ -1584,23 +1552,10 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
             }
         }
         wsync();                                          // the count is settled before this round's pushes
-#ifdef RT_EXP_WF_TIME
-        const unsigned long long xt0 = __builtin_readcyclecounter();
-#endif
         shade_path<MODEL, TEX>(C, in, active, stack, cnt);
-#ifdef RT_EXP_WF_TIME
-        cnt.tris += (uint32_t)((__builtin_readcyclecounter() - xt0) >> 6);
-        cnt.shadow = 0;
-#endif
     }
     flush_counters(C.W.stats, cnt, nprim, nrefl, nrefr);
   } else {
-#ifdef RT_EXP_WF_TIME           /* rays_shadow = wave kilo-cycles (x64) spent at the workgroup barriers of the round loop */
-    uint32_t xbar = 0;
-#define XSYNC() do { const unsigned long long b0_ = __builtin_readcyclecounter(); __syncthreads(); xbar += (uint32_t)((__builtin_readcyclecounter() - b0_) >> 6); } while (0)
-#else
-#define XSYNC() __syncthreads()
-#endif
     const BvhStack stack = bvh_stack(s_stack, Cfg::BVH, C.S.bvh_spill);
     Counters cnt = {0, 0, 0, 0, 0};
     uint32_t nprim = 0, nrefl = 0, nrefr = 0;
@@ -1617,7 +1572,7 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
     C.lds_a = s_qa; C.lds_b = s_qb; C.lds_c = s_qc; C.lds_count = &s_count; C.lds_cap = Cfg::STACK;
     bool more_primaries = true;                           // workgroup-uniform
     for (;;) {
-        XSYNC();                                  // last round's pushes are complete
+        __syncthreads();                                  // last round's pushes are complete
         const uint32_t packed = s_count;
         const uint32_t w0 = packed & 0xFFFFu, w1 = packed >> 16;
         const uint32_t pside = w1 > w0 ? 1u : 0u;         // the fuller side is popped
@@ -1627,7 +1582,7 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
         // per-level launches, the slow path (measured: 5 ms per Cornell frame before this rule)
         const bool pop = waiting >= (uint32_t)Cfg::POP || (!more_primaries && waiting > 0);
         if (!pop && !more_primaries) break;
-        XSYNC();                                  // everyone has read s_count
+        __syncthreads();                                  // everyone has read s_count
         PathIn in;
         bool active;
         if (pop) {
@@ -1656,11 +1611,11 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
                 if (C.S.stochastic || MODEL == RT_SHADE_P12) in.sample = sample_of_slot(C.sm, in.slot);     // P12 draws its hemisphere rays
                 if (in.kind == KIND_REFLECT) nrefl++; else nrefr++;
             }
-            XSYNC();                              // all pops read before anything is pushed over them
+            __syncthreads();                              // all pops read before anything is pushed over them
             if (threadIdx.x == 0) s_count = packed - (n << (16u * pside));
         } else {
             if (threadIdx.x == 0) s_batch = atomicAdd(next_batch, 1u);
-            XSYNC();
+            __syncthreads();
             const unsigned long long batch = s_batch;
             if (batch >= n_batches) { more_primaries = false; continue; }
             if (A.mode == 3) {
@@ -1682,15 +1637,8 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
                 if (active) nprim++;
             }
         }
-        XSYNC();                                  // s_count settled before this round's pushes
-#ifdef RT_EXP_WF_TIME
-        const unsigned long long xt0 = __builtin_readcyclecounter();
-#endif
+        __syncthreads();                                  // s_count settled before this round's pushes
         shade_path<MODEL, TEX>(C, in, active, stack, cnt);
-#ifdef RT_EXP_WF_TIME
-        cnt.tris += (uint32_t)((__builtin_readcyclecounter() - xt0) >> 6);
-        cnt.shadow = xbar;
-#endif
     }
     flush_counters(C.W.stats, cnt, nprim, nrefl, nrefr);
   }
@@ -2054,16 +2002,13 @@ __device__ __forceinline__ float box_dist2(const float4 *b, float px, float py, 
 // only the compiler has to be kept from reordering, plus a wait for outstanding LDS returns.
 __device__ __forceinline__ void wave_sync()
 {
-#ifndef RT_GATHER_SYNC_SCOPE
-#define RT_GATHER_SYNC_SCOPE "wavefront"
-#endif
     // "wavefront" scope: the hardware already executes one wave's LDS instructions in issue order, so a write by one lane is
     // seen by a later read of another lane of the SAME wave without waiting for anything; the fences only keep the compiler
     // from moving LDS accesses across this point.  ("workgroup" scope made every one of the ~10 hand-offs per query an
     // s_waitcnt vmcnt(0) lgkmcnt(0): it also drained the photon loads in flight.)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, RT_GATHER_SYNC_SCOPE);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, RT_GATHER_SYNC_SCOPE);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 struct GatherLds {
@@ -2073,12 +2018,10 @@ struct GatherLds {
         uint32_t hist[256];                              //   the distance-key histogram while the k-th photon's bin is located
         struct { float sel_d[64]; uint32_t sel_i[64]; uint32_t sel_n; };   //   then that bin's photons for the exact rank selection
     };
-#if RT_GATHER_RING
     // everything pass 1 read about a photon whose distance lies in the band around the predicted k-th one,
     // so that the exact selection does not have to read the leaves a second time
     float4   ring_a[RT_GATHER_RING];      // d2, dir.x, dir.y, dir.z
     float2   ring_b[RT_GATHER_RING];      // max power, colour bytes
-#endif
 };
 
 // Color24 -> Color (cyColor.h): byte / 255.0f, correctly rounded, without the ~10-instruction IEEE division and without
@@ -2136,38 +2079,8 @@ __device__ __forceinline__ void scan_subleaves(const DevPhotonMap &pm, const uin
         const uint32_t off = (mine[RT_SUBS_PER_STEP * it] * (RT_SUB_PHOTONS * 16u)) | lane_off;   // < 2^32: checked at upload
         slot = off;
         a = *(const float4 *)(pa + off);
-#ifdef RT_EXP_HALFLOAD          /* cost attribution build: the second 16 bytes of a photon are not read (made up from the first); results are garbage */
-        b = make_float4(a.x * 0.001f, -0.5f, 1.0e-6f, __uint_as_float(0x00808080u));
-#else
         b = *(const float4 *)(pb + off);
-#endif
     };
-#if RT_GATHER_AHEAD == 0
-    for (uint32_t it = 0; it < n_iter; it++) {
-        float4 a, b; uint32_t sl;
-        ld(it, a, b, sl);
-        f(make_cand(a, b, Q), sl);
-    }
-#elif RT_GATHER_AHEAD == 2
-    // three register sets in rotation: two steps in flight while one is processed; reload indices are clamped (the last
-    // step may be fetched again) instead of branched over
-    float4 a0, b0, a1, b1, a2, b2;
-    uint32_t s0, s1, s2;
-    const uint32_t last = n_iter - 1;
-    ld(0u, a0, b0, s0);
-    ld(min(1u, last), a1, b1, s1);
-    uint32_t it = 0;
-    for (; it + 2 < n_iter; it += 3) {
-        ld(it + 2, a2, b2, s2);
-        f(make_cand(a0, b0, Q), s0);
-        ld(min(it + 3, last), a0, b0, s0);
-        f(make_cand(a1, b1, Q), s1);
-        ld(min(it + 4, last), a1, b1, s1);
-        f(make_cand(a2, b2, Q), s2);
-    }
-    if (it < n_iter) f(make_cand(a0, b0, Q), s0);
-    if (it + 1 < n_iter) f(make_cand(a1, b1, Q), s1);
-#else
     // two register sets used alternately, each refilled right after it was consumed; the reload index
     // is clamped instead of branched over (the last step may be fetched twice) so that neither set
     // is a loop-carried copy of the other
@@ -2182,28 +2095,17 @@ __device__ __forceinline__ void scan_subleaves(const DevPhotonMap &pm, const uin
         f(make_cand(a1, b1, Q), s1);
     }
     if (it < n_iter) f(make_cand(a0, b0, Q), s0);
-#endif
 }
 
 #ifndef RT_GATHER_WAVES_PER_EU
 #define RT_GATHER_WAVES_PER_EU 5     // 96 registers: five waves per SIMD is what the LDS footprint allows too
 #endif
-#if RT_GATHER_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(RT_GATHER_WAVES_PER_EU, RT_GATHER_WAVES_PER_EU)))
-#endif
 __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
 {
     __shared__ GatherLds lds_all[RT_GATHER_WAVES];
     GatherLds &L = lds_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
-#if RT_GATHER_LUT
-    __shared__ float s_lut[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_lut[i] = byte_over_255((uint32_t)i);
-    __syncthreads();
-#define BYTE_OVER_255(c) s_lut[c]
-#else
-#define BYTE_OVER_255(c) byte_over_255(c)
-#endif
     uint32_t nq = *G.count_ptr;
     if (nq > G.count_cap) nq = G.count_cap;
     if (nq == 0) return;                                 // most chunks of a frame see no photon query at all
@@ -2213,23 +2115,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     const uint32_t K = (uint32_t)G.k;
     unsigned long long visited = 0;
     uint32_t n_rounds = 0, n_slow = 0, n_reads = 0;       // wave-uniform tallies
-#ifdef RT_EXP_COUNT_FALLBACK2
-    uint32_t x_below = 0, x_above = 0, x_other = 0, x_mk = 0;
-#endif
     float pred_rk2 = 0.0f;                                // k-th squared distance of this wave's previous query (a hint only)
-#ifdef RT_EXP_TIME_PHASEA
-    unsigned long long xa_total = 0, xa_fullsum = 0;
-    const unsigned long long xa_start = __builtin_readcyclecounter();
-#endif
-#ifdef RT_EXP_TIME_PARTS        /* tuning build: wave cycles per part of phase B, /1024: =1: visited = sub-leaf listing, leaf_reads = pass 1 (or the plain pass), slow = everything after pass 1 of a query; =2: visited = the k-th bin search, leaf_reads = ring scan or pass 2, slow = selection + wave sums; rounds = the kernel */
-    unsigned long long xp0 = 0, xp1 = 0, xp2 = 0, xpt = 0;
-    const unsigned long long xp_start = __builtin_readcyclecounter();
-#define XP_MARK() (xpt = __builtin_readcyclecounter())
-#define XP_ADD(which, v) do { if (RT_EXP_TIME_PARTS == (which)) { const unsigned long long n_ = __builtin_readcyclecounter(); (v) += n_ - xpt; xpt = n_; } } while (0)
-#else
-#define XP_MARK() ((void)0)
-#define XP_ADD(which, v) ((void)0)
-#endif
 
     // batches of RT_GATHER_BATCH queries are handed out dynamically (one atomic per batch): query cost varies by
     // two orders of magnitude with the local photon density, so a static split leaves a long tail
@@ -2270,39 +2156,29 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
         // first trial radius from the density grid: about RT_GATHER_GUESS * k photons expected inside (count ~ r^2
         // on a surface through a cell of side h: c photons per h^2)
         float r2cur = r2;
-        float cell_pred = 0.0f;                              // this lane's query: what its grid cell remembers (RT_GATHER_CELLPRED)
+        float cell_pred = 0.0f;                              // this lane's query: what its grid cell remembers
         uint32_t cell_index = 0;
-        uint32_t walk_start = 1;                             // where this lane's query starts its tree walk (RT_GATHER_CELLSTART)
+        uint32_t walk_start = 1;                             // where this lane's query starts its tree walk (DevPhotonMap::cell_start)
         if (have && n_leaves > 1) {
             const float fx = (a.x - G.pm.grid_min[0]) * G.pm.inv_cell, fy = (a.y - G.pm.grid_min[1]) * G.pm.inv_cell, fz = (a.z - G.pm.grid_min[2]) * G.pm.inv_cell;
             const int gx = min(max((int)fx, 0), G.pm.grid_dim[0] - 1);
             const int gy = min(max((int)fy, 0), G.pm.grid_dim[1] - 1);
             const int gz = min(max((int)fz, 0), G.pm.grid_dim[2] - 1);
             cell_index = (uint32_t)(((size_t)gz * G.pm.grid_dim[1] + gy) * G.pm.grid_dim[0] + gx);
-#if RT_GATHER_CELLSTART
             // only for a point that really lies in its cell (points outside the photons' bounding box are clamped to the rim)
             const bool in_grid = fx >= 0.0f && fy >= 0.0f && fz >= 0.0f && (int)fx == gx && (int)fy == gy && (int)fz == gz;
             if (G.pm.cell_start && in_grid && G.radius <= G.pm.start_radius) walk_start = G.pm.cell_start[cell_index];
-#endif
             const uint32_t cnt = G.pm.grid[cell_index];
             r2cur = fminf(fmaxf(guess_c / (float)(cnt > 0u ? cnt : 1u), r2 * 1.0e-4f), r2);
-#if RT_GATHER_CELLPRED
             if (G.cell_rk2) {
                 cell_pred = G.cell_rk2[cell_index];
                 // a cell that has seen a query also knows a better first radius than the density estimate: a little above its k-th distance
                 if (cell_pred > 0.0f) r2cur = fminf(fmaxf(cell_pred * RT_GATHER_CELL_GUESS, r2 * 1.0e-4f), r2);
-#if RT_GATHER_SPARSE
                 else if (cell_pred < 0.0f) r2cur = r2;       // "sparse here": the full radius at once
-#endif
             }
-#endif
         }
 
         while (ballot64(pending)) {
-#ifdef RT_EXP_TIME_PHASEA       /* tuning build: wave cycles spent in phase A (visited), of them in batches with a full-radius query (leaf_reads), and in the kernel (rounds), in units of 1024 cycles */
-            const unsigned long long xa0 = __builtin_readcyclecounter();
-            const bool xa_full = ballot64(pending && r2cur >= r2) != 0;
-#endif
             // ---------------- phase A: pending lanes list the leaves inside their trial radius ----
             // Two lanes walk for one query: lane l and lane l + 32 hold the same point and radius, keep the same walk state
             // and split the box tests of every visit between them (grandchildren 0-1 / 2-3, child 0 / 1); one
@@ -2371,12 +2247,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 }
             }
             wave_sync();
-#ifdef RT_EXP_TIME_PHASEA
-            { const unsigned long long dt = __builtin_readcyclecounter() - xa0; xa_total += dt; if (xa_full) xa_fullsum += dt; }
-#endif
-#ifdef RT_EXP_PHASEA            /* cost attribution build: phase A only, results are garbage */
-            pending = false;
-#endif
             // ---------------- phase B: the wave takes the pending queries one by one --------------
             unsigned long long todo = ballot64(pending);
             while (todo) {
@@ -2397,7 +2267,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 const uint32_t dummy_sub = n_sub_total;    // one more sub-leaf after the real ones, every slot empty
                 uint32_t n_sub = 0;
                 wave_sync();                               // the previous query's passes are done with L.subs
-                XP_MARK();
                 if (!slow) {
                     for (uint32_t base = 0; base < qnl * RT_LEAF_SUBS; base += 64u) {
                         const uint32_t e = base + (uint32_t)lane;
@@ -2419,7 +2288,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     }
                 }
                 n_rounds++; n_slow += slow ? 1u : 0u; n_reads += n_sub;
-                XP_ADD(1, xp0);
                 // run one pass over the query's sub-leaves
                 auto for_each = [&](auto &&f) {
                     if (!slow) { scan_subleaves(G.pm, L.subs, n_sub, lane, Q, f); return; }
@@ -2437,25 +2305,13 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     }
                 };
                 float s_pr = 0, s_pg = 0, s_pb = 0, s_dx = 0, s_dy = 0, s_dz = 0;   // pass 1: sums over ALL candidates
-#ifdef RT_EXP_LOADONLY          /* cost attribution build: phase A + the leaf reads, nothing else; results are garbage */
-                for_each([&](const Cand &cd, uint32_t) { s_pr += cd.pa.x + cd.pb.x; });
-                visited += n_sub;
-                if (G.mode == 1 && s_pr == 12345.678f && lane == 0) G.out_irr[0] = s_pr;
-                if (lane == q) pending = false;
-                continue;
-#endif
                 // sum of power (GetPower = Color24 -> Color times power) and of dir * maxPower for one photon
                 // (branch-free variant: take == false adds exact zeros; measured slower than the branch)
                 auto accumulate5 = [&](float dirx, float diry, float dirz, float maxp, uint32_t cbits, bool take) {
                     RT_FP_CONTRACT
-#ifdef RT_EXP_NOACC             /* cost attribution build: no summation; results are garbage */
-                    return;
-#endif
-#if RT_GATHER_BRANCHY
                     if (!take) return;
-#endif
                     const float mp = take ? maxp : 0.0f;
-                    s_pr += BYTE_OVER_255(cbits & 255u) * mp; s_pg += BYTE_OVER_255((cbits >> 8) & 255u) * mp; s_pb += BYTE_OVER_255((cbits >> 16) & 255u) * mp;
+                    s_pr += byte_over_255(cbits & 255u) * mp; s_pg += byte_over_255((cbits >> 8) & 255u) * mp; s_pb += byte_over_255((cbits >> 16) & 255u) * mp;
                     s_dx += dirx * mp; s_dy += diry * mp; s_dz += dirz * mp;
                 };
                 auto accumulate = [&](const float4 &pa, const float4 &pb, bool take) { accumulate5(pa.w, pb.x, pb.y, pb.z, __float_as_uint(pb.w), take); };
@@ -2463,7 +2319,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 uint32_t M = 0;                            // accepted photons (wave-uniform: popcount of the ballots)
                 float area_d2 = rq2;
                 bool done_plain = false;
-#if RT_GATHER_SPARSE && RT_GATHER_CELLPRED && !defined(RT_EXP_LOADONLY)
                 // "Sparse here": the cell's last query found no more than k photons inside the FULL radius.  Then all accepted
                 // photons count and dist2[0] stays radius^2 (cyPhotonMap.h:309-326): one plain pass sums them -- no histogram, no ring,
                 // no selection.  If more than k turn up after all, the sums are dropped and the normal path below does the query.
@@ -2473,11 +2328,9 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         accumulate(cd.pa, cd.pb, cd.d2 < rq2);
                     });
                     visited += n_sub;
-                    XP_ADD(1, xp1); XP_MARK();
                     if (M <= K) done_plain = true;
                     else { M = 0; s_pr = s_pg = s_pb = s_dx = s_dy = s_dz = 0; n_reads += n_sub; }
                 }
-#endif
                 if (!done_plain) {
                 *(uint4 *)&L.hist[4 * lane] = make_uint4(0u, 0u, 0u, 0u);     // the 256 bins in one 16-byte store per lane
                 wave_sync();
@@ -2487,10 +2340,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                 // The histogram bin is the top 8 bits of the 24-bit key: (uint)(d2 * kscale) >> 16 == (uint)(d2 * (kscale / 65536)),
                 // the scaling by a power of two being exact.
                 const float kscale_bin = Q.kscale * (1.0f / 65536.0f);
-#if RT_GATHER_RING
-#if RT_GATHER_CELLPRED
                 { const float cp = lane_f(cell_pred, q); if (cp > 0.0f) pred_rk2 = cp; }
-#endif
                 const float pk = (pred_rk2 > 0.0f && pred_rk2 < rq2) ? pred_rk2 : rq2 * (1.0f / RT_GATHER_GUESS);
                 const float t_lo = RT_GATHER_BAND_LO * pk;
                 const float t_hi = final_round ? rq2 : fminf(RT_GATHER_BAND_HI * pk, rq2);     // <= rq2: inside the band implies accepted
@@ -2513,20 +2363,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         n_ring += (uint32_t)__popcll(mr);
                     }
                 });
-#else
-                for_each([&](const Cand &cd, uint32_t) {
-                    accumulate(cd.pa, cd.pb, cd.d2 < rq2);
-                    M += (uint32_t)__popcll(ballot64(cd.d2 < rq2));
-                    if (cd.d2 < rq2) atomicAdd(&L.hist[(uint32_t)(cd.d2 * kscale_bin)], 1u);
-                });
-#endif
                 visited += n_sub;
-                XP_ADD(1, xp1); XP_MARK();
-#ifdef RT_EXP_PASS1ONLY         /* cost attribution build: nothing after pass 1; results are garbage */
-                if (G.mode == 1 && s_pr == 12345.678f && lane == 0) G.out_irr[0] = s_pr + (float)M + (float)n_ring;
-                if (lane == q) pending = false;
-                continue;
-#endif
                 if (!final_round && M <= K) {
                     // not enough inside the trial radius: grow it (count ~ r^2 on a surface) and retry
                     float grow = 1.5f * (float)K / (float)(M > 0 ? M : 1u);
@@ -2535,11 +2372,7 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     continue;
                 }
                 area_d2 = rq2;                             // dist2[0]; only reached with rq2 == r2 when M <= K
-#ifdef RT_EXP_NOSELECT          /* cost attribution build: no bin search, ring, selection or fallback pass; results are garbage */
-                if (false) {
-#else
                 if (M > K) {
-#endif
                     // ---- locate the k-th smallest: refine 8 bits of the key per level --------------
                     uint32_t need = K;                     // rank (1-based) inside the current range
                     uint32_t prefix = 0;                   // key bits fixed so far
@@ -2579,14 +2412,12 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         });
                     }
                     const uint32_t bin_mask = ~((1u << shift) - 1u) & 0xFFFFFFu;
-                    XP_ADD(2, xp0);
                     wave_sync();                           // the histogram is dead from here on: its LDS now holds the selection
                     if (lane == 0) L.sel_n = 0;
                     wave_sync();
                     uint32_t tie_taken = 0;                // only used when in_bin > 64 (identical keys)
                     float tmax = 0.0f;
                     bool from_ring = false;
-#if RT_GATHER_RING
                     {
                         // The ring serves the selection when (1) it did not overflow, (2) the k-th photon's bin was
                         // resolved at the first level, (3) every photon below t_lo lies in an earlier bin (so all of
@@ -2619,23 +2450,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                             accumulate5(ra.y, ra.z, ra.w, rb.x, __float_as_uint(rb.y), take);
                         }
                     }
-#endif
-#ifdef RT_EXP_COUNT_FALLBACK2   /* tuning build: why the ring could not serve a query: rounds = k-th bin at or below the band's lower bin, slow = at or above
-                                   its upper bin, leaf_reads (x RT_SUB_PHOTONS / 32) = ring overflow or unresolved bin; visited = queries with M > K */
-                    {
-                        const uint32_t bin_lo2 = (uint32_t)(t_lo * Q.kscale) >> 16, bin_hi2 = (uint32_t)(t_hi * Q.kscale) >> 16, kbin2 = prefix >> 16;
-                        if (!from_ring) {
-                            if (n_ring > (uint32_t)RT_GATHER_RING || shift != 16 || in_bin > 64u) x_other++;
-                            else if (!(bin_lo2 < kbin2)) x_below++;
-                            else x_above++;
-                        }
-                        x_mk++;
-                    }
-#endif
-#ifdef RT_EXP_COUNT_FALLBACK    /* tuning build: ST_GATHER_SLOW counts fallbacks by ring overflow, ST_GATHER_ROUNDS the other fallbacks */
-                    n_rounds--;
-                    if (!from_ring) { if (n_ring > (uint32_t)RT_GATHER_RING) n_slow++; else n_rounds++; }
-#endif
                     if (!from_ring) {
                     n_reads += n_sub;
                     // ---- pass 2: sum everything below the bin, collect the bin, select `need` of it ----
@@ -2666,7 +2480,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         accumulate(cd.pa, cd.pb, take);
                     });
                     }
-                    XP_ADD(2, xp1);
                     wave_sync();
                     if (in_bin <= 64u) {
                         // exact selection: rank by (d2, list position); take ranks < need
@@ -2680,13 +2493,11 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         }
                         if (mine && rank < need) {
                             const uint32_t si = L.sel_i[lane];
-#if RT_GATHER_RING
                             if (from_ring) {
                                 const float4 ra = L.ring_a[si];
                                 const float2 rb = L.ring_b[si];
                                 accumulate5(ra.y, ra.z, ra.w, rb.x, __float_as_uint(rb.y), true);
                             } else
-#endif
                                 accumulate(*(const float4 *)((const char *)G.pm.pa + si), *(const float4 *)((const char *)G.pm.pb + si), true);   // si: byte offset of the slot
                             tmax = md;
                         }
@@ -2694,7 +2505,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     area_d2 = wave_max0(tmax);                        // np.dist2[0] = largest kept distance
                     pred_rk2 = area_d2;
                 }
-#if RT_GATHER_RING && !defined(RT_EXP_NOSELECT)
                 else if (M > 0) {
                     // at most k inside the full radius: all of them count.  Pass 1 summed those below t_lo and, in the
                     // final round, parked every other one in the ring; if that overflowed, sum them with one more pass
@@ -2713,7 +2523,6 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         for_each([&](const Cand &cd, uint32_t) { accumulate(cd.pa, cd.pb, cd.d2 < rq2); });
                     }
                 }
-#endif
                 }
                 // the query is done: its six sums and r_k^2 go to ITS lane; what follows from them (area, normalisation, the
                 // weighted add into the sample) is the same scalar arithmetic for every query, so it is done for all the
@@ -2728,20 +2537,15 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                         pending = false;
                     }
                 }
-                XP_ADD(1, xp2); XP_ADD(2, xp2);
             }
             if (finish) {
                 float irr_r = f_pr, irr_g = f_pg, irr_b = f_pb, dx = f_dx, dy = f_dy, dz = f_dz;
-#if RT_GATHER_CELLPRED
                 // remember the k-th distance for the next query of this cell (only when more than k qualified: f_area < r2)
                 // (or that no more than k were inside the full radius: f_area is then radius^2, or negative without any photon)
                 if (G.cell_rk2 && n_leaves > 1) {
                     if (f_area > 0.0f && f_area < r2) G.cell_rk2[cell_index] = f_area;
-#if RT_GATHER_SPARSE
                     else if (r2cur >= r2) G.cell_rk2[cell_index] = -1.0f;
-#endif
                 }
-#endif
                 if (f_area >= 0.0f) {
                     const float area = (float)M_PI * f_area;               // :326
                     if (area > 0) { const float inv = 1.0f / area; irr_r *= inv; irr_g *= inv; irr_b *= inv; }
@@ -2759,28 +2563,15 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
                     float theta = nx * (-dx) + ny * (-dy) + nz * (-dz);
                     theta = theta > 0.0f ? theta : 0.0f;
                     float *dst = G.sample_rgb + 3 * (size_t)slot;
-#ifdef RT_EXP_NOATOMIC          /* cost attribution build: the result is stored once per batch instead of added per query; results are garbage */
-                    if (slot == 0xFFFFFFFFu) dst[0] = (wr * irr_r) * theta + (wg * irr_g) * theta + (wb * irr_b) * theta;
-#else
                     atomicAdd(dst, (wr * irr_r) * theta);
                     atomicAdd(dst + 1, (wg * irr_g) * theta);
                     atomicAdd(dst + 2, (wb * irr_b) * theta);
-#endif
                 }
                 finish = false;
             }
             wave_sync();
         }
     }
-#ifdef RT_EXP_TIME_PARTS
-    visited = (xp0 >> 10) / RT_SUB_PHOTONS; n_reads = (uint32_t)((xp1 >> 10) * 32u / RT_SUB_PHOTONS); n_slow = (uint32_t)(xp2 >> 10); n_rounds = (uint32_t)((__builtin_readcyclecounter() - xp_start) >> 10);
-#endif
-#ifdef RT_EXP_TIME_PHASEA
-    visited = (xa_total >> 10) / RT_SUB_PHOTONS; n_reads = (uint32_t)((xa_fullsum >> 10) * 32u / RT_SUB_PHOTONS); n_rounds = (uint32_t)((__builtin_readcyclecounter() - xa_start) >> 10);
-#endif
-#ifdef RT_EXP_COUNT_FALLBACK2
-    n_rounds = x_below; n_slow = x_above; n_reads = x_other * 32u / RT_SUB_PHOTONS; visited = x_mk; 
-#endif
     if (lane == 0 && G.stats && visited) {
         atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * (unsigned long long)RT_SUB_PHOTONS);
         atomicAdd(&G.stats[ST_GATHER_ROUNDS], (unsigned long long)n_rounds);

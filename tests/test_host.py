@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.lib()
     for name in declared:
         assert getattr(lib, name)
-    assert lib.rt_abi_version() == 3
+    assert lib.rt_abi_version() == 4
 
 
 def test_struct_sizes_match_header():
