@@ -2652,45 +2652,55 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
         const uint8_t *hitf = W.sample_hit + (size_t)ql * A.max_sample;
         const float *zs = W.sample_z + (size_t)ql * A.max_sample;
         const int ns = A.phase == 1 ? A.max_sample : A.min_sample;
-        // the hit flags of the pixel's samples (bytes 0 / 1): with rows of a multiple of 16 bytes they are read as 16-byte words
-        // and packed into one 64-bit mask (four loads instead of one byte load per sample and pass)
-        const bool packed_hits = (A.max_sample & 15) == 0 && ns <= 64;
-        unsigned long long hmask = 0;
-        if (packed_hits) {
-            const uint4 *h4 = (const uint4 *)hitf;
-            for (int t = 0; 16 * t < ns; t++) {
-                const uint4 w = h4[t];
-                const uint32_t b16 = (((w.x & 0x01010101u) * 0x01020408u) >> 24) | ((((w.y & 0x01010101u) * 0x01020408u) >> 24) << 4) |
-                                     ((((w.z & 0x01010101u) * 0x01020408u) >> 24) << 8) | ((((w.w & 0x01010101u) * 0x01020408u) >> 24) << 12);
-                hmask |= (unsigned long long)(b16 & 0xFFFFu) << (16 * t);
-            }
-            if (ns < 64) hmask &= (1ull << ns) - 1ull;
-        }
-        auto hit_at = [&](int j) { return packed_hits ? (bool)((hmask >> j) & 1ull) : hitf[j] != 0; };
-        int n = 0;
-        float hitz = 0;
-        if (packed_hits) { n = __popcll(hmask); if (hmask) hitz = zs[63 - __clzll((long long)hmask)]; }
-        else { int last = -1; for (int j = 0; j < ns; j++) if (hitf[j]) { n++; last = j; } if (last >= 0) hitz = zs[last]; }
-        // visit(j, r, g, b) for the hit samples in order, from LDS tiles (staged) or straight from memory
-        auto for_hit_samples = [&](auto &&visit) {
-            if (staged) {
-                const float *wave_rgb = W.sample_rgb + 3 * (size_t)i0 * A.max_sample;
-                for (int t0 = 0; t0 < ns; t0 += RT_RESOLVE_TILE) {
-                    const int tn = min(RT_RESOLVE_TILE, ns - t0);              // samples in this tile
-                    const int run = 3 * tn;                                     // floats per pixel
-                    __builtin_amdgcn_wave_barrier();
-                    for (int k = lane; k < 64 * run; k += 64) {
-                        const int pix = k / run, off = k - pix * run;
-                        tile[pix * (3 * RT_RESOLVE_TILE + 1) + off] = wave_rgb[(size_t)pix * 3 * A.max_sample + 3 * t0 + off];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const float *mine = tile + lane * (3 * RT_RESOLVE_TILE + 1);
-                    for (int j = 0; j < tn; j++) if (hit_at(t0 + j)) visit(mine[3 * j], mine[3 * j + 1], mine[3 * j + 2]);
+        // the hit flags of the pixel's samples (bytes 0 / 1), 64 samples at a time: with rows of a multiple of 16 bytes they are read as
+        // 16-byte words and packed into a 64-bit mask (four loads instead of one byte load per sample and pass)
+        const bool packed_hits = (A.max_sample & 15) == 0;
+        const int nblk = (ns + 63) >> 6;
+        auto block_mask = [&](int b) -> unsigned long long {                  // samples [64 b, 64 b + 64) of this pixel, clipped to ns
+            const int base = 64 * b, cnt = min(64, ns - base);
+            unsigned long long m = 0;
+            if (packed_hits) {
+                const uint4 *h4 = (const uint4 *)(hitf + base);
+                for (int t = 0; 16 * t < cnt; t++) {
+                    const uint4 w = h4[t];
+                    const uint32_t b16 = (((w.x & 0x01010101u) * 0x01020408u) >> 24) | ((((w.y & 0x01010101u) * 0x01020408u) >> 24) << 4) |
+                                         ((((w.z & 0x01010101u) * 0x01020408u) >> 24) << 8) | ((((w.w & 0x01010101u) * 0x01020408u) >> 24) << 12);
+                    m |= (unsigned long long)(b16 & 0xFFFFu) << (16 * t);
                 }
             } else {
-                for (int j = 0; j < ns; j++) if (hit_at(j)) visit(rgb[3 * j], rgb[3 * j + 1], rgb[3 * j + 2]);
+                for (int j = 0; j < cnt; j++) if (hitf[base + j]) m |= 1ull << j;
+            }
+            if (cnt < 64) m &= (1ull << cnt) - 1ull;
+            return m;
+        };
+        int n = 0, last = -1;
+        for (int b = 0; b < nblk; b++) { const unsigned long long m = block_mask(b); n += __popcll(m); if (m) last = 64 * b + 63 - __clzll((long long)m); }
+        float hitz = 0;
+        if (last >= 0) hitz = zs[last];
+        // visit(r, g, b) for the hit samples in order, from LDS tiles (staged) or straight from memory
+        auto for_hit_samples = [&](auto &&visit) {
+            const float *wave_rgb = W.sample_rgb + 3 * (size_t)i0 * A.max_sample;
+            for (int b = 0; b < nblk; b++) {
+                const unsigned long long hm = block_mask(b);
+                const int base = 64 * b, cnt = min(64, ns - base);
+                if (staged) {
+                    for (int t0 = 0; t0 < cnt; t0 += RT_RESOLVE_TILE) {
+                        const int tn = min(RT_RESOLVE_TILE, cnt - t0);             // samples in this tile
+                        const int run = 3 * tn;                                     // floats per pixel
+                        __builtin_amdgcn_wave_barrier();
+                        for (int k = lane; k < 64 * run; k += 64) {
+                            const int pix = k / run, off = k - pix * run;
+                            tile[pix * (3 * RT_RESOLVE_TILE + 1) + off] = wave_rgb[(size_t)pix * 3 * A.max_sample + 3 * (base + t0) + off];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const float *mine = tile + lane * (3 * RT_RESOLVE_TILE + 1);
+                        for (int j = 0; j < tn; j++) if ((hm >> (t0 + j)) & 1ull) visit(mine[3 * j], mine[3 * j + 1], mine[3 * j + 2]);
+                    }
+                } else {
+                    for (int j = 0; j < cnt; j++) if ((hm >> j) & 1ull) visit(rgb[3 * (base + j)], rgb[3 * (base + j) + 1], rgb[3 * (base + j) + 2]);
+                }
             }
         };
         bool over = false;

@@ -151,6 +151,44 @@ def test_config5_stand_in_frame_and_full_size_properties():
     assert (acc_z == a_z).all() and (np.abs(acc_rgb.astype(int) - a_rgb.astype(int)) <= 1).all()
 
 
+def test_config5_stand_in_at_its_stated_256_samples_per_pixel(monkeypatch):
+    """BASELINE config 5 at its stated sample count -- 1920 x 1080 x 256 spp = 531 M samples, eight 64 Mi-sample chunks per
+    frame, a chunk count (and a sample count beyond the 64-entry Halton tables and the 64-bit hit masks of k_resolve) nothing
+    else exercises -- on every 16th tile of the frame (33 M samples): rendered in NINE chunks and in one, the two must be the
+    same image (a pixel does not depend on chunking); seeded blocks of it against the oracle at 256 spp; ray counts exact."""
+    from raytracing_folder_amd import workloads
+    s, cam = workloads.make_balls_scene(1920, 1080)
+    p = capi.default_params(min_sample=256, max_sample=256, threshold=-1.0)
+    tiles = capi.TileRange(32, 8, 5, 16)
+    monkeypatch.setenv("RT_CHUNK_SAMPLES", str(4 << 20))
+    a_rgb, a_z, a_cnt, a_st, a_prog = s.render(cam, p, tiles=tiles)
+    monkeypatch.delenv("RT_CHUNK_SAMPLES")
+    own = a_z != 0
+    n_tiles = len(range(5, 60 * 135, 16))
+    assert a_prog == own.sum() == n_tiles * 256 and a_st.rays_primary == 256 * int(own.sum())
+    import torch
+    dev = torch.device("cuda", 0)
+    rgb_t = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device=dev); z_t = torch.zeros((1080, 1920), dtype=torch.float32, device=dev)
+    cnt_t = torch.zeros((1080, 1920), dtype=torch.uint8, device=dev)
+    b_st = s.render_tiles_device(cam, p, tiles, 0, rgb_t.data_ptr(), z_t.data_ptr(), cnt_t.data_ptr())      # one 64 Mi-sample chunk
+    b_rgb, b_z = rgb_t.cpu().numpy(), z_t.cpu().numpy()
+    assert b_st.rays_primary == a_st.rays_primary and b_st.rays_shadow == a_st.rays_shadow and b_st.rays_reflect == a_st.rays_reflect
+    assert (a_z == b_z).all() and (np.abs(a_rgb.astype(int) - b_rgb.astype(int))[own] <= 1).all()
+    # the oracle on seeded 2 x 2 blocks of owned tiles (256 spp each)
+    e = s.export()
+    osc, ocam, op = scenes.oracle_scene(e), scenes.oracle_camera(cam), scenes.oracle_params(p)
+    rng = np.random.default_rng(256)
+    ys, xs = np.nonzero(own)
+    checked = 0
+    for i in rng.choice(len(ys), 6, replace=False):
+        x0, y0 = int(xs[i]) & ~1, int(ys[i]) & ~1
+        orgb, oz, _ = orc.render(osc, ocam, op, x0, y0, x0 + 2, y0 + 2)
+        assert (a_z[y0:y0 + 2, x0:x0 + 2] == oz[y0:y0 + 2, x0:x0 + 2]).all()
+        assert (np.abs(a_rgb[y0:y0 + 2, x0:x0 + 2].astype(int) - orgb[y0:y0 + 2, x0:x0 + 2].astype(int)) <= 1).all()
+        checked += 4
+    assert checked == 24
+
+
 def test_frame_that_overflows_the_lds_ray_stacks(cornell):
     """the camera looks at the glass sphere from close by, 32 samples per pixel: every ray of a workgroup's 256-sample
     round spawns a reflection and a refraction, so the 704-ray LDS stacks of k_wavefront overflow into the global queue
