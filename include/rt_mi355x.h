@@ -342,6 +342,11 @@ rt_status rt_photon_balance(rt_photon *in, uint32_t n, rt_photon *out);
  * paths of those slots only (about 2n element visits); `in` is not modified.  raw_indices (1-based, ascending) needs room
  * for 4; *count receives how many there are. */
 rt_status rt_photon_unreachable(const rt_photon *in, uint32_t n, uint32_t *raw_indices, uint32_t cap, uint32_t *count);
+/* ABI 4: the same search ON THE DEVICE (what rt_scene_generate_photons runs: the root paths of those heap slots are followed with
+ * radix selects, the photons never leave HBM).  *exact = 0 when the key of some median on those paths is not unique in its
+ * segment -- then the reference's swap sequence decides which photon lands where, and only rt_photon_unreachable (the host's
+ * replay of BalanceSegment, FIN/include/cyPhotonMap.h:222-284) gives the answer; *count is 0 in that case. */
+rt_status rt_photon_unreachable_device(int device, const rt_photon *in, uint32_t n, uint32_t *raw_indices, uint32_t cap, uint32_t *count, int32_t *exact);
 
 /* The photon dump generatePhotonMap leaves behind (FIN/main.cpp:397-400: fwrite of
  * Photon[NumPhotons], before balancing) and the way the reference's viewer reads it back

@@ -89,7 +89,7 @@ SYMBOLS = [
     "rt_scene_get_mesh", "rt_bvh_build", "rt_photon_balance", "rt_photons_write_dat", "rt_photons_read_dat", "rt_photon_pass", "rt_caustic_pass", "rt_render_begin",
     "rt_render_tiles_device", "rt_render_tiles_packed_device", "rt_tiles_packed_size", "rt_tiles_unpack_device", "rt_render_check", "rt_render_counters", "rt_render_progress", "rt_render_stop", "rt_render_wait",
     "rt_job_stats", "rt_job_setup_ms", "rt_job_destroy", "rt_trace_rays", "rt_estimate_irradiance", "rt_shade_rays",
-    "rt_scene_generate_photons", "rt_scene_set_photon_dump", "rt_scene_get_photons", "rt_photon_unreachable",
+    "rt_scene_generate_photons", "rt_scene_set_photon_dump", "rt_scene_get_photons", "rt_photon_unreachable", "rt_photon_unreachable_device",
 ]
 
 
@@ -247,6 +247,17 @@ def photon_unreachable(photons_1based):
     n = C.c_uint32()
     _check(lib().rt_photon_unreachable(_p(a), C.c_uint32(len(a) - 1), _p(idx), 8, C.byref(n)))
     return idx[: n.value].copy()
+
+
+def photon_unreachable_device(photons_1based, device=0):
+    """the same on the GPU (rt_photon_unreachable_device): (sorted 1-based raw indices, exact); exact == False: a median key is not
+    unique, only the host function answers"""
+    ph = np.ascontiguousarray(photons_1based, PHOTON)
+    n = len(ph) - 1
+    idx = np.zeros(16, np.uint32)
+    cnt, exact = C.c_uint32(), C.c_int32()
+    _check(lib().rt_photon_unreachable_device(int(device), _p(ph), C.c_uint32(n), _p(idx), 16, C.byref(cnt), C.byref(exact)))
+    return idx[:cnt.value].copy(), bool(exact.value)
 
 
 class Scene:

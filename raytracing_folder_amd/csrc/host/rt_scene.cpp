@@ -570,6 +570,24 @@ uint32_t ReachablePhotonSlots(uint32_t n)
     return n ? (uint32_t)reach : 0u;
 }
 
+void UnreachablePhotonRecs(PhotonPosRec *recs, uint32_t n, std::vector<uint32_t> &raw_indices)
+{
+    static_assert(sizeof(PhotonPosRec) == sizeof(PathBalancer::Rec) && sizeof(PhotonPosRec) == 16, "same record");
+    raw_indices.clear();
+    const uint32_t reach = ReachablePhotonSlots(n);
+    if (n == 0 || reach >= n) return;
+    float bmin[3] = {recs[0].pos[0], recs[0].pos[1], recs[0].pos[2]};             // the reference's box loop starts at the unused slot
+    float bmax[3] = {bmin[0], bmin[1], bmin[2]};
+    for (uint32_t i = 1; i <= n; i++)
+        for (int a = 0; a < 3; a++) {
+            if (bmin[a] > recs[i].pos[a]) bmin[a] = recs[i].pos[a];
+            if (bmax[a] < recs[i].pos[a]) bmax[a] = recs[i].pos[a];
+        }
+    PathBalancer b{reinterpret_cast<PathBalancer::Rec *>(recs), reach + 1, n, &raw_indices};
+    b.Segment(bmin, bmax, 1, 1, n);
+    std::sort(raw_indices.begin(), raw_indices.end());
+}
+
 void UnreachablePhotons(const rt_photon *in, uint32_t n, std::vector<uint32_t> &raw_indices)
 {
     raw_indices.clear();

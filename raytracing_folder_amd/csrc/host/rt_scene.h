@@ -339,6 +339,9 @@ void BalancePhotons(rt_photon *in, uint32_t n, rt_photon *out);
 uint32_t ReachablePhotonSlots(uint32_t n);
 // indices (1-based, ascending) into an UNBALANCED array of the photons that balancing would put beyond them
 void UnreachablePhotons(const rt_photon *in, uint32_t n, std::vector<uint32_t> &raw_indices);
+// the same on (position, raw index) records [0, n] ([0] = the unused all-zero slot), which the replay permutes in place
+struct PhotonPosRec { float pos[3]; uint32_t idx; };
+void UnreachablePhotonRecs(PhotonPosRec *recs, uint32_t n, std::vector<uint32_t> &raw_indices);
 
 // RenderImage::ComputeZBufferImage / ComputeSampleCountImage (FIN/include/scene.h:591-637) on plain arrays
 void ZBufferImage(const float *zbuffer, size_t size, uint8_t *zbufferImg);

@@ -60,6 +60,9 @@ void rtk_photon_copy_skipping(hipStream_t, const rt_photon *in, uint32_t n_in, c
 size_t rtk_photon_structure_scratch(uint32_t n, uint32_t n_sub);
 hipError_t rtk_photon_structure(hipStream_t, const rt_photon *ph, uint32_t n, uint32_t n_sub, float4 *pa, float4 *pb, float4 *box4,
                                 uint32_t *grid, PhotonGridOut *grid_out, void *scratch, size_t scratch_bytes);
+size_t rtk_photon_unreachable_scratch(uint32_t n);
+hipError_t rtk_photon_unreachable(hipStream_t, const rt_photon *ph0, uint32_t n, uint32_t first, uint32_t last, void *scratch, size_t scratch_bytes, uint32_t result[16]);
+void rtk_photon_pack_positions(hipStream_t, const rt_photon *ph0, uint32_t n, void *recs16);
 void rtk_photon_cell_start(hipStream_t, const float4 *tbox, uint32_t n_leaves, const float grid_min[3], float cell, const int dim[3], float radius, uint32_t *start);
 
 // ---- errors ---------------------------------------------------------------------------------------
@@ -221,12 +224,17 @@ struct rt_scene {
     // there is none or when the render asks for another count / bounce limit / seed -- the reference runs generatePhotonMap() on
     // every BeginRender (FIN/main.cpp:984-990).  A map handed over with rt_scene_set_photons is the caller's: it stays.
     struct Generated { bool valid = false; uint32_t count = 0; int bounce = 0; uint32_t seed = 0; } gen;
+    // ... and it STAYS on the device that generated it (DeviceState::raw_photons of gen_dev, gen_n photons) until somebody needs it
+    // on the host: the .dat dump, rt_scene_get_photons, another device, the host's replay of BalanceSegment when a median is not
+    // unique (raw_to_host below).  gen_n != 0 with an empty photons_raw = "on gen_dev only".
+    DeviceState *gen_dev = nullptr; uint32_t gen_n = 0;
     std::string photon_dump;            // where rt_render_begin's photon pass writes its .dat ("" = nowhere)
     std::mutex gen_mu;                  // jobs started together on several devices: ONE of them runs the photon pass, the others wait for it
     std::mutex mu;
     std::vector<DeviceState *> devs;
     std::atomic<int> live_jobs{0};
-    uint32_t photon_count() const { return !photons_raw.empty() ? (uint32_t)photons_raw.size() - 1 : (data.photons.empty() ? 0u : (uint32_t)data.photons.size() - 1); }
+    uint32_t photon_count() const { return gen_n ? gen_n : (!photons_raw.empty() ? (uint32_t)photons_raw.size() - 1 : (data.photons.empty() ? 0u : (uint32_t)data.photons.size() - 1)); }
+    void drop_generated() { photons_raw.clear(); photons_skip.clear(); gen.valid = false; gen_dev = nullptr; gen_n = 0; }
     void invalidate(bool scene, bool photons, bool caustic = false)
     {
         for (DeviceState *d : devs) { if (scene) d->scene_valid = false; if (photons) d->photons_valid = false; if (caustic) d->caustic_valid = false; }
@@ -234,7 +242,7 @@ struct rt_scene {
     // geometry, materials or lights changed (caller holds mu): re-upload, and a generated photon map is no longer this scene's
     void geometry_changed()
     {
-        if (gen.valid) { photons_raw.clear(); photons_skip.clear(); data.photons.clear(); gen.valid = false; invalidate(true, true); }
+        if (gen.valid) { drop_generated(); data.photons.clear(); invalidate(true, true); }
         else invalidate(true, false);
     }
 };
@@ -503,7 +511,7 @@ extern "C" rt_status rt_scene_set_photons(rt_scene *s, const rt_photon *photons,
     if (st) return st;
     if (n_stored > 0 && !photons) return fail(RT_ERR_ARG, "rt_scene_set_photons: photons is NULL");
     std::lock_guard<std::mutex> lk(s->mu);
-    s->photons_raw.clear(); s->photons_skip.clear(); s->gen.valid = false;
+    s->drop_generated();
     if (n_stored == 0) s->data.photons.clear();
     else s->data.photons.assign(photons, photons + (size_t)n_stored + 1);
     s->invalidate(false, true);
@@ -658,6 +666,34 @@ extern "C" rt_status rt_photon_unreachable(const rt_photon *in, uint32_t n, uint
     if (raw_indices) {
         if (cap < idx.size()) return fail(RT_ERR_ARG, "rt_photon_unreachable: room for %u indices, %zu needed", cap, idx.size());
         if (!idx.empty()) memcpy(raw_indices, idx.data(), idx.size() * 4);
+    }
+    return RT_OK;
+}
+
+extern "C" rt_status rt_photon_unreachable_device(int device, const rt_photon *in, uint32_t n, uint32_t *raw_indices, uint32_t cap, uint32_t *count, int32_t *exact)
+{
+    if (!in || !count || !exact) return fail(RT_ERR_ARG, "rt_photon_unreachable_device: NULL argument");
+    *count = 0; *exact = 1;
+    if (!device_is_gfx950(device)) return fail(RT_ERR_NO_DEVICE, "rt_photon_unreachable_device: device %d is not gfx950 (no CPU path: rt_photon_unreachable is the host's)", device);
+    const uint32_t reach = rt::ReachablePhotonSlots(n);
+    if (n == 0 || reach >= n) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    struct TempBuf : DevBuf { ~TempBuf() { release(); } } ph, scratch;
+    rt_status st;
+    if ((st = ph.upload(in, ((size_t)n + 1) * sizeof(rt_photon)))) return st;
+    HIP_TRY(hipMemset(ph.p, 0, sizeof(rt_photon)));                  // slot 0 is the unused all-zero photon
+    const size_t sbytes = rtk_photon_unreachable_scratch(n);
+    if ((st = scratch.ensure(sbytes))) return st;
+    uint32_t res[16];
+    const hipError_t e = rtk_photon_unreachable(nullptr, (const rt_photon *)ph.p, n, reach + 1, n, scratch.p, sbytes, res);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_photon_unreachable_device: %s", hipGetErrorString(e));
+    if (res[1] != 0 || res[0] != n - reach) { *exact = 0; return RT_OK; }
+    std::vector<uint32_t> idx(res + 2, res + 2 + res[0]);
+    std::sort(idx.begin(), idx.end());
+    *count = (uint32_t)idx.size();
+    if (raw_indices) {
+        if (cap < idx.size()) return fail(RT_ERR_ARG, "rt_photon_unreachable_device: room for %u indices, %zu needed", cap, idx.size());
+        memcpy(raw_indices, idx.data(), idx.size() * 4);
     }
     return RT_OK;
 }
@@ -1014,8 +1050,32 @@ static rt_status build_photon_structure(DeviceState *D, bool caustic, const rt_p
     return RT_OK;
 }
 
+// the generated photons on the host (caller holds s->mu): copied from the device that made them, once
+static rt_status raw_to_host(rt_scene *s)
+{
+    if (!s->gen_n || !s->photons_raw.empty()) return RT_OK;
+    if (!s->gen_dev || !s->gen_dev->raw_photons.p) return fail(RT_ERR_STATE, "the generated photon map is gone from its device");
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    HIP_TRY(hipSetDevice(s->gen_dev->device));
+    std::vector<rt_photon> raw((size_t)s->gen_n + 1);
+    HIP_TRY(hipMemcpy(raw.data(), s->gen_dev->raw_photons.p, raw.size() * sizeof(rt_photon), hipMemcpyDeviceToHost));
+    HIP_TRY(hipSetDevice(cur));
+    s->photons_raw.swap(raw);
+    return RT_OK;
+}
+
 static rt_status upload_photons(rt_scene *s, DeviceState *D, bool caustic)
 {
+    if (!caustic && s->gen_n) {
+        std::vector<uint32_t> skip0;
+        for (uint32_t i : s->photons_skip) skip0.push_back(i - 1);              // 1-based raw index -> position in [1..n]
+        if (D == s->gen_dev && D->raw_photons.p)                                 // still on this device
+            return build_photon_structure(D, false, (const rt_photon *)D->raw_photons.p + 1, nullptr, s->gen_n, skip0.data(), (uint32_t)skip0.size(), nullptr, nullptr);
+        rt_status st = raw_to_host(s);                                           // another device: through the host
+        if (st) return st;
+        HIP_TRY(hipSetDevice(D->device));
+    }
     if (!caustic && !s->photons_raw.empty()) {
         // as generated (unbalanced): everything but the photons balancing would put out of LocatePhotons' reach
         std::vector<uint32_t> skip0;
@@ -1935,6 +1995,10 @@ static rt_status photon_pass_device(rt_scene *s, DeviceState *D, uint32_t max_co
     for (const rt_light &l : s->data.lights) if (l.type == RT_LIGHT_POINT) have_source = true;
     if (!have_source) return fail(RT_ERR_STATE, "%s: the scene has no photon source (point light)", who);
     rt_status st;
+    {   // D->raw_photons is about to be overwritten: a generated map that lives only there goes to the host first
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (s->gen_dev == D && s->gen_n && s->photons_raw.empty() && (st = raw_to_host(s))) return st;
+    }
     const uint32_t batch = 1u << 18;
     static_assert((1u << 18) / RT_BLOCK <= RT_SPILL_BLOCKS, "DevScene::bvh_spill is sized for RT_SPILL_BLOCKS workgroups");
     const uint32_t out_cap = max_count + 8 + 1;                 // index 0 unused, up to 7 photons of overshoot
@@ -2018,21 +2082,60 @@ static rt_status generate_photons(rt_scene *s, int device, uint32_t max_photons,
     if (!claim.ok) return fail(RT_ERR_STATE, "rt_scene_generate_photons: another call on this scene is using device %d", device);
     if ((st = order_after_pending(D, D->stream))) return st;
     if (D->last_pending && D->last_done) HIP_TRY(hipEventSynchronize(D->last_done));       // the structure is rebuilt in place
+    {   // the map this call replaces: if it lives only on this device, it is simply dropped (not fetched to the host first)
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (s->gen_n && s->gen_dev == D && s->photons_raw.empty()) { s->drop_generated(); s->invalidate(false, true); }
+    }
     const auto t0 = clk::now();
     uint32_t n = 0;
     if ((st = photon_pass_device(s, D, max_photons, photon_bounce, seed, 0, &n, nullptr, "rt_scene_generate_photons"))) return st;
     const auto t1 = clk::now();
     T.photon_pass = ms(t0, t1);
-    // the unbalanced photons come to the host once: for the dump, for the few that balancing would put out of
-    // LocatePhotons' reach, for other devices and for rt_scene_get_photons
-    std::vector<rt_photon> raw((size_t)n + 1);
-    HIP_TRY(hipMemcpy(raw.data(), D->raw_photons.p, raw.size() * sizeof(rt_photon), hipMemcpyDeviceToHost));
+    // Which photons balancing would put out of LocatePhotons' reach (heap slots > ReachablePhotonSlots(n): the last three or four):
+    // found ON THE DEVICE along the root paths of those slots (rt_photon_build.hip: photon_unreachable); the photons stay where
+    // they are.  They come to the host only for the .dat dump, or when a median's key is not unique in its segment (then the
+    // reference's swap sequence decides and the host replays it: rt::UnreachablePhotons).
+    std::vector<rt_photon> raw;
+    auto fetch = [&]() -> rt_status {
+        if (!raw.empty()) return RT_OK;
+        raw.resize((size_t)n + 1);
+        HIP_TRY(hipMemcpy(raw.data(), D->raw_photons.p, raw.size() * sizeof(rt_photon), hipMemcpyDeviceToHost));
+        return RT_OK;
+    };
     const auto t2 = clk::now();
-    T.upload = ms(t1, t2);
-    if (dat_path && dat_path[0] && (st = rt_photons_write_dat(dat_path, raw.data(), n))) return st;
+    if (dat_path && dat_path[0]) {
+        if ((st = fetch())) return st;
+        if ((st = rt_photons_write_dat(dat_path, raw.data(), n))) return st;
+    }
     const auto t2b = clk::now();
+    T.upload = ms(t2, t2b);
     std::vector<uint32_t> skip;
-    rt::UnreachablePhotons(raw.data(), n, skip);
+    const uint32_t reach = rt::ReachablePhotonSlots(n);
+    if (n && reach < n) {
+        bool on_device = false;
+        {
+            struct TempBuf : DevBuf { ~TempBuf() { release(); } } scratch;
+            const size_t sbytes = rtk_photon_unreachable_scratch(n);
+            uint32_t res[16];
+            if (getenv("RT_UNREACHABLE_ON_HOST") == nullptr && scratch.ensure(sbytes) == RT_OK &&
+                rtk_photon_unreachable(D->stream, (const rt_photon *)D->raw_photons.p, n, reach + 1, n, scratch.p, sbytes, res) == hipSuccess &&
+                res[1] == 0 && res[0] == n - reach) {
+                skip.assign(res + 2, res + 2 + res[0]);
+                std::sort(skip.begin(), skip.end());
+                on_device = true;
+            } else (void)hipGetLastError();
+        }
+        if (!on_device) {
+            // the host's replay of BalanceSegment on (position, index) records packed on the device: 16 bytes per photon come over
+            struct TempBuf : DevBuf { ~TempBuf() { release(); } } packed;
+            if ((st = packed.ensure(((size_t)n + 1) * 16))) return st;
+            rtk_photon_pack_positions(D->stream, (const rt_photon *)D->raw_photons.p, n, packed.p);
+            std::vector<rt::PhotonPosRec> recs((size_t)n + 1);
+            HIP_TRY(hipMemcpyAsync(recs.data(), packed.p, recs.size() * 16, hipMemcpyDeviceToHost, D->stream));
+            HIP_TRY(hipStreamSynchronize(D->stream));
+            rt::UnreachablePhotonRecs(recs.data(), n, skip);
+        }
+    }
     const auto t3 = clk::now();
     T.balance = ms(t2b, t3);
     std::vector<uint32_t> skip0;
@@ -2043,9 +2146,10 @@ static rt_status generate_photons(rt_scene *s, int device, uint32_t max_photons,
     {
         std::lock_guard<std::mutex> lk(s->mu);
         s->data.photons.clear();
-        s->photons_raw.swap(raw);
+        s->photons_raw.swap(raw);                 // empty unless the photons had to come to the host
         s->photons_skip.swap(skip);
         s->gen.valid = true; s->gen.count = max_photons; s->gen.bounce = photon_bounce; s->gen.seed = seed;
+        s->gen_dev = D; s->gen_n = n;
         for (DeviceState *d : s->devs) if (d != D) d->photons_valid = false;
     }
     T.total = ms(t_begin, clk::now());
@@ -2077,6 +2181,7 @@ extern "C" rt_status rt_scene_get_photons(rt_scene *s, rt_photon *out, uint32_t 
     if (!out) return RT_OK;
     if (cap < n + 1) return fail(RT_ERR_ARG, "rt_scene_get_photons: buffer of %u records, %u needed", cap, n + 1);
     if (n == 0) { memset(out, 0, sizeof(rt_photon)); return RT_OK; }
+    { rt_status st = raw_to_host(s); if (st) return st; }
     if (!s->photons_raw.empty() && s->data.photons.empty()) {
         // PrepareForIrradianceEstimation (cyPhotonMap.h:196-218) of the generated photons, bit for bit, on first request
         std::vector<rt_photon> tmp = s->photons_raw;

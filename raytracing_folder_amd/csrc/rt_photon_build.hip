@@ -17,6 +17,9 @@
 #include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
 #include "rt_dev.h"
 
 #define PB_BLOCK 256
@@ -126,6 +129,239 @@ void rtk_photon_copy_skipping(hipStream_t st, const rt_photon *in, uint32_t n_in
     SkipList S; S.n = n_skip > 8 ? 8 : n_skip;
     for (uint32_t k = 0; k < S.n; k++) S.idx[k] = skip[k];
     if (n_in) hipLaunchKernelGGL(k_copy_skipping, dim3((n_in + PB_BLOCK - 1) / PB_BLOCK), dim3(PB_BLOCK), 0, st, in, n_in, S, out);
+}
+
+// ---- photon_unreachable ---------------------------------------------------------------------------------------------
+// Which photons of an UNBALANCED array PhotonMap::BalanceSegment (FIN/include/cyPhotonMap.h:222-284) would put into the heap slots
+// LocatePhotons never visits (slots [first, last] = the last three or four: it descends only while index < halfStoredPhotons,
+// :217,:371).  The content of a segment when BalanceSegment partitions it is a SET that depends only on the partitions of its
+// ancestors -- the `median - start` smallest keys go left, the larger ones right -- as long as the key of the median is unique
+// in its segment (with equal keys the reference's swap sequence decides; that case is reported and left to the host's exact
+// replay, rt::UnreachablePhotons).  So only the root paths of those slots are followed: per level and live segment a radix
+// select (three histogram passes over 11 + 11 + 10 key bits) of the median's key among the photons labelled with the segment,
+// then one pass that relabels them with the child segments.  Segment sizes, median ranks and which children matter are a
+// closed form of n and come precomputed from the host; boxes, split axes and split values are found here.
+#define UR_MAX_LEVELS 40
+#define UR_MAX_SEGS 4
+#define UR_BINS 2048
+struct UrSeg {
+    uint32_t index, count, m;            // heap slot of the segment's median, photons in it, 0-based rank of the median key (host)
+    int32_t left_next, right_next;       // position of the child segment in the next level's list, -1: not followed (host)
+    uint32_t left_single, right_single, median_target;   // a one-photon child / the median itself lands in a wanted slot (host)
+    float box[6];                        // bmin, bmax handed down by the parent (device)
+};
+struct UrState { uint32_t n_out, tie; uint32_t out[14]; };
+__device__ __forceinline__ uint32_t ur_key(float f) { if (f == 0.0f) f = 0.0f; return ((__float_as_uint(f) & 0x80000000u) ? ~__float_as_uint(f) : (__float_as_uint(f) | 0x80000000u)); }
+__device__ __forceinline__ int ur_axis(const float *box)      // BalanceSegment's choice, :234-240
+{
+    const float dx = box[3] - box[0], dy = box[4] - box[1], dz = box[5] - box[2];
+    int axis = 2;
+    if (dx > dy) { if (dx > dz) axis = 0; }
+    else if (dy > dz) axis = 1;
+    return axis;
+}
+// the bin of `hist` (nbins counters) that holds 0-based rank r, and r's rank inside that bin; whole block, nbins <= 8 * blockDim
+__device__ uint32_t ur_pick(const uint32_t *hist, uint32_t nbins, uint32_t &r, uint32_t *s_scan)
+{
+    const uint32_t t = threadIdx.x, per = (nbins + blockDim.x - 1) / blockDim.x;
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < per; k++) { const uint32_t b = t * per + k; if (b < nbins) mine += hist[b]; }
+    s_scan[t] = mine;
+    __syncthreads();
+    __shared__ uint32_t s_bin, s_rank;
+    if (t == 0) {
+        uint32_t cum = 0, owner = 0;
+        for (uint32_t i = 0; i < blockDim.x; i++) { if (cum + s_scan[i] > r) { owner = i; break; } cum += s_scan[i]; owner = i; }
+        uint32_t b = owner * per;
+        for (; b < nbins && b < (owner + 1) * per; b++) { const uint32_t h = hist[b]; if (cum + h > r) break; cum += h; }
+        s_bin = b < nbins ? b : nbins - 1; s_rank = r - cum;
+    }
+    __syncthreads();
+    r = s_rank;
+    const uint32_t bin = s_bin;
+    __syncthreads();
+    return bin;
+}
+// prefix (the key bits fixed so far) and remaining rank after `passes` finished histogram passes of this segment
+__device__ void ur_prefix(const uint32_t *hists, const UrSeg &S, int passes, uint32_t &prefix, uint32_t &rank, uint32_t *s_scan)
+{
+    prefix = 0; rank = S.m;
+    if (passes >= 1) prefix = ur_pick(hists, UR_BINS, rank, s_scan);
+    if (passes >= 2) prefix = (prefix << 11) | ur_pick(hists + UR_BINS, UR_BINS, rank, s_scan);
+    if (passes >= 3) prefix = (prefix << 10) | ur_pick(hists + 2 * UR_BINS, 1024, rank, s_scan);
+}
+__global__ __launch_bounds__(PB_BLOCK) void k_ur_bbox(const rt_photon *ph0, uint32_t n, uint32_t *ord)
+{
+    // the reference's box loop covers photons[0], the unused all-zero slot, too (cyPhotonMap.h:201-210)
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; a++) { const uint32_t k = ur_key(ph0[i].position[a]); lo[a] = min(lo[a], k); hi[a] = max(hi[a], k); }
+    __shared__ uint32_t s_lo[3], s_hi[3];
+    if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0xFFFFFFFFu; s_hi[threadIdx.x] = 0u; }
+    __syncthreads();
+    for (int a = 0; a < 3; a++) {
+        for (int off = 32; off > 0; off >>= 1) { lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], off)); hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], off)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_lo[a], lo[a]); atomicMax(&s_hi[a], hi[a]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) { atomicMin(&ord[threadIdx.x], s_lo[threadIdx.x]); atomicMax(&ord[3 + threadIdx.x], s_hi[threadIdx.x]); }
+}
+// (position, raw index) records of photons [0, n]: what the host's replay of BalanceSegment works on (16 bytes instead of the 24-byte photon)
+__global__ __launch_bounds__(PB_BLOCK) void k_ur_pack(const rt_photon *ph0, uint32_t n, float4 *recs)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) recs[i] = make_float4(ph0[i].position[0], ph0[i].position[1], ph0[i].position[2], __uint_as_float(i));
+}
+void rtk_photon_pack_positions(hipStream_t st, const rt_photon *ph0, uint32_t n, void *recs16)
+{
+    hipLaunchKernelGGL(k_ur_pack, dim3((n + 1 + PB_BLOCK - 1) / PB_BLOCK), dim3(PB_BLOCK), 0, st, ph0, n, (float4 *)recs16);
+}
+__global__ void k_ur_root(const uint32_t *ord, UrSeg *root)
+{
+    for (int a = 0; a < 6; a++) { const uint32_t u = ord[a]; root->box[a] = __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+}
+// one histogram pass (pass 0, 1, 2) of every live segment of a level: grid = (blocks, segments)
+__global__ __launch_bounds__(PB_BLOCK) void k_ur_hist(const rt_photon *ph0, const uint32_t *label, uint32_t n, const UrSeg *segs, uint32_t *hists, int pass)
+{
+    __shared__ uint32_t s_hist[UR_BINS];
+    __shared__ uint32_t s_scan[PB_BLOCK];
+    const UrSeg S = segs[blockIdx.y];
+    uint32_t *H = hists + (size_t)blockIdx.y * 3 * UR_BINS;
+    uint32_t prefix, rank;
+    ur_prefix(H, S, pass, prefix, rank, s_scan);
+    for (uint32_t b = threadIdx.x; b < UR_BINS; b += blockDim.x) s_hist[b] = 0;
+    __syncthreads();
+    const int axis = ur_axis(S.box);
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    const uint32_t mask = pass == 2 ? 1023u : 2047u;
+    for (uint32_t i = 1 + blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+        if (label[i] != S.index) continue;
+        const uint32_t k = ur_key(ph0[i].position[axis]);
+        if (pass > 0 && (k >> (shift + (pass == 1 ? 11 : 10))) != prefix) continue;
+        atomicAdd(&s_hist[(k >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    uint32_t *G = H + (size_t)pass * UR_BINS;
+    for (uint32_t b = threadIdx.x; b < UR_BINS; b += blockDim.x) if (s_hist[b]) atomicAdd(&G[b], s_hist[b]);
+}
+// relabel the photons of every live segment with its children; hand the children their boxes; record wanted photons
+__global__ __launch_bounds__(PB_BLOCK) void k_ur_apply(const rt_photon *ph0, uint32_t *label, uint32_t n, const UrSeg *segs, UrSeg *next, const uint32_t *hists,
+                                                       UrState *state)
+{
+    __shared__ uint32_t s_scan[PB_BLOCK];
+    const UrSeg S = segs[blockIdx.y];
+    const uint32_t *H = hists + (size_t)blockIdx.y * 3 * UR_BINS;
+    uint32_t vkey, rank;
+    ur_prefix(H, S, 3, vkey, rank, s_scan);
+    const bool unique = H[2 * UR_BINS + (vkey & 1023u)] == 1u;          // the median's key occurs once in the segment
+    const int axis = ur_axis(S.box);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!unique) atomicExch(&state->tie, 1u);
+        const float v = __uint_as_float((vkey & 0x80000000u) ? (vkey & 0x7FFFFFFFu) : ~vkey);
+        if (S.left_next >= 0) { UrSeg &L = next[S.left_next]; for (int a = 0; a < 6; a++) L.box[a] = S.box[a]; L.box[3 + axis] = v; }     // tmax[axis] = split (:262)
+        if (S.right_next >= 0) { UrSeg &R = next[S.right_next]; for (int a = 0; a < 6; a++) R.box[a] = S.box[a]; R.box[axis] = v; }        // tmin[axis] = split (:271)
+    }
+    for (uint32_t i = 1 + blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+        if (label[i] != S.index) continue;
+        const uint32_t k = ur_key(ph0[i].position[axis]);
+        bool want = false;
+        uint32_t nl = 0;
+        if (k < vkey) { if (S.left_next >= 0) nl = 2u * S.index; want = S.left_single != 0; }
+        else if (k > vkey) { if (S.right_next >= 0) nl = 2u * S.index + 1u; want = S.right_single != 0; }
+        else want = S.median_target != 0;
+        label[i] = nl;
+        if (want) { const uint32_t at = atomicAdd(&state->n_out, 1u); if (at < 14u) state->out[at] = i; }
+    }
+}
+__global__ __launch_bounds__(PB_BLOCK) void k_ur_fill(uint32_t *p, uint32_t n, uint32_t v)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+size_t rtk_photon_unreachable_scratch(uint32_t n)
+{
+    return (((size_t)n + 1) * 4 + 255 & ~(size_t)255) + (size_t)UR_MAX_LEVELS * UR_MAX_SEGS * (sizeof(UrSeg) + 3 * UR_BINS * 4) + 1024;
+}
+// ph0: the photons as generated, 1-based ([0] all zero), on the device.  Heap slots [first, last] are wanted.  result (host):
+// [0] = number of photons found, [1] = 1 when a median's key was not unique (the caller must use the host's exact replay),
+// [2..] = their 1-based raw indices (unsorted).  Returns after the stream has been synchronised.
+hipError_t rtk_photon_unreachable(hipStream_t st, const rt_photon *ph0, uint32_t n, uint32_t first, uint32_t last, void *scratch, size_t scratch_bytes,
+                                  uint32_t result[16])
+{
+    memset(result, 0, 16 * sizeof(uint32_t));
+    if (n == 0 || first > last || first > n) return hipSuccess;
+    if (scratch_bytes < rtk_photon_unreachable_scratch(n)) return hipErrorInvalidValue;
+    // ---- the schedule: segment sizes and median ranks along the root paths of the wanted slots (closed form of n) ----
+    auto holds = [&](uint32_t index) { for (uint32_t t = first; t <= last; t++) { uint32_t a = t; while (a > index) a >>= 1; if (a == index) return true; } return false; };
+    auto wanted = [&](uint32_t slot) { return slot >= first && slot <= last; };
+    std::vector<std::vector<UrSeg>> sched(1);
+    { UrSeg r; memset(&r, 0, sizeof r); r.index = 1; r.count = n; r.left_next = r.right_next = -1; sched[0].push_back(r); }
+    for (size_t L = 0; L < sched.size(); L++) {
+        std::vector<UrSeg> nxt;
+        for (UrSeg &S : sched[L]) {
+            const uint32_t start = 1, end = S.count;          // ranks are relative to the segment
+            if (S.count == 1) { S.m = 0; S.median_target = wanted(S.index); continue; }      // (never scheduled: a one-photon child is a *_single)
+            uint32_t median = 1;
+            while (4 * median <= end - start + 1) median += median;
+            if (3 * median <= end - start + 1) { median += median; median += start - 1; }
+            else median = end - median + 1;
+            S.m = median - start;
+            S.median_target = wanted(S.index);
+            const uint32_t nleft = median - start, nright = end - median;
+            if (nleft == 1) S.left_single = wanted(2 * S.index);
+            else if (nleft >= 2 && holds(2 * S.index)) { UrSeg c; memset(&c, 0, sizeof c); c.index = 2 * S.index; c.count = nleft; c.left_next = c.right_next = -1; S.left_next = (int32_t)nxt.size(); nxt.push_back(c); }
+            if (nright == 1) S.right_single = wanted(2 * S.index + 1);
+            else if (nright >= 2 && holds(2 * S.index + 1)) { UrSeg c; memset(&c, 0, sizeof c); c.index = 2 * S.index + 1; c.count = nright; c.left_next = c.right_next = -1; S.right_next = (int32_t)nxt.size(); nxt.push_back(c); }
+        }
+        if (!nxt.empty()) sched.push_back(nxt);
+        if (sched.size() > UR_MAX_LEVELS || nxt.size() > UR_MAX_SEGS) return hipErrorInvalidValue;
+    }
+    // ---- device buffers inside `scratch` ----
+    char *base = (char *)scratch;
+    uint32_t *label = (uint32_t *)base;
+    base += (((size_t)n + 1) * 4 + 255) & ~(size_t)255;
+    UrSeg *d_sched = (UrSeg *)base;
+    base += (size_t)UR_MAX_LEVELS * UR_MAX_SEGS * sizeof(UrSeg);
+    uint32_t *d_hists = (uint32_t *)base;
+    base += (size_t)UR_MAX_LEVELS * UR_MAX_SEGS * 3 * UR_BINS * 4;
+    UrState *d_state = (UrState *)base;
+    uint32_t *d_ord = (uint32_t *)(base + 256);
+    std::vector<UrSeg> flat((size_t)UR_MAX_LEVELS * UR_MAX_SEGS);
+    memset(flat.data(), 0, flat.size() * sizeof(UrSeg));
+    for (size_t L = 0; L < sched.size(); L++) for (size_t k = 0; k < sched[L].size(); k++) flat[L * UR_MAX_SEGS + k] = sched[L][k];
+    hipError_t e;
+    if ((e = hipMemcpyAsync(d_sched, flat.data(), flat.size() * sizeof(UrSeg), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d_hists, 0, sched.size() * UR_MAX_SEGS * 3 * UR_BINS * 4, st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d_state, 0, sizeof(UrState), st)) != hipSuccess) return e;
+    const uint32_t ord_init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    if ((e = hipMemcpyAsync(d_ord, ord_init, sizeof ord_init, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    const int grid = (int)std::min<size_t>(((size_t)n + PB_BLOCK) / PB_BLOCK, 1024);
+    hipLaunchKernelGGL(k_ur_fill, dim3((n + 1 + PB_BLOCK - 1) / PB_BLOCK), dim3(PB_BLOCK), 0, st, label, n + 1, 1u);
+    hipLaunchKernelGGL(k_ur_bbox, dim3(grid), dim3(PB_BLOCK), 0, st, ph0, n, d_ord);
+    hipLaunchKernelGGL(k_ur_root, dim3(1), dim3(1), 0, st, d_ord, d_sched);
+    for (size_t L = 0; L < sched.size(); L++) {
+        const UrSeg *segs = d_sched + L * UR_MAX_SEGS;
+        uint32_t *hists = d_hists + L * UR_MAX_SEGS * 3 * UR_BINS;
+        const dim3 g(grid, (unsigned)sched[L].size());
+        for (int pass = 0; pass < 3; pass++) hipLaunchKernelGGL(k_ur_hist, g, dim3(PB_BLOCK), 0, st, ph0, label, n, segs, hists, pass);
+        hipLaunchKernelGGL(k_ur_apply, g, dim3(PB_BLOCK), 0, st, ph0, label, n, segs, d_sched + (L + 1) * UR_MAX_SEGS, hists, d_state);
+        if (L < 6 || (L & 3) == 3) {
+            // a median that is not unique ends the search: found out early (maps whose photons sit on axis-aligned walls tie within
+            // the first levels -- the wanted slots lie on the path of the LARGEST keys, where a wall's photons share one coordinate)
+            uint32_t tie = 0;
+            if ((e = hipMemcpyAsync(&tie, &d_state->tie, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+            if (tie) { result[1] = 1; return hipSuccess; }
+        }
+    }
+    UrState h;
+    if ((e = hipMemcpyAsync(&h, d_state, sizeof h, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    result[0] = h.n_out; result[1] = h.tie;
+    for (uint32_t k = 0; k < 14 && k < h.n_out; k++) result[2 + k] = h.out[k];
+    return hipSuccess;
 }
 
 // ---- photon_structure -----------------------------------------------------------------------------------------------

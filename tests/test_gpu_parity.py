@@ -1396,6 +1396,46 @@ def test_generated_photon_map_follows_the_scene_and_the_render_parameters():
     assert s.get_photons().tobytes() == first.tobytes()
 
 
+def test_unreachable_photons_found_on_the_device_equal_the_host_replay():
+    """rt_photon_unreachable_device (radix selects along the root paths of the heap slots LocatePhotons never visits; what
+    rt_scene_generate_photons runs) against rt_photon_unreachable (the host's replay of BalanceSegment with the reference's own
+    swap sequence, pinned to PrepareForIrradianceEstimation in tests/test_host.py): every array size shape -- a full last level,
+    one photon past it (two root paths apart from the root on), odd and even counts -- and arrays whose keys tie: on a tie at a
+    median the device must SAY so (exact == False) instead of answering."""
+    rng = np.random.default_rng(77)
+    for n in (5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 100, 1023, 1024, 1025, 4097, 65535, 65536, 65537, 100003, 262145):
+        ph = np.zeros(n + 1, capi.PHOTON)
+        ph["position"][1:] = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
+        got, exact = capi.photon_unreachable_device(ph)
+        want = capi.photon_unreachable(ph)
+        assert exact and list(got) == list(want), (n, got, want)
+        assert len(want) in (3, 4) or n < 8
+    # photons of the generated Cornell map (walls: one coordinate the same float for a whole wall)
+    s, _ = scenes.load_cornell()
+    raw, _ = s.photon_pass(50000, 8, seed=3)
+    got, exact = capi.photon_unreachable_device(raw)
+    if exact:
+        assert list(got) == list(capi.photon_unreachable(raw))
+    # ties everywhere: every key one of four values -- some median on the paths cannot be unique
+    n = 5000
+    ph = np.zeros(n + 1, capi.PHOTON)
+    ph["position"][1:] = rng.integers(0, 4, (n, 3)).astype(np.float32)
+    got, exact = capi.photon_unreachable_device(ph)
+    assert not exact and len(got) == 0
+    # ... and rt_scene_generate_photons falls back to the host's replay then: same map either way
+    s1, _ = scenes.load_cornell(); s1.generate_photons(30000, 8, seed=9)
+    os.environ["RT_UNREACHABLE_ON_HOST"] = "1"
+    try:
+        s2, _ = scenes.load_cornell(); s2.generate_photons(30000, 8, seed=9)
+    finally:
+        del os.environ["RT_UNREACHABLE_ON_HOST"]
+    pos = s1.get_photons()["position"][1:400] + np.float32(0.01)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (len(pos), 1))
+    i1, d1 = s1.estimate_irradiance(50, 2.0, pos, nrm)
+    i2, d2 = s2.estimate_irradiance(50, 2.0, pos, nrm)
+    assert s1.get_photons().tobytes() == s2.get_photons().tobytes() and np.array_equal(i1, i2) and np.array_equal(d1, d2)
+
+
 def test_full_size_frame_properties():
     """BASELINE size (1920 x 1080) with 2 fixed samples: size-independent properties"""
     s, cam = scenes.load_cornell(1920, 1080)
