@@ -609,6 +609,16 @@ def main():
             own = R.rgb.cpu() if rehearsal else R.rgb
             assert bool((frgb[:8, :32].cpu() == own[:8, :32].cpu()).all()), "gathered frame disagrees with rank 0's tile"
             out["gathered_frame_nonzero_fraction"] = round(float((fz.float() != 0).float().mean()), 4)
+            if rehearsal:
+                # every rank sits on this one GPU: render the N = 1 frame here and hold the gathered one against it
+                R1 = ShardedRenderer(s, cam, p, 0, 1, local)
+                R1.step()
+                one = tuple(t.cpu() for t in (R1.rgb, R1.z, R1.cnt))
+                g = tuple(t.cpu() for t in frame)
+                drgb = (g[0].int() - one[0].int()).abs()
+                out["rehearsal_check"] = {"z_equal": bool((g[1] == one[1]).all()), "count_equal": bool((g[2] == one[2]).all()),
+                                          "rgb_max_abs_diff": int(drgb.max()), "against": "the N = 1 frame rendered on the same device"}
+                assert out["rehearsal_check"]["z_equal"] and out["rehearsal_check"]["count_equal"] and out["rehearsal_check"]["rgb_max_abs_diff"] <= 1, out["rehearsal_check"]
         print(json.dumps(out), flush=True)
         if failed:
             sys.exit("bench.py: the timed frame FAILS the parity gate against the oracle (see parity_check in the line above)")
