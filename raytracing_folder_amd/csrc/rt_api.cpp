@@ -709,103 +709,149 @@ static DeviceState *device_state(rt_scene *s, int device)
     return d;
 }
 
-// reference node tree -> device BVH: children's boxes live in the parent, triangles in leaf order.  stack_need = the most
-// traversal-stack entries a ray can have pending in this tree (near-first, the other hit children pushed).
-#if RT_BVH_WIDTH == 4
-// Four-wide: a device node stands for a binary node of the reference's tree (cyBVH.h:76-106; root id 1, children adjacent)
-// and holds its GRANDCHILDREN -- a child that is a leaf stays one child -- in the reference's child1-before-child2 order.
-// Same boxes, same leaves, same triangle order inside a leaf: the traversal tests the same triangles as on the binary tree.
-static rt_status convert_bvh(const rt::MeshData &m, std::vector<DevBvhNode> &out, uint32_t &root_ref, int &stack_need)
+// The tree the kernels walk is built HERE from the triangles (binned surface-area heuristic, leaves of at most four, collapsed
+// four-wide by largest child first): any bounding hierarchy over the same triangles gives the same closest hit -- the
+// triangle tests are the reference's, operation by operation, and `t < z` keeps the nearest whatever the order (only two
+// hits at EXACTLY equal t depend on it) -- so the reference's mean-split tree (rt_bvh_build, rt_scene_set_mesh: kept bit-identical
+// for whoever reads it back) is not what limits traversal any more.  slot_face: the face of every triangle slot (leaf order).
+static rt_status build_sah_bvh(const rt::MeshData &m, std::vector<DevBvhNode> &out, std::vector<uint32_t> &slot_face, uint32_t &root_ref, int &stack_need)
 {
+    const size_t nf = m.f.size() / 3;
+    struct TB { float lo[3], hi[3], c[3]; };
+    std::vector<TB> tb(nf);
+    for (size_t f = 0; f < nf; f++) {
+        TB &t = tb[f];
+        for (int a = 0; a < 3; a++) { t.lo[a] = 3.0e38f; t.hi[a] = -3.0e38f; }
+        for (int k = 0; k < 3; k++) {
+            const float *q = &m.v[3 * (size_t)m.f[3 * f + k]];
+            for (int a = 0; a < 3; a++) { t.lo[a] = std::min(t.lo[a], q[a]); t.hi[a] = std::max(t.hi[a], q[a]); }
+        }
+        for (int a = 0; a < 3; a++) t.c[a] = 0.5f * (t.lo[a] + t.hi[a]);
+    }
+    struct BN { float lo[3], hi[3]; int32_t left, right; uint32_t first, count; };      // binary tree: leaf when left < 0
+    std::vector<BN> bn;
+    std::vector<uint32_t> idx(nf);
+    for (size_t i = 0; i < nf; i++) idx[i] = (uint32_t)i;
+    auto area = [](const float *lo, const float *hi) { const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return 2.0f * (dx * dy + dy * dz + dz * dx); };
     struct Rec {
-        const rt::MeshData &m; std::vector<DevBvhNode> &out; int max_levels = 0; bool bad = false; size_t visited = 0;
-        static uint32_t LEAFREF(uint32_t off, uint32_t cnt) { return 0x80000000u | ((cnt - 1) << 28) | (off & 0x0FFFFFFFu); }
-        bool ok_id(uint32_t id) const { return id != 0 && id < m.nodes.size(); }
-        bool is_leaf(uint32_t id) const { return (m.nodes[id].data & 0x80000000u) != 0; }
-        uint32_t leaf_ref(uint32_t id)
+        std::vector<TB> &tb; std::vector<BN> &bn; std::vector<uint32_t> &idx; decltype(area) &area;
+        int32_t go(uint32_t b, uint32_t e, int depth)
         {
-            const rt_bvh_node &n = m.nodes[id];
-            const uint32_t cnt = ((n.data >> 28) & 7u) + 1, off = n.data & 0x0FFFFFFFu;
-            if ((size_t)off + cnt > m.elements.size()) { bad = true; return LEAFREF(0, 1); }
-            return LEAFREF(off, cnt);
+            BN n;
+            for (int a = 0; a < 3; a++) { n.lo[a] = 3.0e38f; n.hi[a] = -3.0e38f; }
+            float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            for (uint32_t i = b; i < e; i++) {
+                const TB &t = tb[idx[i]];
+                for (int a = 0; a < 3; a++) { n.lo[a] = std::min(n.lo[a], t.lo[a]); n.hi[a] = std::max(n.hi[a], t.hi[a]); clo[a] = std::min(clo[a], t.c[a]); chi[a] = std::max(chi[a], t.c[a]); }
+            }
+            n.left = n.right = -1; n.first = b; n.count = e - b;
+            const int32_t me = (int32_t)bn.size();
+            bn.push_back(n);
+            // leaves of at most four triangles (measured on MI355X, tracer ms Cornell / 102 k triangles / C3: 2: 15.45 / 21.77 / 202.4, 3: 15.46 / 21.79 /
+            // 201.1, 4: 15.51 / 22.22 / 196.5, 6: 15.62 / 22.63 / 202.6, 8: 15.87 / 23.65 / 213.6), its triangles by face id
+            if (e - b <= 4) { std::sort(idx.begin() + b, idx.begin() + e); return me; }
+            uint32_t mid = 0;
+            if (depth < 28) {
+                // binned SAH over the centroids, 16 bins per axis
+                const int NB = 16;
+                float best = 3.0e38f; int best_axis = -1, best_bin = 0;
+                for (int a = 0; a < 3; a++) {
+                    const float ext = chi[a] - clo[a];
+                    if (!(ext > 0)) continue;
+                    struct Bin { float lo[3], hi[3]; uint32_t n; } bins[NB];
+                    for (int k = 0; k < NB; k++) { bins[k].n = 0; for (int c = 0; c < 3; c++) { bins[k].lo[c] = 3.0e38f; bins[k].hi[c] = -3.0e38f; } }
+                    const float scale = (float)NB / ext;
+                    for (uint32_t i = b; i < e; i++) {
+                        const TB &t = tb[idx[i]];
+                        int k = (int)((t.c[a] - clo[a]) * scale);
+                        k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+                        bins[k].n++;
+                        for (int c = 0; c < 3; c++) { bins[k].lo[c] = std::min(bins[k].lo[c], t.lo[c]); bins[k].hi[c] = std::max(bins[k].hi[c], t.hi[c]); }
+                    }
+                    float rlo[NB][3], rhi[NB][3]; uint32_t rn[NB];
+                    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}; uint32_t cnt = 0;
+                    for (int k = NB - 1; k >= 1; k--) {
+                        cnt += bins[k].n;
+                        for (int c = 0; c < 3; c++) { lo[c] = std::min(lo[c], bins[k].lo[c]); hi[c] = std::max(hi[c], bins[k].hi[c]); }
+                        rn[k] = cnt; for (int c = 0; c < 3; c++) { rlo[k][c] = lo[c]; rhi[k][c] = hi[c]; }
+                    }
+                    for (int c = 0; c < 3; c++) { lo[c] = 3.0e38f; hi[c] = -3.0e38f; }
+                    cnt = 0;
+                    for (int k = 0; k + 1 < NB; k++) {               // split between bin k and k + 1
+                        cnt += bins[k].n;
+                        for (int c = 0; c < 3; c++) { lo[c] = std::min(lo[c], bins[k].lo[c]); hi[c] = std::max(hi[c], bins[k].hi[c]); }
+                        if (cnt == 0 || rn[k + 1] == 0) continue;
+                        const float cost = area(lo, hi) * (float)cnt + area(rlo[k + 1], rhi[k + 1]) * (float)rn[k + 1];
+                        if (cost < best) { best = cost; best_axis = a; best_bin = k; }
+                    }
+                }
+                if (best_axis >= 0) {
+                    const int a = best_axis;
+                    const float scale = 16.0f / (chi[a] - clo[a]);
+                    auto it = std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t f) {
+                        int k = (int)((tb[f].c[a] - clo[a]) * scale);
+                        k = k < 0 ? 0 : (k >= 16 ? 15 : k);
+                        return k <= best_bin;
+                    });
+                    mid = (uint32_t)(it - idx.begin());
+                }
+            }
+            if (mid <= b || mid >= e) {
+                // no usable plane (all centroids in one bin, or the tree got deep): halves by the widest centroid axis
+                int a = 0;
+                if (chi[1] - clo[1] > chi[a] - clo[a]) a = 1;
+                if (chi[2] - clo[2] > chi[a] - clo[a]) a = 2;
+                mid = b + (e - b) / 2;
+                std::nth_element(idx.begin() + b, idx.begin() + mid, idx.begin() + e, [&](uint32_t x, uint32_t y) { return tb[x].c[a] < tb[y].c[a] || (tb[x].c[a] == tb[y].c[a] && x < y); });
+            }
+            const int32_t l = go(b, mid, depth + 1);
+            const int32_t r = go(mid, e, depth + 1);
+            bn[me].left = l; bn[me].right = r;
+            return me;
         }
-        // children of binary node `id` (internal): its two child ids, or bad
-        bool kids(uint32_t id, uint32_t k[2])
+    } rec{tb, bn, idx, area};
+    const int32_t root = rec.go(0, (uint32_t)nf, 0);
+    auto leafref = [](uint32_t off, uint32_t cnt) { return 0x80000000u | ((cnt - 1) << 28) | (off & 0x0FFFFFFFu); };
+    slot_face = idx;
+    if (nf >= 0x10000000ull) return fail(RT_ERR_LIMIT, "mesh too large");
+    int max_levels = 0;
+    // four-wide: a device node holds up to four descendants of the binary node it stands for -- starting from its two children, the
+    // internal one with the largest surface is replaced by its own two children until there are four (or only leaves)
+    struct Col {
+        std::vector<BN> &bn; std::vector<DevBvhNode> &out; decltype(area) &area; decltype(leafref) &leafref; int &max_levels;
+        uint32_t go(int32_t id, int level)
         {
-            const uint32_t c = m.nodes[id].data & 0x7FFFFFFFu;
-            if (c == 0 || (size_t)c + 1 >= m.nodes.size()) { bad = true; return false; }
-            k[0] = c; k[1] = c + 1;
-            return true;
-        }
-        uint32_t go(uint32_t id, int level)          // id: an INTERNAL binary node; returns the device node index
-        {
-            // a well-formed tree visits every node once: more visits than input nodes means a cycle
-            if (bad || !ok_id(id) || level > 256 || ++visited > m.nodes.size()) { bad = true; return 0; }
             if (level > max_levels) max_levels = level;
             const uint32_t me = (uint32_t)out.size();
             out.push_back(DevBvhNode{});
-            uint32_t ch[4]; int n = 0;
-            uint32_t k[2];
-            if (!kids(id, k)) return 0;
-            for (int i = 0; i < 2; i++) {
-                if (!ok_id(k[i])) { bad = true; return 0; }
-                if (is_leaf(k[i])) ch[n++] = k[i];
-                else { uint32_t g[2]; if (!kids(k[i], g)) return 0; if (!ok_id(g[0]) || !ok_id(g[1])) { bad = true; return 0; } ch[n++] = g[0]; ch[n++] = g[1]; }
+            int32_t ch[4]; int n = 0;
+            ch[n++] = bn[id].left; ch[n++] = bn[id].right;
+            while (n < 4) {
+                int pick = -1; float big = -1.0f;
+                for (int i = 0; i < n; i++) if (bn[ch[i]].left >= 0) { const float s = area(bn[ch[i]].lo, bn[ch[i]].hi); if (s > big) { big = s; pick = i; } }
+                if (pick < 0) break;
+                const int32_t c = ch[pick];
+                for (int i = n; i > pick + 1; i--) ch[i] = ch[i - 1];
+                ch[pick] = bn[c].left; ch[pick + 1] = bn[c].right;
+                n++;
             }
             DevBvhNode d;
             memset(&d, 0, sizeof d);
             const float nan = std::nanf("");
             for (int i = 0; i < 4; i++) {
-                for (int a = 0; a < 3; a++) { d.lo[a][i] = i < n ? m.nodes[ch[i]].box[a] : nan; d.hi[a][i] = i < n ? m.nodes[ch[i]].box[a + 3] : nan; }
-                d.c[i] = i < n ? (is_leaf(ch[i]) ? leaf_ref(ch[i]) : go(ch[i], level + 1)) : LEAFREF(0, 1);
+                for (int a = 0; a < 3; a++) { d.lo[a][i] = i < n ? bn[ch[i]].lo[a] : nan; d.hi[a][i] = i < n ? bn[ch[i]].hi[a] : nan; }
+                if (i >= n) d.c[i] = leafref(0, 1);
+                else if (bn[ch[i]].left < 0) d.c[i] = leafref(bn[ch[i]].first, bn[ch[i]].count);
+                else d.c[i] = go(ch[i], level + 1);
             }
             out[me] = d;
             return me;
         }
-    } r{m, out};
-    if (m.nodes.size() < 2) return fail(RT_ERR_ARG, "mesh BVH is empty");
-    if (r.is_leaf(1)) { root_ref = r.leaf_ref(1); stack_need = 0; }
-    else { root_ref = r.go(1, 1); stack_need = 3 * r.max_levels; }
-    if (r.bad) return fail(RT_ERR_ARG, "mesh BVH is malformed (child/element index out of range)");
-    if (out.size() >= 0x10000000u) return fail(RT_ERR_LIMIT, "mesh BVH too large");
+    } col{bn, out, area, leafref, max_levels};
+    if (bn[root].left < 0) { root_ref = leafref(bn[root].first, bn[root].count); stack_need = 0; }
+    else { root_ref = col.go(root, 1); stack_need = 3 * max_levels; }
     return RT_OK;
 }
-#else
-static rt_status convert_bvh(const rt::MeshData &m, std::vector<DevBvhNode> &out, uint32_t &root_ref, int &depth_out)
-{
-    struct Rec {
-        const rt::MeshData &m; std::vector<DevBvhNode> &out; int max_depth = 0; bool bad = false;
-        uint32_t go(uint32_t id, int depth)
-        {
-            // a well-formed tree visits every node once: more device nodes than input nodes means a cycle
-            if (bad || id == 0 || id >= m.nodes.size() || depth > 512 || out.size() > m.nodes.size()) { bad = true; return LEAFREF(0, 1); }
-            if (depth > max_depth) max_depth = depth;
-            const rt_bvh_node &n = m.nodes[id];
-            if (n.data & 0x80000000u) {
-                const uint32_t cnt = ((n.data >> 28) & 7u) + 1, off = n.data & 0x0FFFFFFFu;
-                if ((size_t)off + cnt > m.elements.size()) { bad = true; return LEAFREF(0, 1); }
-                return LEAFREF(off, cnt);
-            }
-            const uint32_t c = n.data & 0x7FFFFFFFu;
-            if (c == 0 || (size_t)c + 1 >= m.nodes.size()) { bad = true; return LEAFREF(0, 1); }
-            const uint32_t me = (uint32_t)out.size();
-            out.push_back(DevBvhNode{});
-            DevBvhNode d{};
-            memcpy(d.lo0, m.nodes[c].box, 12); memcpy(d.hi0, m.nodes[c].box + 3, 12);
-            memcpy(d.lo1, m.nodes[c + 1].box, 12); memcpy(d.hi1, m.nodes[c + 1].box + 3, 12);
-            d.c0 = go(c, depth + 1);
-            d.c1 = go(c + 1, depth + 1);
-            out[me] = d;
-            return me;
-        }
-        static uint32_t LEAFREF(uint32_t off, uint32_t cnt) { return 0x80000000u | ((cnt - 1) << 28) | (off & 0x0FFFFFFFu); }
-    } r{m, out};
-    root_ref = r.go(1, 1);
-    depth_out = r.max_depth;
-    if (r.bad) return fail(RT_ERR_ARG, "mesh BVH is malformed (child/element index out of range)");
-    return RT_OK;
-}
-#endif
 
 static rt_status upload_scene(rt_scene *s, DeviceState *D)
 {
@@ -897,7 +943,8 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
         std::vector<DevBvhNode> bn;
         uint32_t root_ref = 0;
         int depth = 0;
-        if ((st = convert_bvh(m, bn, root_ref, depth))) return st;
+        std::vector<uint32_t> slot_face;
+        if ((st = build_sah_bvh(m, bn, slot_face, root_ref, depth))) return st;
         // (the smallest LDS stack of any tracing kernel is 24 entries; RT_BVH_SPILL more per thread wait in HBM: spill buffers below)
         if (depth > 24 + RT_BVH_SPILL) return fail(RT_ERR_LIMIT, "mesh %zu: the BVH can need %d traversal-stack entries, the device provides %d", mi, depth, 24 + RT_BVH_SPILL);
         max_depth = std::max(max_depth, depth);
@@ -906,7 +953,7 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
         std::vector<uint32_t> tri_face(nf);
         std::vector<float> nrm(9 * nf);
         for (size_t sidx = 0; sidx < nf; sidx++) {
-            const uint32_t face = m.elements[sidx];
+            const uint32_t face = slot_face[sidx];
             tri_face[sidx] = face;
             rt::Point3 P[3];
             for (int k = 0; k < 3; k++) { const float *q = &m.v[3 * (size_t)m.f[3 * (size_t)face + k]]; P[k] = rt::Point3(q[0], q[1], q[2]); }

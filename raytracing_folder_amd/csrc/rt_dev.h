@@ -7,8 +7,8 @@
 //                                      `chain` = ancestor node indices root..self (every level's
 //                                      ToNodeCoords is applied in turn, exactly like the
 //                                      recursion in FIN/main.cpp:108-130)
-//   per mesh   DevBvhNode[ ]           64 B: both children's boxes + child refs (one visit = one
-//                                      64-byte read, no separate child fetch)
+//   per mesh   DevBvhNode[ ]           128 B: four children's boxes + their refs (one visit = one 128-byte read
+//                                      for two levels of a binary tree); built from the triangles (surface-area heuristic)
 //              DevTri[ ]               48 B: A, B, C, unit face normal -- in LEAF order, so a
 //                                      leaf's triangles are contiguous
 //              nrm[ ]                  36 B per leaf-ordered triangle: its three vertex normals (read once per ray, on the
@@ -58,14 +58,6 @@ struct DevObject {
 };
 static_assert(sizeof(DevObject) == 128, "one object = two 64-byte scalar loads");
 
-#ifndef RT_BVH_WIDTH
-#define RT_BVH_WIDTH 4           // children per device BVH node: 4 = two levels of the reference's binary tree per visit (128-byte nodes); 2 = the binary tree as it is (64-byte nodes; A/B)
-#endif
-#if RT_BVH_WIDTH == 4
-// 128 bytes: the boxes of up to four children, one axis after the other (lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4]: six
-// 16-byte loads), and their refs.  Collapsed from the reference's binary tree (cyBVH.h:76-106) on the host: a node's children
-// are the grandchildren of the binary node it stands for (a child that is a leaf stays one child), in the reference's
-// child1-before-child2 order.  An unused child has NaN bounds (never entered).  One visit = ONE dependent read for two levels.
 // What a closest hit needs of its object once the loop over the objects is over: Node::FromNodeCoords (scene.h:509-513) of the
 // object's own node and of up to two ancestors below the root, INLINE -- every address depends on the object index alone, so
 // a lane's loads go out together (chasing object -> chain entry -> node transform level by level was seven dependent round
@@ -78,20 +70,16 @@ struct DevObjectBack {
 };
 static_assert(sizeof(DevObjectBack) == 16 + 96 * RT_BACK_LEVELS, "layout");
 
+// 128 bytes: the boxes of up to four children, one axis after the other (lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4]: six
+// 16-byte loads), and their refs.  Built on the host from the mesh's triangles (rt_api.cpp: binned surface-area heuristic,
+// leaves of at most four triangles, collapsed four-wide by the largest child first).  An unused child has NaN bounds (never
+// entered).  One visit = ONE dependent read for two levels of a binary tree.
 struct DevBvhNode {
     float lo[3][4], hi[3][4];
     uint32_t c[4];               // bit31: leaf (bits28-30 count-1, bits0-27 first triangle slot); else the index of a DevBvhNode
     uint32_t pad[4];
 };
 static_assert(sizeof(DevBvhNode) == 128, "one visit = one 128-byte record");
-#else
-struct DevBvhNode {              // 64 bytes
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
-    uint32_t c0, c1;             // bit31: leaf (bits28-30 count-1, bits0-27 first triangle slot)
-    uint32_t pad[2];
-};
-#endif
 #define RT_BVH_SPILL 16          // traversal-stack entries per thread beyond the kernel's LDS stack, in HBM (DevScene::bvh_spill): touched only by a
                                  // traversal deeper than the LDS stack (a four-wide node leaves up to three entries per level)
 #define RT_SPILL_BLOCKS 1280     // workgroups the spill buffer is sized for (every tracing launch stays within it)

@@ -313,7 +313,6 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
     const uint32_t DONE = 0xFFFFFFFFu;                  // has LEAF_BIT set: ends the inner loop
     while (cur != DONE) {
         while (!(cur & LEAF_BIT)) {
-#if RT_BVH_WIDTH == 4
             // one 128-byte record = the boxes of four children (two levels of the reference's tree): six 16-byte loads of
             // bounds, one of refs, issued together -- ONE dependent round trip where the binary tree takes two
             const float4 *np = (const float4 *)(M.nodes + cur);
@@ -335,20 +334,6 @@ __device__ bool mesh_hit(const DevMesh *Mp, V3 o, V3 d, float &z, V3 &hp, V3 &hN
             if (e2 < 2.0e30f) bvh_push(stack, sp, c2);
             if (e1 < 2.0e30f) bvh_push(stack, sp, c1);
             cur = (e0 < 2.0e30f) ? c0 : (sp ? bvh_pop(stack, sp) : DONE);
-#else
-            const DevBvhNode nd = M.nodes[cur];
-            cnt.nodes++;
-            const float e0 = box_entry(nd.lo0, nd.hi0, o, inv, z);
-            const float e1 = box_entry(nd.lo1, nd.hi1, o, inv, z);
-            const bool h0 = e0 < 2.0e30f, h1 = e1 < 2.0e30f;
-            if (h0 && h1) {
-                const bool first0 = e0 <= e1;
-                bvh_push(stack, sp, first0 ? nd.c1 : nd.c0);
-                cur = first0 ? nd.c0 : nd.c1;
-            } else if (h0) cur = nd.c0;
-            else if (h1) cur = nd.c1;
-            else cur = sp ? bvh_pop(stack, sp) : DONE;
-#endif
         }
         if (cur == DONE) break;
         const uint32_t count = ((cur >> 28) & 7u) + 1;

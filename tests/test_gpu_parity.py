@@ -112,6 +112,54 @@ def test_trace_100k_triangle_mesh_bit_exact():
         _assert_hits_equal(s.trace_rays(rays, model), hit, hits)
 
 
+def test_device_bvh_on_awkward_meshes_bit_exact():
+    """The kernels walk a tree of their own (binned surface-area heuristic, four-wide; rt_api.cpp) while the oracle walks the
+    reference's mean-split tree: the closest hit must not depend on which -- on meshes that push the builder off its main path: a
+    single triangle, fewer triangles than a node has children, hundreds of triangles with ONE centroid (no split plane: halves
+    by index), a sliver strip (one centroid axis), a flat grid (coplanar neighbours: equal t on shared edges) and a random soup of
+    wildly different triangle sizes."""
+    rng = np.random.default_rng(41)
+    def soup(n, scale):
+        c = rng.uniform(-5, 5, (n, 1, 3))
+        return (c + rng.normal(scale=scale, size=(n, 3, 3))).reshape(-1, 3).astype(np.float32), np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    cases = {}
+    cases["one"] = soup(1, 2.0)
+    cases["three"] = soup(3, 2.0)
+    v1 = np.tile(np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32), (300, 1))               # 300 copies of ONE triangle
+    cases["stack"] = (v1, np.arange(900, dtype=np.uint32).reshape(300, 3))
+    xs = np.linspace(-8, 8, 400).astype(np.float32)
+    strip_v = np.stack([np.repeat(xs, 2), np.tile(np.array([-0.05, 0.05], np.float32), 400), np.zeros(800, np.float32)], 1)
+    strip_f = np.array([[2 * i, 2 * i + 2, 2 * i + 1] for i in range(399)] + [[2 * i + 1, 2 * i + 2, 2 * i + 3] for i in range(399)], np.uint32)      # facing +z
+    cases["strip"] = (strip_v, strip_f)
+    gx, gy = np.meshgrid(np.linspace(-6, 6, 40), np.linspace(-6, 6, 40))
+    grid_v = np.stack([gx.ravel(), gy.ravel(), np.zeros(1600)], 1).astype(np.float32)
+    gf = []
+    for j in range(39):
+        for i in range(39):
+            a = j * 40 + i
+            gf += [[a, a + 1, a + 41], [a, a + 41, a + 40]]
+    cases["grid"] = (grid_v, np.array(gf, np.uint32))
+    big_v, big_f = soup(6000, 0.05)
+    hv, hf = soup(40, 3.0)
+    cases["soup"] = (np.concatenate([big_v, hv]), np.concatenate([big_f, hf + len(big_v)]))
+    for name, (v, f) in cases.items():
+        nodes, el = capi.bvh_build(v, f, 4)
+        vn = np.tile(np.array([[0, 0, 1]], np.float32), (len(v), 1))
+        s = capi.Scene()
+        s.set_nodes(np.concatenate([scenes.identity_node(), scenes.identity_node(0, capi.OBJ_MESH, 0, 0)]))
+        s.set_mesh(0, v, f, vn, f, nodes, el)
+        s.set_materials(np.zeros(1, capi.BLINN))
+        osc = scenes.oracle_scene(s.export())
+        o = rng.uniform(-9, 9, (4000, 3)) + np.array([0, 0, 12.0])
+        tgt = v[rng.integers(0, len(v), 4000)] + rng.normal(scale=0.02 if name == "strip" else 0.3, size=(4000, 3))
+        rays = np.concatenate([o, tgt - o], 1).astype(np.float32)
+        for model in (capi.SHADE_FIN, capi.SHADE_P13):
+            hit, hits = orc.trace(osc, model, rays)
+            got = s.trace_rays(rays, model)
+            assert hit.sum() > 20, name
+            _assert_hits_equal(got, hit, hits)         # (where two triangles give EXACTLY the same t -- the copies, the grid's shared edges -- they give the same record too)
+
+
 def test_config5_stand_in_frame_and_full_size_properties():
     """BASELINE config 5 (christmas_balls: geometry and HDRI absent from the reference tree) on its stand-in:
     both 51 k-triangle meshes, the mirror material, the PNG sky as environment AND background, FIN model --
