@@ -100,6 +100,10 @@ if sq:
             # cycles for a while in round 2: the build without packed ops then came out at 1.17 of that "peak".  Packed f32 ops
             # (v_pk_*) hold the pipe twice as long; they are counted once here.
             d["valu_issue_frac_of_peak"] = round(d["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e3 * d["avg_launch_us"]), 4)
+            # ... and against what the chip was MEASURED to issue (tools_peaks.hip -> profiles/r*_peaks.json, newest), under the profiler's clock
+            pk = sorted(glob.glob("profiles/r[0-9]*_peaks.json"))
+            if pk:
+                d["valu_frac_of_measured_peak"] = round(d["SQ_INSTS_VALU"] / (d["avg_launch_us"] * 1e3) / json.load(open(pk[-1]))["valu_peak_Gwave_inst_per_s"], 4)
         if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]:
             d["wait_any_frac"] = round(d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], 4)
         if "TCC_HIT_sum" in d and d["TCC_HIT_sum"] + d.get("TCC_MISS_sum", 0) > 0:
