@@ -945,8 +945,8 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
         int depth = 0;
         std::vector<uint32_t> slot_face;
         if ((st = build_sah_bvh(m, bn, slot_face, root_ref, depth))) return st;
-        // (the smallest LDS stack of any tracing kernel is 24 entries; RT_BVH_SPILL more per thread wait in HBM: spill buffers below)
-        if (depth > 24 + RT_BVH_SPILL) return fail(RT_ERR_LIMIT, "mesh %zu: the BVH can need %d traversal-stack entries, the device provides %d", mi, depth, 24 + RT_BVH_SPILL);
+        // (the smallest LDS stack of any tracing kernel is RT_BVH_LDS entries; RT_BVH_SPILL more per thread wait in HBM: spill buffers below)
+        if (depth > RT_BVH_LDS + RT_BVH_SPILL) return fail(RT_ERR_LIMIT, "mesh %zu: the BVH can need %d traversal-stack entries, the device provides %d", mi, depth, RT_BVH_LDS + RT_BVH_SPILL);
         max_depth = std::max(max_depth, depth);
         const size_t nf = m.f.size() / 3;
         std::vector<DevTri> tris(nf);
@@ -1009,7 +1009,7 @@ static rt_status upload_scene(rt_scene *s, DeviceState *D)
     S.use_uvw = sd.material_maps.empty() ? 0 : 1;
     S.max_bvh_depth = max_depth;
     S.bvh_spill = nullptr;
-    if (max_depth > 24) {
+    if (max_depth > RT_BVH_LDS) {
         if ((st = D->bvh_spill.ensure(SPILL_BYTES))) return st;
         S.bvh_spill = (uint32_t *)D->bvh_spill.p;
     }
@@ -1217,7 +1217,7 @@ static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int 
     for (int k = 0; k < 3; k++) if ((st = w.pq[k].ensure((size_t)pq_cap * 16))) return st;
     if (caustic) for (int k = 0; k < 3; k++) if ((st = w.cq[k].ensure((size_t)pq_cap * 16))) return st;
     if ((st = w.counts.ensure(CNT_TOTAL * 4))) return st;
-    if (D->scene.max_bvh_depth > 24 && (st = w.bvh_spill.ensure(SPILL_BYTES))) return st;
+    if (D->scene.max_bvh_depth > RT_BVH_LDS && (st = w.bvh_spill.ensure(SPILL_BYTES))) return st;
     if ((st = w.pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
     if (!D->stats.p) { if ((st = D->stats.ensure(ST_COUNT * 8))) return st; }
     if (slot > 0 && !w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
@@ -1237,7 +1237,7 @@ static DevWork make_work(DeviceState *D, int slot)
     W.pq.qa = (float4 *)w.pq[0].p; W.pq.qb = (float4 *)w.pq[1].p; W.pq.qc = (float4 *)w.pq[2].p; W.pq.cap = w.pq_cap;
     W.cq.qa = (float4 *)w.cq[0].p; W.cq.qb = (float4 *)w.cq[1].p; W.cq.qc = (float4 *)w.cq[2].p; W.cq.cap = w.cq[0].p ? w.pq_cap : 0;
     W.counts = (uint32_t *)w.counts.p; W.pixel_list = (uint32_t *)w.pixel_list.p;
-    W.bvh_spill = D->scene.max_bvh_depth > 24 ? (uint32_t *)w.bvh_spill.p : nullptr;
+    W.bvh_spill = D->scene.max_bvh_depth > RT_BVH_LDS ? (uint32_t *)w.bvh_spill.p : nullptr;
     W.stats = (unsigned long long *)D->stats.p;
     return W;
 }
@@ -1356,6 +1356,8 @@ static rt_status run_pipeline(DeviceState *D, int slot, hipStream_t st, const De
     // models without that kernel, take one launch per level
     int first_level = 1;
     if (max_level >= 2 && rtk_launch_wavefront_queue(st, D->scene, W, P, W.rq[1], W.counts + 1, W.rq[0], W.counts + 2, dc, dt, q0, max_sample, mode)) first_level = 2;
+    // (further passes of the same kernel over what the second one could not keep were measured: 1 / 2 / 3 / 4 queue passes, tracer ms behind
+    // the first pass, Cornell 0.34 / 0.36 / 0.40 / 0.44, C3 13.0 / 13.0 / 13.1 / 13.1 -- the second pass takes everything that matters)
     for (int level = first_level; level <= max_level && level < 15; level++)
         rtk_launch_bounce(st, D->scene, W, P, W.rq[level & 1], W.rq[(level + 1) & 1], W.counts + level + 1, level, max_blocks);
     if ((s = mark(1))) return s;

@@ -80,8 +80,18 @@ struct DevBvhNode {
     uint32_t pad[4];
 };
 static_assert(sizeof(DevBvhNode) == 128, "one visit = one 128-byte record");
-#define RT_BVH_SPILL 16          // traversal-stack entries per thread beyond the kernel's LDS stack, in HBM (DevScene::bvh_spill): touched only by a
-                                 // traversal deeper than the LDS stack (a four-wide node leaves up to three entries per level)
+// A thread's BVH traversal stack: RT_BVH_LDS entries per lane in LDS in k_wavefront (the per-level kernels keep RT_BVH_STACK) and
+// RT_BVH_SPILL more per thread in HBM behind them (DevScene::bvh_spill; allocated for scenes whose trees can need more than the LDS
+// part, touched only by a traversal that is that deep).  Measured on MI355X (frame ms Cornell / 102 k triangles / C3, LDS entries
+// and the ray stack the freed LDS buys, see WfCfg): 24 + 592 rays: 38.5 / 22.9 / 196.7; 12 + 840: 37.0 / 22.5 / 185.1; 8 + 928: 37.0 /
+// 22.5 / 185.1; 4 + 1020: 37.1 / 23.1 / 186.7; 2 + 1064: 37.1 / 23.8 / 193.3 -- the LDS is worth more as ray stack (rays that do not
+// fit take the global queue and a second pass) than as traversal stack (a deep traversal's pops come from L2 instead).
+#ifndef RT_BVH_LDS
+#define RT_BVH_LDS 8
+#endif
+#ifndef RT_BVH_SPILL
+#define RT_BVH_SPILL 32
+#endif
 #define RT_SPILL_BLOCKS 1280     // workgroups the spill buffer is sized for (every tracing launch stays within it)
 
 struct DevTri { float A[3], B[3], C[3], N[3]; };   // 48 bytes

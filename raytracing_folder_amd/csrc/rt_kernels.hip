@@ -1280,6 +1280,7 @@ struct PrimaryArgs {
     int j0, ns, max_sample, mode;
     const float *rays;           // mode 2
     FastDiv div_ns;
+    uint32_t lds_rays;           // k_wavefront: entries of the LDS ray stack to use (0: all of them; the test hook RT_WF_LDS_RAYS makes the stack overflow on small frames)
     DevRayQueue qsrc;            // mode 3 (k_wavefront only): the work is a ray queue (count in *qsrc_count), not primary samples
     const uint32_t *qsrc_count;
 };
@@ -1413,8 +1414,10 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
 // ------------------------------------------------------------------------------------------------
 // Configuration: the texture-free instantiations run THREE workgroups per CU (3 waves/SIMD: the traversal waits on dependent
 // loads for 0.44 of its wave cycles at two) -- 168 VGPRs, and per workgroup at most 53 760 B of LDS (160 KB / 3 in 1280-byte
-// granules): 24 BVH stack entries per lane (24.6 KB; meshes deeper than that take the per-level kernels, see
-// rtk_launch_primary) + a 592-ray stack of 48-byte records (28.4 KB) + two 64-entry Halton tables.  The textured
+// granules): RT_BVH_LDS = 8 BVH stack entries per lane (8 KB; a deeper traversal continues in the HBM spill part, rt_dev.h) + a
+// 928-ray stack of 48-byte records (44.5 KB) + two 64-entry Halton tables.  (Round 3 and the start of round 4: 24 entries + 592
+// rays.  The rays that do not fit the stack take the global queue, a second pass and the per-level launches: 7.8 M of the Cornell
+// frame's 42 M secondary rays and 1.8 ms at 592 rays, 0.6 M and 0.36 ms at 928; C3: 27 -> 13 ms.)  The textured
 // instantiations get the same configuration (the compiler would take 255 VGPRs for them; held to 168 the texture lookups'
 // temporaries go to scratch, which costs less than the third wave buys).  RT_WF_WAVES=2 / RT_WF_TEX_WAVES=2: two workgroups
 // per CU, 32-entry BVH stacks, 1008 rays (A/B builds).
@@ -1427,8 +1430,11 @@ RT_TRACE_OCC __global__ __launch_bounds__(RT_BLOCK) void k_bounce(ShadeCtx C, De
 #define RT_WF_HALTON 64
 template <bool TEX> struct WfCfg {
     static constexpr int WAVES = TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES;
-    static constexpr int BVH = WAVES >= 3 ? 24 : RT_BVH_STACK;
-    static constexpr int STACK = WAVES >= 3 ? 592 : 1008;
+#ifndef RT_WF_STACK
+#define RT_WF_STACK 928
+#endif
+    static constexpr int BVH = WAVES >= 3 ? RT_BVH_LDS : RT_BVH_STACK;
+    static constexpr int STACK = WAVES >= 3 ? RT_WF_STACK : 1008;
     // pop a round as soon as a round of primary rays (two children each) could no longer be sure to fit
     static constexpr int POP = STACK - 2 * RT_BLOCK + 1 < RT_BLOCK ? STACK - 2 * RT_BLOCK + 1 : RT_BLOCK;
     static_assert(BVH * RT_BLOCK * 4 + STACK * 48 + 2 * RT_WF_HALTON * 4 + 16 <= (WAVES >= 3 ? 53760 : 81920), "LDS budget of the occupancy the kernel is built for");
@@ -1554,7 +1560,7 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
     uint32_t *next_batch = C.W.counts + (A.mode == 3 ? CNT_WF2_NEXT : CNT_PRIMARY_NEXT);
     if (h_table && (int)threadIdx.x < A.ns) { s_h2[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 2); s_h3[threadIdx.x] = halton(A.j0 + (int)threadIdx.x, 3); }
     if (threadIdx.x == 0) s_count = 0;
-    C.lds_a = s_qa; C.lds_b = s_qb; C.lds_c = s_qc; C.lds_count = &s_count; C.lds_cap = Cfg::STACK;
+    C.lds_a = s_qa; C.lds_b = s_qb; C.lds_c = s_qc; C.lds_count = &s_count; C.lds_cap = (A.lds_rays && A.lds_rays < (uint32_t)Cfg::STACK) ? A.lds_rays : (uint32_t)Cfg::STACK;
     bool more_primaries = true;                           // workgroup-uniform
     for (;;) {
         __syncthreads();                                  // last round's pushes are complete
@@ -1582,7 +1588,7 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
             in.slot = 0; in.bounce = 0; in.kind = 0; in.node = 1; in.sample = 0; in.spec = 0;
             in.side_dir = mk(0, 0, 1); in.side_K = mk(0, 0, 0);
             if (active) {
-                const uint32_t src = pside ? (uint32_t)Cfg::STACK - wside + threadIdx.x : wside - 1u - threadIdx.x;
+                const uint32_t src = pside ? C.lds_cap - wside + threadIdx.x : wside - 1u - threadIdx.x;
                 const float4 a = s_qa[src], b = s_qb[src], c = s_qc[src];
                 in.o = mk(a.x, a.y, a.z); in.d = mk(a.w, b.x, b.y);
                 in.thr = mk(b.z, b.w, c.x);
@@ -2755,9 +2761,17 @@ static SlotMap make_slotmap(const DevCamera &cam, const DevTiles &tiles_prepared
     m.div_ms = fastdiv_make((uint32_t)(max_sample > 0 ? max_sample : 1));
     return m;
 }
-// k_wavefront serves the FIN and P13 models (at most two children per hit) when every mesh's BVH fits the traversal stack the
-// kernel keeps in LDS (24 entries per lane at 3 workgroups per CU; deeper meshes take the per-level kernels with 32);
+// k_wavefront serves the FIN, P13 and P12 models when every mesh's BVH fits its traversal stack (RT_BVH_LDS entries per lane in LDS
+// + RT_BVH_SPILL per thread in HBM; the host refuses meshes beyond that);
 // RT_TRACER=levels forces the per-level structure (A/B)
+// test hook: RT_WF_LDS_RAYS=n makes k_wavefront's workgroup rounds use only n entries of their LDS ray stack, so that a small frame
+// already sends rays through the global queue, the second pass and the per-level launches
+static uint32_t wf_lds_rays()
+{
+    const char *e = getenv("RT_WF_LDS_RAYS");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (uint32_t)v : 0u;
+}
 static bool wavefront_usable(const DevScene &S, const rt_params &P, bool tex)
 {
     static int wavefront = -1;
@@ -2770,7 +2784,7 @@ static bool wavefront_usable(const DevScene &S, const rt_params &P, bool tex)
     const bool model_ok = P.shade_model == RT_SHADE_FIN || P.shade_model == RT_SHADE_P13 || (P.shade_model == RT_SHADE_P12 && p12 && P.hemisphere_sample <= 2);
     if (!wavefront || !model_ok) return false;
     // (the traversal stack: the kernel's LDS part plus, when the scene has the spill buffer, RT_BVH_SPILL entries per thread behind it)
-    return S.max_bvh_depth <= (tex ? WfCfg<true>::BVH : WfCfg<false>::BVH) + (S.max_bvh_depth > 24 ? RT_BVH_SPILL : 0);
+    return S.max_bvh_depth <= (tex ? WfCfg<true>::BVH : WfCfg<false>::BVH) + (S.max_bvh_depth > RT_BVH_LDS ? RT_BVH_SPILL : 0);
 }
 
 bool rtk_wavefront_usable(const DevScene &S, const rt_params &P)
@@ -2785,7 +2799,7 @@ void rtk_launch_primary(hipStream_t st, const DevScene &S, const DevWork &W, con
 {
     ShadeCtx C; C.S = S; C.S.bvh_spill = W.bvh_spill; C.W = W; C.P = P; C.qout = qout; C.qout_count = qout_count;
     PrimaryArgs A; A.cam = cam; A.tiles = tiles; A.q0 = q0; A.npix = npix; A.j0 = j0; A.ns = ns;
-    A.max_sample = max_sample; A.mode = mode; A.rays = rays;
+    A.max_sample = max_sample; A.mode = mode; A.rays = rays; A.lds_rays = wf_lds_rays();
     tiles_prepare(A.tiles);
     A.div_ns = fastdiv_make((uint32_t)(ns > 0 ? ns : 1));
     const int grid = grid_for((unsigned long long)npix * ns, RT_BLOCK, max_blocks);
@@ -2838,7 +2852,7 @@ bool rtk_launch_wavefront_queue(hipStream_t st, const DevScene &S, const DevWork
     C.sm = make_slotmap(cam, tp, q0, max_sample, mode);
     PrimaryArgs A;
     memset(&A, 0, sizeof A);
-    A.mode = 3; A.ns = 1; A.qsrc = qin; A.qsrc_count = qin_count;
+    A.mode = 3; A.ns = 1; A.qsrc = qin; A.qsrc_count = qin_count; A.lds_rays = wf_lds_rays();
     A.div_ns = fastdiv_make(1u);
     const int wgrid = 256 * (tex ? RT_WF_TEX_WAVES : RT_WF_WAVES);       // the count is on the device: a full persistent grid, idle workgroups leave at once
     if (P.shade_model == RT_SHADE_FIN) {

@@ -237,11 +237,12 @@ def test_config5_stand_in_at_its_stated_256_samples_per_pixel(monkeypatch):
     assert checked == 24
 
 
-def test_frame_that_overflows_the_lds_ray_stacks(cornell):
-    """the camera looks at the glass sphere from close by, 32 samples per pixel: every ray of a workgroup's 256-sample
-    round spawns a reflection and a refraction, so the 704-ray LDS stacks of k_wavefront overflow into the global queue
-    -- the second k_wavefront pass (queue as the source) and the per-level launches behind it all take part, and the
-    frame must still be the oracle's"""
+def test_frame_that_overflows_the_lds_ray_stacks(cornell, monkeypatch):
+    """the camera looks at the glass sphere from close by, 32 samples per pixel, eight bounces: every ray of a workgroup's
+    256-sample round spawns a reflection and a refraction, level after level; with the LDS ray stacks of k_wavefront held to
+    300 entries (test hook RT_WF_LDS_RAYS; 928 would swallow this small frame) they overflow into the global queue -- the second
+    k_wavefront pass (queue as the source) and the per-level launches behind it all take part, and the frame must still be the
+    oracle's"""
     s, cam0, e = cornell
     s2, cam = scenes.load_cornell(48, 36)
     target = np.array([-8.0, -6.0, 4.0])                    # sphere2: glass
@@ -253,7 +254,8 @@ def test_frame_that_overflows_the_lds_ray_stacks(cornell):
     for i in range(3):
         cam.pos[i], cam.dir[i], cam.up[i] = pos[i], d[i], up[i]
     cam.fov = 24.0
-    p = capi.default_params(min_sample=32, max_sample=32, threshold=-1.0, bounce=5)
+    p = capi.default_params(min_sample=32, max_sample=32, threshold=-1.0, bounce=8)
+    monkeypatch.setenv("RT_WF_LDS_RAYS", "300")
     rgb, z, cnt, st, _ = s2.render(cam, p)
     orgb, oz, ocnt = orc.render(scenes.oracle_scene(e), scenes.oracle_camera(cam), scenes.oracle_params(p))
     _frame_gate(rgb, orgb, z, oz, cnt, ocnt)
