@@ -169,7 +169,11 @@ typedef struct rt_params {
      * the replacement of BeginRender, which calls generatePhotonMap() before it spawns its workers (:984-998) -- runs the
      * photon pass first, on the job's thread, when shade_model is RT_SHADE_FIN, photon_count > 0 and the scene holds no
      * photon map yet (rt_scene_set_photons / rt_scene_generate_photons); photon_count = 0 renders the scene as it is.
-     * The generator is seeded with `seed`.  The device-side entry points (rt_render_tiles_*) never generate. */
+     * The generator is seeded with `seed`.  The device-side entry points (rt_render_tiles_*) never generate.
+     * A map the library generated is DERIVED from the scene (ABI 4): rt_scene_set_nodes / _mesh / _materials / _lights and
+     * rt_scene_load_xml drop it, and rt_render_begin makes a new one when photon_count, photon_bounce or seed differ from
+     * the ones it was made with -- the reference regenerates on every BeginRender (FIN/main.cpp:984-990).  A map the caller
+     * handed over with rt_scene_set_photons is the caller's and stays until it is replaced. */
     int32_t  photon_count;
     int32_t  photon_bounce;
 } rt_params;
