@@ -47,6 +47,7 @@ static int gather_blocks()
     }
     return n;
 }
+static const size_t STATS_BYTES = (size_t)ST_COUNT * RT_STAT_STRIDE * 8;    // the statistics block: counters RT_STAT_STRIDE apart (rt_dev.h)
 #define GATHER_BLOCKS gather_blocks()
 
 void rtk_launch_photon_trace(hipStream_t, const DevScene &, unsigned long long, uint32_t, uint32_t, int, float *, uint32_t *, int);
@@ -1219,7 +1220,7 @@ static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int 
     if ((st = w.counts.ensure(CNT_TOTAL * 4))) return st;
     if (D->scene.max_bvh_depth > RT_BVH_LDS && (st = w.bvh_spill.ensure(SPILL_BYTES))) return st;
     if ((st = w.pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
-    if (!D->stats.p) { if ((st = D->stats.ensure(ST_COUNT * 8))) return st; }
+    if (!D->stats.p) { if ((st = D->stats.ensure(STATS_BYTES))) return st; }
     if (slot > 0 && !w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     w.samples = samples; w.rq_cap = (uint32_t)rq_cap; w.pq_cap = (uint32_t)pq_cap;
     return RT_OK;
@@ -1249,11 +1250,24 @@ static rt_status order_after_pending(DeviceState *D, hipStream_t st)
     return RT_OK;
 }
 // Dropped rays / photon queries of the renders since the counter was last cleared (host-synchronous read).
+// The statistics block keeps its counters RT_STAT_STRIDE apart (rt_dev.h): counters [first, first + n) as a dense array, and back to zero
+static hipError_t stats_read(const void *dev, int first, int n, unsigned long long *out)
+{
+    return hipMemcpy2D(out, 8, (const unsigned long long *)dev + ST_AT(first), (size_t)RT_STAT_STRIDE * 8, 8, (size_t)n, hipMemcpyDeviceToHost);
+}
+static hipError_t stats_zero(void *dev, int first, int n, hipStream_t st)
+{
+    if (first == 0 && n == ST_COUNT) return hipMemsetAsync(dev, 0, STATS_BYTES, st);
+    for (int i = first; i < first + n; i++)
+        if (hipError_t e = hipMemsetAsync((unsigned long long *)dev + ST_AT(i), 0, 8, st)) return e;
+    return hipSuccess;
+}
+
 static rt_status read_overflow(DeviceState *D, unsigned long long *drops)
 {
     *drops = 0;
     if (!D->stats.p) return RT_OK;
-    HIP_TRY(hipMemcpy(drops, (unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(stats_read(D->stats.p, ST_QUEUE_OVERFLOW, 1, drops));
     return RT_OK;
 }
 
@@ -1427,7 +1441,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         HIP_TRY(hipEventSynchronize(D->last_done));
         unsigned long long drops = 0;
         if ((st = read_overflow(D, &drops))) return st;
-        if (drops) { D->async_overflow = true; D->qhist.valid = false; HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 0, 8)); }
+        if (drops) { D->async_overflow = true; D->qhist.valid = false; HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_AT(ST_QUEUE_OVERFLOW), 0, 8)); }
         D->last_pending = false;
     }
 
@@ -1520,14 +1534,14 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         }
     } event_guard{tm, e_begin, e_end, resolve_ev, flight};
     if (want_stats) {
-        HIP_TRY(hipMemsetAsync(Ws[0].stats, 0, ST_COUNT * 8, stream));
+        HIP_TRY(stats_zero(Ws[0].stats, 0, ST_COUNT, stream));
         HIP_TRY(hipEventCreate(&e_begin)); HIP_TRY(hipEventCreate(&e_end));
         HIP_TRY(hipEventRecord(e_begin, stream));
     } else if (!D->last_pending) {
         // the drop counter is read back after every synchronous render (below) and by rt_render_check after
         // asynchronous ones; consecutive asynchronous renders accumulate into it until it is checked
-        HIP_TRY(hipMemsetAsync(Ws[0].stats + ST_QUEUE_OVERFLOW, 0, 8, stream));
-        HIP_TRY(hipMemsetAsync(Ws[0].stats + ST_PEAK_RAYS, 0, 16, stream));
+        HIP_TRY(stats_zero(Ws[0].stats, ST_QUEUE_OVERFLOW, 1, stream));
+        HIP_TRY(stats_zero(Ws[0].stats, ST_PEAK_RAYS, 2, stream));
     }
     // the gathers' start tables are built on `stream` before the slots fork from it
     if ((st = ensure_cell_start(D, false, p->knn_k, p->knn_radius, stream))) return st;
@@ -1647,7 +1661,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         {
             // a dropped ray or photon query means a wrong image: never RT_OK, whether or not statistics were asked for
             unsigned long long tail[ST_COUNT - ST_QUEUE_OVERFLOW];
-            HIP_TRY(hipMemcpy(tail, (unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, sizeof tail, hipMemcpyDeviceToHost));
+            HIP_TRY(stats_read(D->stats.p, ST_QUEUE_OVERFLOW, ST_COUNT - ST_QUEUE_OVERFLOW, tail));
             const unsigned long long drops = tail[0], peak_r = tail[ST_PEAK_RAYS - ST_QUEUE_OVERFLOW], peak_q = tail[ST_PEAK_QUERIES - ST_QUEUE_OVERFLOW];
             if (drops) {
                 D->qhist.valid = false;
@@ -1669,7 +1683,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         rt_stats R;
         memset(&R, 0, sizeof R);
         unsigned long long hs[ST_COUNT];
-        HIP_TRY(hipMemcpy(hs, Ws[0].stats, sizeof hs, hipMemcpyDeviceToHost));
+        HIP_TRY(stats_read(Ws[0].stats, 0, ST_COUNT, hs));
         R.rays_primary = hs[ST_RAYS_PRIMARY]; R.rays_shadow = hs[ST_RAYS_SHADOW]; R.rays_reflect = hs[ST_RAYS_REFLECT];
         R.rays_refract = hs[ST_RAYS_REFRACT]; R.instance_visits = hs[ST_INSTANCE_VISITS]; R.bvh_nodes_visited = hs[ST_BVH_NODES];
         R.tris_tested = hs[ST_TRIS]; R.photon_queries = hs[ST_PHOTON_QUERIES]; R.photons_visited = hs[ST_PHOTONS_VISITED];
@@ -1787,7 +1801,7 @@ extern "C" rt_status rt_render_check(rt_scene *s, int device)
     D->async_overflow = false;
     if (drops || earlier) {
         D->qhist.valid = false;                             // the next render starts from the worst case again
-        if (drops) HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_QUEUE_OVERFLOW, 0, 8));
+        if (drops) HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_AT(ST_QUEUE_OVERFLOW), 0, 8));
         return fail(RT_ERR_LIMIT, "rt_render_check: a ray/photon queue overflowed (%llu drops) in an asynchronous render", drops);
     }
     return RT_OK;
@@ -1809,7 +1823,7 @@ extern "C" rt_status rt_render_counters(rt_scene *s, int device, int reset, rt_s
     // (the verdict of the asynchronous renders stays with rt_render_check: last_pending is left as it is)
     if (D->last_pending && D->last_done) HIP_TRY(hipEventSynchronize(D->last_done));
     unsigned long long hs[ST_COUNT];
-    HIP_TRY(hipMemcpy(hs, D->stats.p, sizeof hs, hipMemcpyDeviceToHost));
+    HIP_TRY(stats_read(D->stats.p, 0, ST_COUNT, hs));
     out->rays_primary = hs[ST_RAYS_PRIMARY]; out->rays_shadow = hs[ST_RAYS_SHADOW]; out->rays_reflect = hs[ST_RAYS_REFLECT];
     out->rays_refract = hs[ST_RAYS_REFRACT]; out->instance_visits = hs[ST_INSTANCE_VISITS]; out->bvh_nodes_visited = hs[ST_BVH_NODES];
     out->tris_tested = hs[ST_TRIS]; out->photon_queries = hs[ST_PHOTON_QUERIES]; out->photons_visited = hs[ST_PHOTONS_VISITED];
@@ -1819,8 +1833,8 @@ extern "C" rt_status rt_render_counters(rt_scene *s, int device, int reset, rt_s
     if (reset) {
         // the drop counter and the queue peaks belong to the overflow verdict and the queue sizing: not touched
         static_assert(ST_QUEUE_OVERFLOW == ST_PHOTONS_VISITED + 1 && ST_GATHER_ROUNDS == ST_QUEUE_OVERFLOW + 1 && ST_PEAK_RAYS == ST_GATHER_LEAF_READS + 1, "counter layout");
-        HIP_TRY(hipMemset(D->stats.p, 0, ST_QUEUE_OVERFLOW * 8));
-        HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_GATHER_ROUNDS, 0, (ST_PEAK_RAYS - ST_GATHER_ROUNDS) * 8));
+        HIP_TRY(hipMemset(D->stats.p, 0, ST_AT(ST_QUEUE_OVERFLOW) * 8));
+        HIP_TRY(hipMemset((unsigned long long *)D->stats.p + ST_AT(ST_GATHER_ROUNDS), 0, ST_AT(ST_PEAK_RAYS - ST_GATHER_ROUNDS) * 8));
     }
     return RT_OK;
 }
@@ -1966,13 +1980,14 @@ extern "C" rt_status rt_estimate_irradiance(rt_scene *s, int device, int32_t k, 
         qb[i] = make_float4(normal[3 * i + 1], normal[3 * i + 2], 0, 0);
         qc[i] = make_float4(0, 0, 0, 0);
     }
-    const uint32_t cnt[9] = {(uint32_t)n, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};     // query count, the eight work counters
+    std::vector<uint32_t> cnt(1 + (size_t)RT_GATHER_CTRS * RT_CTR_STRIDE, 0u);  // query count, then the work counters as k_gather lays them out
+    cnt[0] = (uint32_t)n;
     if ((st = D->t_out[0].upload(qa.data(), (size_t)n * 16))) return st;
     if ((st = D->t_out[1].upload(qb.data(), (size_t)n * 16))) return st;
     if ((st = D->t_out[2].upload(qc.data(), (size_t)n * 16))) return st;
     if ((st = D->t_out[3].ensure((size_t)n * 12))) return st;
     if ((st = D->t_out[4].ensure((size_t)n * 12))) return st;
-    if ((st = D->t_in.upload(cnt, sizeof cnt))) return st;
+    if ((st = D->t_in.upload(cnt.data(), cnt.size() * 4))) return st;
     if ((st = ensure_cell_start(D, false, k, radius, D->stream))) return st;
     rtk_launch_gather(D->stream, D->scene.pm, (const float4 *)D->t_out[0].p, (const float4 *)D->t_out[1].p, (const float4 *)D->t_out[2].p,
                       (const uint32_t *)D->t_in.p, cnt[0], k, radius, nullptr, (float *)D->t_out[3].p, (float *)D->t_out[4].p, 1, nullptr, GATHER_BLOCKS,
@@ -2008,7 +2023,7 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
     const DevWork W = make_work(D, 0);
     DevCamera dc; camera_setup(cam, dc);
     DevTiles dt; memset(&dt, 0, sizeof dt);
-    HIP_TRY(hipMemsetAsync(W.stats, 0, ST_COUNT * 8, D->stream));
+    HIP_TRY(stats_zero(W.stats, 0, ST_COUNT, D->stream));
     for (int64_t off = 0; off < n; off += (int64_t)chunk) {
         const uint32_t m = (uint32_t)std::min<int64_t>((int64_t)chunk, n - off);
         if ((st = D->t_in.upload(rays + 6 * off, (size_t)m * 24))) return st;
@@ -2021,7 +2036,7 @@ extern "C" rt_status rt_shade_rays(rt_scene *s, const rt_params *p, int device, 
         HIP_TRY(hipMemcpy(z + off, W.sample_z, (size_t)m * 4, hipMemcpyDeviceToHost));
     }
     unsigned long long hs[ST_COUNT];
-    HIP_TRY(hipMemcpy(hs, W.stats, sizeof hs, hipMemcpyDeviceToHost));
+    HIP_TRY(stats_read(W.stats, 0, ST_COUNT, hs));
     if (hs[ST_QUEUE_OVERFLOW]) return fail(RT_ERR_LIMIT, "rt_shade_rays: queue overflow");
     for (int64_t i = 0; i < n; i++) if (!hit[i]) z[i] = 1.0e30f;
     return RT_OK;

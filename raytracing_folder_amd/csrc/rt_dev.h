@@ -202,7 +202,13 @@ static inline void tiles_prepare(DevTiles &t)
     t.div_tiles_x = fastdiv_make((uint32_t)t.tiles_x);
 }
 
-// device-side statistics block (uint64 counters, see rt_stats)
+// device-side statistics block (uint64 counters, see rt_stats).  Counter i lives at stats[ST_AT(i)]: RT_STAT_STRIDE uint64s (4 KB +
+// 256 B) apart, so that the atomics on different counters go to different memory channels instead of queueing on one line (the
+// note at RT_CTR_STRIDE below)
+#ifndef RT_STAT_STRIDE
+#define RT_STAT_STRIDE 544
+#endif
+#define ST_AT(i) ((size_t)(i) * RT_STAT_STRIDE)
 enum {
     ST_RAYS_PRIMARY = 0, ST_RAYS_SHADOW, ST_RAYS_REFLECT, ST_RAYS_REFRACT,
     ST_INSTANCE_VISITS, ST_BVH_NODES, ST_TRIS, ST_PHOTON_QUERIES, ST_PHOTONS_VISITED,
@@ -231,14 +237,24 @@ struct DevWork {
     unsigned long long *stats;
     uint32_t *bvh_spill;      // DevScene::bvh_spill of this working set's launches
 };
-#define CNT_PHOTONQ 16
-#define CNT_GATHER_NEXT 17     // work counters of k_gather, one per XCD (8): query batches handed out so far from each segment
-#define CNT_PRIMARY_NEXT 25    // work counter of k_wavefront: batches of 256 primary samples handed out so far
-#define CNT_CAUSTICQ 26        // caustic-map query count
-#define CNT_GATHER_NEXT2 27    // the eight work counters of the caustic gather
-#define CNT_WF2_NEXT 35        // work counter of k_wavefront's second pass (source: the overflow queue of the first)
-#define CNT_RESET   36         // counters [0, CNT_RESET) are cleared before every pass
-#define CNT_PIXLIST 46         // survives the passes of a chunk
-#define CNT_TOTAL   48
+// The hot ones -- work counters and queue tails that every wave of a launch adds to -- sit RT_CTR_STRIDE uint32s apart: device-scope
+// atomics are executed at the memory side, one after the other per channel (about 15-20 ns each), so counters that share a line queue
+// behind each other (r4: the end of a k_gather launch was 41 000 failing grabs on eight adjacent counters = 0.8 ms).  4 KB + 256 B
+// steps to another channel whether the interleave is 256 B or 4 KB.
+#ifndef RT_CTR_STRIDE
+#define RT_CTR_STRIDE 1088
+#endif
+#define CNT_PHOTONQ      (16 + 0 * RT_CTR_STRIDE)
+#define CNT_PRIMARY_NEXT (16 + 1 * RT_CTR_STRIDE)   // work counter of k_wavefront: batches of 256 primary samples handed out so far
+#define CNT_CAUSTICQ     (16 + 2 * RT_CTR_STRIDE)   // caustic-map query count
+#define CNT_WF2_NEXT     (16 + 3 * RT_CTR_STRIDE)   // work counter of k_wavefront's second pass (source: the overflow queue of the first)
+// k_gather's work counters, each RT_CTR_STRIDE apart: [seg] = 32-query batches handed out of XCD segment seg (8), [8] = mask of the
+// segments known to be used up
+#define RT_GATHER_CTRS 9
+#define CNT_GATHER_NEXT  (16 + 4 * RT_CTR_STRIDE)
+#define CNT_GATHER_NEXT2 (CNT_GATHER_NEXT + RT_GATHER_CTRS * RT_CTR_STRIDE)    // the same for the caustic gather
+#define CNT_RESET   (CNT_GATHER_NEXT2 + RT_GATHER_CTRS * RT_CTR_STRIDE)        // counters [0, CNT_RESET) are cleared before every pass
+#define CNT_PIXLIST (CNT_RESET + 10)   // survives the passes of a chunk
+#define CNT_TOTAL   (CNT_RESET + 12)
 
 #endif

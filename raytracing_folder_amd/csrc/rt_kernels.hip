@@ -814,7 +814,7 @@ __device__ __forceinline__ void push_ray(const ShadeCtx &C, bool pred, V3 o, V3 
                 C.qout.e[idx] = make_float4(side_dir.x, side_dir.y, side_dir.z, side_K.x);
             } else C.qout.c[idx] = make_float4(thr.z, absorb.x, absorb.y, absorb.z);
             C.qout.d[idx] = make_uint4(slot, (uint32_t)bounce | (kind << 8) | (spec << 16), node, sample);
-        } else atomicAdd(&C.W.stats[ST_QUEUE_OVERFLOW], 1ull);
+        } else atomicAdd(&C.W.stats[ST_AT(ST_QUEUE_OVERFLOW)], 1ull);
     }
 }
 
@@ -827,7 +827,7 @@ __device__ __forceinline__ void push_photon_query(const ShadeCtx &C, bool pred, 
             Q.qa[idx] = make_float4(p.x, p.y, p.z, N.x);
             Q.qb[idx] = make_float4(N.y, N.z, w.x, w.y);
             Q.qc[idx] = make_float4(w.z, __uint_as_float(slot), 0.f, 0.f);
-        } else atomicAdd(&C.W.stats[ST_QUEUE_OVERFLOW], 1ull);
+        } else atomicAdd(&C.W.stats[ST_AT(ST_QUEUE_OVERFLOW)], 1ull);
     }
 }
 
@@ -1233,8 +1233,15 @@ __device__ void shade_path(const ShadeCtx &C, const PathIn &in, bool active, con
     }
 }
 
+// The whole workgroup calls this once, at the end of its kernel.  The waves' counts meet in LDS and ONE thread per counter adds them
+// to the statistics block: a wave-level flush was 7 device-scope atomics per wave on one 128-byte line, all of them when the launch
+// drains -- 21 000 per k_wavefront launch queueing at the memory side while the kernel waits to retire (r4: 0.4 ms of the Cornell
+// frame's tracer, 0.3 of its gather).  The block's counters sit RT_STAT_STRIDE apart for the same reason (rt_dev.h).
 __device__ __forceinline__ void flush_counters(unsigned long long *stats, const Counters &c, uint32_t nprim, uint32_t nrefl, uint32_t nrefr)
 {
+    __shared__ unsigned long long s_acc[7];
+    if (threadIdx.x < 7) s_acc[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t v[7] = {c.inst, c.nodes, c.tris, c.shadow, nprim, nrefl, nrefr};
 #pragma unroll
     for (int i = 0; i < 7; i++) {
@@ -1243,13 +1250,15 @@ __device__ __forceinline__ void flush_counters(unsigned long long *stats, const 
         v[i] = x;
     }
     if (__lane_id() == 0) {
-        if (v[0]) atomicAdd(&stats[ST_INSTANCE_VISITS], (unsigned long long)v[0]);
-        if (v[1]) atomicAdd(&stats[ST_BVH_NODES], (unsigned long long)v[1]);
-        if (v[2]) atomicAdd(&stats[ST_TRIS], (unsigned long long)v[2]);
-        if (v[3]) atomicAdd(&stats[ST_RAYS_SHADOW], (unsigned long long)v[3]);
-        if (v[4]) atomicAdd(&stats[ST_RAYS_PRIMARY], (unsigned long long)v[4]);
-        if (v[5]) atomicAdd(&stats[ST_RAYS_REFLECT], (unsigned long long)v[5]);
-        if (v[6]) atomicAdd(&stats[ST_RAYS_REFRACT], (unsigned long long)v[6]);
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (v[i]) atomicAdd(&s_acc[i], (unsigned long long)v[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int slot = threadIdx.x == 0 ? ST_INSTANCE_VISITS : threadIdx.x == 1 ? ST_BVH_NODES : threadIdx.x == 2 ? ST_TRIS : threadIdx.x == 3 ? ST_RAYS_SHADOW
+                       : threadIdx.x == 4 ? ST_RAYS_PRIMARY : threadIdx.x == 5 ? ST_RAYS_REFLECT : ST_RAYS_REFRACT;
+        const unsigned long long x = s_acc[threadIdx.x];
+        if (x) atomicAdd(&stats[ST_AT(slot)], x);
     }
 }
 
@@ -1886,7 +1895,7 @@ struct GatherArgs {
     DevPhotonMap pm;
     const float4 *qa, *qb, *qc;      // query queue
     const uint32_t *count_ptr;       // number of queries (device)
-    uint32_t *next_batch;            // eight work counters (one per XCD), zero at launch
+    uint32_t *next_batch;            // zero at launch, RT_CTR_STRIDE apart: [seg] = batches handed out of XCD segment seg (8), [8] = mask of the segments used up
     uint32_t count_cap;
     int k; float radius;
     float *sample_rgb;               // mode 0: atomicAdd w * irr * max(0, N.(-dir)) into the slot
@@ -2123,20 +2132,32 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
     const uint32_t seg_len = (n_batches + 7u) / 8u;
-    uint32_t seg = xcc, seg_tried = 0;
+    uint32_t seg = xcc;
+    // A wave that finds a segment used up says so in a mask the others READ before they try it: without it every wave ends with
+    // eight failing atomics -- 41 000 of them queueing at the memory side (device-scope atomics are executed there, one after the
+    // other per channel) while nothing else is left to do.  The counters sit RT_CTR_STRIDE apart for the same reason (rt_dev.h).
+    // Measured and not kept (r4, profiles/r04_experiments.json): the last batches of a segment handed out as 8-query units, a
+    // segment handed out from its end.
     for (;;) {
-        uint32_t batch = 0;
-        if (lane == 0) batch = atomicAdd(G.next_batch + seg, 1u);
-        batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)batch);
         const uint32_t seg_first = seg * seg_len;
         const uint32_t seg_size = seg_first >= n_batches ? 0u : min(seg_len, n_batches - seg_first);
-        if (batch >= seg_size) {                               // this segment is finished: move on, or stop after all eight
-            if (++seg_tried >= 8u) break;
-            seg = (seg + 1u) & 7u;
+        uint32_t got = 0;
+        if (lane == 0) got = atomicAdd(G.next_batch + seg * RT_CTR_STRIDE, 1u);
+        got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+        if (got >= seg_size) {                               // this segment is finished: move on to one that is not known to be, or stop
+            uint32_t *const done_mask = G.next_batch + 8 * RT_CTR_STRIDE;
+            uint32_t done = 0;                               // (what this wave marked earlier is in the mask it reads: same address, program order)
+            if (lane == 0) {
+                done = __hip_atomic_load(done_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!((done >> seg) & 1u)) atomicOr(done_mask, 1u << seg);
+            }
+            done = ((uint32_t)__builtin_amdgcn_readfirstlane((int)done) | (1u << seg)) & 255u;
+            if (done == 255u) break;
+            const uint32_t rot = ((done ^ 255u) | ((done ^ 255u) << 8)) >> (seg + 1u);     // segments still open, seen from seg + 1
+            seg = (seg + 1u + ((uint32_t)__ffs((int)rot) - 1u)) & 7u;
             continue;
         }
-        batch += seg_first;
-        const uint32_t qbase = batch * (uint32_t)RT_GATHER_BATCH;
+        const uint32_t qbase = (seg_first + got) * (uint32_t)RT_GATHER_BATCH;
         const uint32_t qi = qbase + lane;
         const bool have = lane < RT_GATHER_BATCH && qi < nq;
         float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
@@ -2563,13 +2584,24 @@ __global__ __launch_bounds__(64 * RT_GATHER_WAVES) void k_gather(GatherArgs G)
             wave_sync();
         }
     }
-    if (lane == 0 && G.stats && visited) {
-        atomicAdd(&G.stats[ST_PHOTONS_VISITED], visited * (unsigned long long)RT_SUB_PHOTONS);
-        atomicAdd(&G.stats[ST_GATHER_ROUNDS], (unsigned long long)n_rounds);
-        atomicAdd(&G.stats[ST_GATHER_SLOW], (unsigned long long)n_slow);
-        atomicAdd(&G.stats[ST_GATHER_LEAF_READS], (unsigned long long)n_reads * RT_SUB_PHOTONS / 32ull);     // in units of 32 slots = 1 KiB
+    if (G.stats) {                                        // workgroup-uniform; every wave gets here (flush_counters says why it is done this way)
+        __shared__ unsigned long long s_acc[4];
+        if (threadIdx.x < 4) s_acc[threadIdx.x] = 0;
+        __syncthreads();
+        if (lane == 0 && visited) {
+            atomicAdd(&s_acc[0], visited * (unsigned long long)RT_SUB_PHOTONS);
+            atomicAdd(&s_acc[1], (unsigned long long)n_rounds);
+            atomicAdd(&s_acc[2], (unsigned long long)n_slow);
+            atomicAdd(&s_acc[3], (unsigned long long)n_reads * RT_SUB_PHOTONS / 32ull);     // in units of 32 slots = 1 KiB
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int slot = threadIdx.x == 0 ? ST_PHOTONS_VISITED : threadIdx.x == 1 ? ST_GATHER_ROUNDS : threadIdx.x == 2 ? ST_GATHER_SLOW : ST_GATHER_LEAF_READS;
+            const unsigned long long x = s_acc[threadIdx.x];
+            if (x) atomicAdd(&G.stats[ST_AT(slot)], x);
+        }
     }
-    if (G.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&G.stats[ST_PHOTON_QUERIES], (unsigned long long)nq);
+    if (G.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&G.stats[ST_AT(ST_PHOTON_QUERIES)], (unsigned long long)nq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2624,9 +2656,9 @@ __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
         // can size them from what a scene really produces instead of the 2^bounce worst case
         uint32_t pr = 0;
         for (int l = 1; l < CNT_PHOTONQ; l++) pr = max(pr, W.counts[l]);
-        atomicMax(&W.stats[ST_PEAK_RAYS], (unsigned long long)pr);
+        atomicMax(&W.stats[ST_AT(ST_PEAK_RAYS)], (unsigned long long)pr);
         // both query queues are sized from this one figure (the caustic queue gets the photon queue's capacity)
-        atomicMax(&W.stats[ST_PEAK_QUERIES], (unsigned long long)max(W.counts[CNT_PHOTONQ], W.counts[CNT_CAUSTICQ]));
+        atomicMax(&W.stats[ST_AT(ST_PEAK_QUERIES)], (unsigned long long)max(W.counts[CNT_PHOTONQ], W.counts[CNT_CAUSTICQ]));
     }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix_round; i += gridDim.x * blockDim.x) {
         const uint32_t i0 = i - (uint32_t)lane;                  // first pixel of this wave
