@@ -49,6 +49,9 @@
 // the photon loop of k_gather may contract mul+add into fma (d^2, dir.N, box distances, weighted sums; gate there: 2e-5); the rest of the
 // file stays uncontracted: hit records are bit-exact
 #define RT_FP_CONTRACT _Pragma("clang fp contract(fast)")
+#ifndef RT_WF_GRAB
+#define RT_WF_GRAB 2           // rounds of 256 primary samples (or queued rays) a workgroup of k_wavefront takes per atomic on the work counter
+#endif
 #ifndef RT_WF_PERWAVE
 #define RT_WF_PERWAVE 1        // 1: for the P12 model every wave of k_wavefront runs its own rounds on its own part of the LDS ray stack (no workgroup barriers); 0: the four waves always share stack and rounds
 #endif
@@ -1571,6 +1574,12 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
     if (threadIdx.x == 0) s_count = 0;
     C.lds_a = s_qa; C.lds_b = s_qb; C.lds_c = s_qc; C.lds_count = &s_count; C.lds_cap = (A.lds_rays && A.lds_rays < (uint32_t)Cfg::STACK) ? A.lds_rays : (uint32_t)Cfg::STACK;
     bool more_primaries = true;                           // workgroup-uniform
+    // A workgroup takes RT_WF_GRAB rounds of 256 per atomic on the work counter when the launch has plenty: the returning atomic is a
+    // round trip to the memory side with the whole workgroup at the barrier behind it (r4, pairs: -2.7 % on the 102 k-triangle frame,
+    // Cornell tracer 13.67 -> 13.35 ms with its gather 0.13 ms slower for the changed order of its queue; fours: the gather loses more).
+    // The per-wave rounds of P12 keep one round per atomic: pairs cost C3 0.9 %, fours 3 %.
+    const uint32_t grab = n_batches >= 128ull * gridDim.x ? (uint32_t)RT_WF_GRAB : 1u;
+    unsigned long long grabbed = 0; uint32_t in_hand = 0; // workgroup-uniform: the rounds this workgroup holds
     for (;;) {
         __syncthreads();                                  // last round's pushes are complete
         const uint32_t packed = s_count;
@@ -1614,9 +1623,14 @@ __attribute__((amdgpu_waves_per_eu(TEX ? RT_WF_TEX_WAVES : RT_WF_WAVES, TEX ? RT
             __syncthreads();                              // all pops read before anything is pushed over them
             if (threadIdx.x == 0) s_count = packed - (n << (16u * pside));
         } else {
-            if (threadIdx.x == 0) s_batch = atomicAdd(next_batch, 1u);
-            __syncthreads();
-            const unsigned long long batch = s_batch;
+            if (in_hand == 0) {                           // `grab` rounds per visit of the work counter
+                if (threadIdx.x == 0) s_batch = atomicAdd(next_batch, 1u);
+                __syncthreads();
+                grabbed = (unsigned long long)s_batch * grab;
+                in_hand = grab;
+            }
+            const unsigned long long batch = grabbed + (grab - in_hand);
+            in_hand--;
             if (batch >= n_batches) { more_primaries = false; continue; }
             if (A.mode == 3) {
                 const unsigned long long src = batch * RT_BLOCK + threadIdx.x;
