@@ -1181,8 +1181,10 @@ static int render_streams(uint64_t n_chunks)
     // 3: 73.5, 4: 71.7 -- a second chunk fills the first one's launch gaps and drain phases, three slots leave the
     // sixteenth chunk alone at the end, two need the least memory.  One or two whole-frame chunks (64 Mi samples): the
     // kernels are persistent grids that fill the GPU on their own and the frame is the sum of them -- a second chunk
-    // in flight only makes them share it: 1: 50.5 ms, 2: 51.2.
-    const int v = e ? atoi(e) : (n_chunks <= 2 ? 1 : 2);
+    // in flight only makes them share it: 1: 50.5 ms, 2: 51.2.  Round 4, with kernels a third faster: the drain phase of a
+    // persistent launch (its last workgroups, its overflow pass) is now worth filling with the other chunk -- Cornell frame
+    // 36.15 -> 35.64 ms, the 102 k-triangle frame 21.81 -> 20.66; four chunks of 32 Mi samples stay slower (37.2).
+    const int v = e ? atoi(e) : (n_chunks <= 1 ? 1 : 2);
     return v < 1 ? 1 : (v > RT_STREAMS ? RT_STREAMS : v);
 }
 

@@ -7,6 +7,9 @@ tag=$1; groups=$2; shift 2
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# one chunk in flight, as in the frames bench.py takes its roofline from (--profile-frames): with two, a kernel's interval in the trace
+# includes the time it shares the GPU with the other chunk's kernels (the timed frames of a default run do overlap them)
+export RT_STREAMS=${RT_STREAMS:-1}
 python3 -c "import json; from raytracing_folder_amd import buildinfo as b; json.dump({'kernel_source_sha16': b.kernel_source_sha16(), 'build_flags': b.build_flags()}, open('$out/build_id.json', 'w'))"
 run() {  # name, extra rocprof args...
   local name=$1; shift
