@@ -178,6 +178,8 @@ struct DeviceState {
     // stats: `last_done` is recorded at its join and every later call orders its own stream behind it
     hipEvent_t last_done = nullptr;
     bool last_pending = false;
+    bool last_pipelined = false;        // the render in flight ran every slot on the library's own streams (render_tiles_once)
+    uint64_t frame_seq = 0;             // rotates the slots from one pipelined frame to the next
     bool async_overflow = false;        // an asynchronous render dropped rays and nobody has collected that verdict yet (rt_render_check does)
     // How full the ray / photon-query queues of the last renders got, per sample of a chunk (device-side peaks,
     // rt_stats.peak_*): the next render of the same kind sizes its queues from that instead of the 2^bounce worst case.
@@ -1223,7 +1225,7 @@ static rt_status ensure_workspace(DeviceState *D, int slot, size_t samples, int 
     if (D->scene.max_bvh_depth > RT_BVH_LDS && (st = w.bvh_spill.ensure(SPILL_BYTES))) return st;
     if ((st = w.pixel_list.ensure(std::max<size_t>(list_pixels, 1) * 4))) return st;
     if (!D->stats.p) { if ((st = D->stats.ensure(STATS_BYTES))) return st; }
-    if (slot > 0 && !w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    if (!w.stream) HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));      // (slot 0 uses its own only in a pipelined frame)
     w.samples = samples; w.rq_cap = (uint32_t)rq_cap; w.pq_cap = (uint32_t)pq_cap;
     return RT_OK;
 }
@@ -1322,7 +1324,7 @@ static rt_status validate_render(const rt_scene *s, const rt_camera *cam, const 
 
 // DevPhotonMap::cell_start for the radius the gather is about to use: built on first use and again when a larger radius comes
 // (a table built for a radius serves every smaller one), on the stream the gather will run on
-static rt_status ensure_cell_start(DeviceState *D, bool caustic, int k, float radius, hipStream_t st)
+static rt_status ensure_cell_start(DeviceState *D, bool caustic, int k, float radius, hipStream_t st, bool *did_work = nullptr)
 {
     DevPhotonMap &pm = caustic ? D->scene.cm : D->scene.pm;
     {
@@ -1330,7 +1332,7 @@ static rt_status ensure_cell_start(DeviceState *D, bool caustic, int k, float ra
         // or radius left there is dropped, so that it cannot steer this render's choice between the (exact) gather paths
         int &hk = caustic ? D->rk2_k_c : D->rk2_k; float &hr = caustic ? D->rk2_radius_c : D->rk2_radius;
         DevBuf &b_rk = caustic ? D->ccell_rk2 : D->cell_rk2;
-        if (b_rk.p && hk != 0 && (hk != k || hr != radius)) HIP_TRY(hipMemsetAsync(b_rk.p, 0, (size_t)64 * 64 * 64 * 4, st));
+        if (b_rk.p && hk != 0 && (hk != k || hr != radius)) { HIP_TRY(hipMemsetAsync(b_rk.p, 0, (size_t)64 * 64 * 64 * 4, st)); if (did_work) *did_work = true; }
         hk = k; hr = radius;
     }
     if (pm.n_leaves < 2 || (pm.cell_start && radius <= pm.start_radius)) return RT_OK;
@@ -1339,6 +1341,7 @@ static rt_status ensure_cell_start(DeviceState *D, bool caustic, int k, float ra
     if (s) return s;
     rtk_photon_cell_start(st, pm.tbox, pm.n_leaves, pm.grid_min, pm.cell, pm.grid_dim, radius, (uint32_t *)b.p);
     HIP_TRY(hipGetLastError());
+    if (did_work) *did_work = true;
     pm.cell_start = (const uint32_t *)b.p; pm.start_radius = radius;
     return RT_OK;
 }
@@ -1466,7 +1469,24 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     // of the three classes dominates per material, so the queues are sized for a fan-out of 2 and an
     // overflow is reported as an error rather than silently dropped
     const uint64_t n_chunks = total_px ? (total_px + ppc - 1) / ppc : 0;
-    int n_slots = (int)std::min<uint64_t>(std::max<uint64_t>(n_chunks, 1), (uint64_t)render_streams(n_chunks));
+    // FRAME PIPELINING (opt-in: RT_FRAME_PIPELINE=1).  An asynchronous render behind another one that is still in flight runs all of its
+    // slots on the library's own streams and lets its tracing and gathering start at once: they touch nothing but the slot's working
+    // set, which the slot's stream already orders, and read scene tables no stream-ordered work of the caller can change.  Only
+    // k_resolve, which writes the caller's buffers, waits for what the caller's stream holds before this call (e_fork) -- the frame
+    // before it, an all-gather of its tiles, a copy of the image; frames of one chunk alternate between two slots.  What it is for:
+    // the tile exchange of a multi-GPU step sits between two frames, and this puts the next frame's rays beside it.  Why it is not the
+    // default: measured on ONE GPU (r4, profiles/r04_experiments.json) it gains nothing where there is no exchange to hide -- a rank's
+    // share at N = 2 / 4 / 8: 18.73 / 10.14 / 5.39 ms against 18.73 / 10.14 / 5.33 -- and costs the two-chunk frames their lockstep
+    // (both chunks tracing, then both gathering: Cornell 36.4 against 36.0 ms, 102 k triangles 21.75 against 20.64: a tracer and a gather
+    // side by side take each other's LDS); with an exchange beside persistent grids that leave no LDS free it is unmeasured.
+    bool pipelined = false;
+    {
+        const char *e = getenv("RT_FRAME_PIPELINE");
+        pipelined = e && atoi(e) != 0 && !sync && stats_out == nullptr && job == nullptr && D->last_pending && total_px > 0;
+    }
+    const int streams_wanted = render_streams(pipelined ? std::max<uint64_t>(n_chunks, 2) : n_chunks);
+    if (streams_wanted < 2) pipelined = false;              // RT_STREAMS=1: one chunk at a time, as asked
+    int n_slots = pipelined ? streams_wanted : (int)std::min<uint64_t>(std::max<uint64_t>(n_chunks, 1), (uint64_t)streams_wanted);
     const int fan = p->shade_model == RT_SHADE_P12 && p->hemisphere_sample > 1 ? 1 + p->hemisphere_sample : 2;
     const bool use_photons = D->scene.pm.n_leaves != 0, use_caustic = p->caustic_k > 0 && D->scene.cm.n_leaves != 0;
     const DeviceState::QueueHistory &H = D->qhist;
@@ -1546,17 +1566,29 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         HIP_TRY(stats_zero(Ws[0].stats, ST_PEAK_RAYS, 2, stream));
     }
     // the gathers' start tables are built on `stream` before the slots fork from it
-    if ((st = ensure_cell_start(D, false, p->knn_k, p->knn_radius, stream))) return st;
-    if (use_caustic && (st = ensure_cell_start(D, true, p->caustic_k, p->caustic_radius, stream))) return st;
+    bool tables_touched = false;
+    if ((st = ensure_cell_start(D, false, p->knn_k, p->knn_radius, stream, &tables_touched))) return st;
+    if (use_caustic && (st = ensure_cell_start(D, true, p->caustic_k, p->caustic_radius, stream, &tables_touched))) return st;
     // slot 0 runs on `stream` itself; the other slots' streams start after everything already queued on
     // `stream` (fork) and `stream` waits for them at the end (join), so the call keeps stream-order semantics
-    auto slot_stream = [&](int slot) { return slot == 0 ? stream : D->ws[slot].stream; };
-    if (n_slots > 1) {
-        hipEvent_t e_fork;
+    auto slot_stream = [&](int slot) { return (slot == 0 && !pipelined) ? stream : D->ws[slot].stream; };
+    hipEvent_t e_fork = nullptr;
+    struct ForkGuard { hipEvent_t &e; ~ForkGuard() { if (e) (void)hipEventDestroy(e); } } fork_guard{e_fork};
+    bool wait_at_start[RT_STREAMS];                      // the slot's stream has not been put behind e_fork yet
+    for (int i = 0; i < RT_STREAMS; i++) wait_at_start[i] = false;
+    bool resolve_waits[RT_STREAMS];
+    for (int i = 0; i < RT_STREAMS; i++) resolve_waits[i] = false;
+    if (n_slots > 1 || pipelined) {
         HIP_TRY(hipEventCreateWithFlags(&e_fork, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(e_fork, stream));
-        for (int i = 1; i < n_slots; i++) HIP_TRY(hipStreamWaitEvent(slot_stream(i), e_fork, 0));
-        (void)hipEventDestroy(e_fork);
+        for (int i = 0; i < n_slots; i++) {
+            if (i == 0 && !pipelined) continue;          // slot 0 IS `stream`
+            // pipelined: the gathers' tables were just rewritten on `stream`, or the frame before used the slots on other streams
+            // (slot 0 on the caller's): start behind everything; otherwise only this slot's k_resolve launches wait
+            if (!pipelined || tables_touched || !D->last_pipelined) wait_at_start[i] = true;
+            else resolve_waits[i] = true;
+        }
+        for (int i = 0; i < n_slots; i++) if (wait_at_start[i]) HIP_TRY(hipStreamWaitEvent(slot_stream(i), e_fork, 0));
     }
     const float inv_gamma = (float)(1.0 / p->gamma);        // powf(x, 1.0/gamma): double quotient narrowed to float
     double ms_resolve = 0;
@@ -1616,7 +1648,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     uint64_t chunk_index = 0;
     for (uint64_t q0 = 0; q0 < total_px; q0 += ppc, chunk_index++) {
         if (job && job->stop.load()) break;
-        const int slot = (int)(chunk_index % (uint64_t)n_slots);
+        const int slot = (int)((chunk_index + (pipelined ? D->frame_seq : 0)) % (uint64_t)n_slots);
         const hipStream_t cs = slot_stream(slot);
         const DevWork &W = Ws[slot];
         Timing *tmp = want_stats ? &tm[slot] : nullptr;
@@ -1631,6 +1663,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
             if (want_stats) { HIP_TRY(hipEventRecord(r1, cs)); resolve_ev.emplace_back(r0, r1); }
             return RT_OK;
         };
+        if (resolve_waits[slot]) { HIP_TRY(hipStreamWaitEvent(cs, e_fork, 0)); resolve_waits[slot] = false; }
         if ((st = timed_resolve(0))) return st;
         if (p->max_sample > p->min_sample) {
             if ((st = run_pipeline(D, slot, cs, W, *p, tmp, dc, dt, (uint32_t)q0, npix, p->min_sample,
@@ -1647,8 +1680,8 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
         }
     }
     while (job && !flight.empty()) if ((st = finish_oldest())) return st;
-    if (n_slots > 1) {
-        for (int i = 1; i < n_slots; i++) {
+    if (n_slots > 1 || pipelined) {
+        for (int i = pipelined ? 0 : 1; i < n_slots; i++) {
             hipEvent_t e_join;
             HIP_TRY(hipEventCreateWithFlags(&e_join, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(e_join, slot_stream(i)));
@@ -1660,6 +1693,7 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     if (sync || want_stats) {
         HIP_TRY(hipStreamSynchronize(stream));
         D->last_pending = false;
+        D->last_pipelined = false;
         {
             // a dropped ray or photon query means a wrong image: never RT_OK, whether or not statistics were asked for
             unsigned long long tail[ST_COUNT - ST_QUEUE_OVERFLOW];
@@ -1680,6 +1714,8 @@ static rt_status render_tiles_once(rt_scene *s, const rt_camera *cam, const rt_p
     } else {
         HIP_TRY(hipEventRecord(D->last_done, stream));
         D->last_pending = true;
+        D->last_pipelined = pipelined;
+        if (pipelined) D->frame_seq += n_chunks;
     }
     if (want_stats) {
         rt_stats R;

@@ -1052,6 +1052,49 @@ def test_async_device_renders_keep_stream_order(cornell, monkeypatch):
     assert (np.abs(rgb_copy.cpu().numpy().astype(int) - ref.astype(int)) <= 1).all()
 
 
+@pytest.mark.parametrize("chunk", [None, "16384"])
+def test_pipelined_frames_stay_behind_the_callers_stream(cornell, monkeypatch, chunk):
+    """Frame pipelining (rt_api.cpp, render_tiles_once): an asynchronous frame behind one that is still in flight traces and gathers
+    at once on the library's streams, but its k_resolve -- the only kernel that writes the caller's buffers -- waits for everything the
+    caller's stream held before the call.  Six frames from two alternating cameras go into the SAME buffers; behind each one the stream
+    first does slow work of its own and then copies the image.  Every copy must hold exactly its own frame (the next frame may not
+    overwrite it early, the copy may not see a half-finished one).  One chunk per frame (the slots alternate from frame to frame) and
+    many chunks per frame."""
+    import torch
+    monkeypatch.setenv("RT_FRAME_PIPELINE", "1")              # opt-in (measured: no gain on one GPU; meant for the multi-GPU step)
+    if chunk:
+        monkeypatch.setenv("RT_CHUNK_SAMPLES", chunk)
+    s, cam_a = scenes.load_cornell(160, 120)
+    _, cam_b = scenes.load_cornell(160, 120)
+    cam_b.pos[0] += 6.0
+    cam_b.pos[2] += 3.0
+    s.set_photons(photons.synth_cornell_photon_map(20000, seed=3))
+    p = capi.default_params(min_sample=4, max_sample=4, threshold=-1.0)
+    refs = [s.render(c, p)[:2] for c in (cam_a, cam_b)]
+    assert (refs[0][1] != refs[1][1]).mean() > 0.2            # the two frames really differ
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    rgb = torch.zeros((120, 160, 3), dtype=torch.uint8, device=dev)
+    z = torch.zeros((120, 160), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((120, 160), dtype=torch.uint8, device=dev)
+    busy = torch.randn((2048, 2048), device=dev)
+    snaps = []
+    with torch.cuda.stream(side):
+        for i in range(6):
+            cam = cam_a if i % 2 == 0 else cam_b
+            s.render_tiles_device(cam, p, capi.TileRange(32, 8, 0, 1), 0, rgb.data_ptr(), z.data_ptr(), cnt.data_ptr(),
+                                  stream=side.cuda_stream, sync=False, want_stats=False)
+            for _ in range(8):
+                busy = (busy @ busy).clamp_(-1.0, 1.0)       # the caller's own work between the frame and its copy
+            snaps.append((rgb.clone(), z.clone()))
+    side.synchronize()
+    s.render_check(0)
+    for i, (c_rgb, c_z) in enumerate(snaps):
+        ref, zref = refs[i % 2]
+        assert (c_z.cpu().numpy() == zref).all(), i
+        assert (np.abs(c_rgb.cpu().numpy().astype(int) - ref.astype(int)) <= 1).all(), i
+
+
 def test_packed_tile_render_and_hip_unpack_match_the_torch_reference():
     """Multi-GPU step without Python packing: every "rank" (here one after the other on one GPU) renders its
     interleaved tiles straight into its all-gather contribution; the packed bytes equal what the torch helper
