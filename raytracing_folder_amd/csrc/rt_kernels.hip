@@ -2652,7 +2652,9 @@ __device__ __forceinline__ uint8_t float_to_byte(float r)
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+#ifndef RT_RESOLVE_TILE
 #define RT_RESOLVE_TILE 8            // samples per pixel staged through LDS at a time
+#endif
 __global__ __launch_bounds__(256) void k_resolve(DevWork W, ResolveArgs A)
 {
     // A pixel's samples are contiguous (max_sample slots of 12 B), so a thread walking its own pixel reads 12 B
