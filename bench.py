@@ -280,11 +280,12 @@ def parity_check(kept, frame):
     return out
 
 
-def profile_figures(default_workload):
+def profile_figures(workload_tag):
     """What cannot be read from inside bench.py -- HBM bytes (FETCH_SIZE / WRITE_SIZE) and VALU instructions (SQ_INSTS_VALU)
-    per launch -- from the NEWEST committed counter summaries (profiles/r*_bench_pmc_hbm.json, r*_bench_sq_counters.json:
+    per launch -- from the NEWEST committed counter summaries (profiles/r*<tag>_bench_pmc_hbm.json, r*<tag>_bench_sq_counters.json:
     separate rocprofv3 --pmc passes of this very command, condensed by tools_profile_summary.py, gfx950 x2 fetch
-    correction applied).  Only quoted for the default workload they were measured on, and only for the kernel build they
+    correction applied; tag "" = the headline, "_balls" = the 102 k-triangle frame at 256 spp, "_gi" = C3).  Only quoted for the
+    exact workload they were measured on (workload_tag None: nothing is quoted), and only for the kernel build they
     were measured on: each summary carries the hash of the kernel sources + build flags of its run (`kernel_source_sha16`);
     when that differs from the build in this tree, or the live launch time of a kernel differs from the file's by more than
     5 %, the figures are reported as STALE instead of quoted (main() then emits frac: null, stale_profile: true)."""
@@ -292,12 +293,12 @@ def profile_figures(default_workload):
     from raytracing_folder_amd import buildinfo
     out = {"hbm": {}, "hbm_launches": {}, "valu_insts": {}, "l1_accesses": {}, "file_launch_us": {}, "hbm_source": None, "valu_source": None,
            "build": buildinfo.kernel_source_sha16(), "stale": []}
-    if not default_workload:
+    if workload_tag is None:
         return out
     for key, pat in (("hbm", "_bench_pmc_hbm.json"), ("valu", "_bench_sq_counters.json")):
         # tags of the headline workload carry no workload suffix: r03v_bench_..., not r03v_balls_bench_...
         import re
-        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*" + pat)) if re.match(r"^r\d+[a-z]*" + re.escape(pat) + "$", os.path.basename(f)))
+        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*" + pat)) if re.match(r"^r\d+[a-z]*" + re.escape(workload_tag + pat) + "$", os.path.basename(f)))
         if not files:
             continue
         try:
@@ -470,8 +471,14 @@ def main():
             assert all(x["streams"] == 1 for x in prof)
             n = float(len(prof))
             P = {k: sum(float(x[k]) for x in prof) / n for k in prof[0]}          # per-frame averages of rank 0's share
-            figs = profile_figures((a.workload, a.width, a.height, a.spp, a.photons, a.synthetic_photons, world) ==
-                                   ("cornell", 1920, 1080, 64, 1000000, False, 1))
+            # the counter summaries under profiles/ belong to three exact commands: the headline, the 102 k-triangle frame at its
+            # stated 256 spp, and C3
+            prof_tag = None
+            if world == 1 and not a.synthetic_photons:
+                if (a.workload, a.width, a.height, a.spp, a.photons) == ("cornell", 1920, 1080, 64, 1000000): prof_tag = ""
+                elif (a.workload, a.width, a.height, a.spp) == ("balls", 1920, 1080, 256): prof_tag = "_balls"
+                elif (a.workload, a.width, a.height, a.spp) == ("gi", 800, 600, 64): prof_tag = "_gi"
+            figs = profile_figures(prof_tag)
             p_rays = P["rays_primary"] + P["rays_shadow"] + P["rays_reflect"] + P["rays_refract"]
             classes = {
                 # algorithmic bytes: SURVEY.md section 8(d) / BASELINE.md section 3.4; l2 bytes: what the kernel asks its
